@@ -1,0 +1,198 @@
+// csam_gemm_f16: C[M,N] = epilogue(A[M,K] * W[N,K]^T)  -- fp16 operands, fp32 MFMA accumulate.
+//
+// Replaces every nn.Linear / 1x1 conv / im2col'd conv on the hot path of the reference
+// (segment_anything_cs/modeling/image_encoder.py:227,238 qkv/proj; common.py:25-26 MLP;
+// image_encoder.py:88-104 neck; transformer.py:228-254 decoder projections;
+// mask_decoder.py:56-62 ConvTranspose2d as GEMM).  W is the PyTorch Linear layout [N,K],
+// so both operands are K-contiguous ("B^T input").
+//
+// CDNA4 design (cdna_hip_programming.md §5, step-3 structure):
+//   * 128x128x64 tile, 256 threads = 4 waves in a 2x2 grid, each wave owns 64x64 = 4x4 MFMA
+//     16x16x32 f16 tiles (16 floatx4 accumulators).
+//   * operands staged HBM->LDS by global_load_lds (16 B/lane, no VGPR round trip), double
+//     buffered, one barrier per K tile.
+//   * LDS image is lane-linear (glds constraint), so the bank-conflict XOR swizzle
+//     (chunk ^= row&7 within a 128-B row) is applied to the per-lane SOURCE address and again
+//     on the ds_read_b128 fragment reads (rule 21: both sides or neither).
+//   * MFMA is issued "swapped" (W rows as the A operand, activation rows as B) so that each
+//     lane ends up with 4 consecutive N columns of one output row -> 8/16-byte stores.
+//   * epilogue fused: +bias[n], GELU(erf)/ReLU, *colscale[n] (DINOv2 LayerScale),
+//     +residual[m,n] (f16 or f32), cast to f16 or f32.
+#include "csam_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+struct GemmArgs {
+  const half_t* A; long lda;
+  const half_t* W; long ldw;
+  void* C; long ldc; int c_dt;
+  const float* bias;
+  const float* colscale;
+  const void* R; long ldr; int r_dt;
+  int act;
+  int M, N, K;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [stage][A|W][128 rows][128 B]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bn0 = blockIdx.x * BN;
+  const int bm0 = blockIdx.y * BM;
+
+  // ---- staging addresses: wave w, instr i covers tile rows (w*4+i)*8 .. +7
+  const int srow = lane >> 3;            // row within the 8-row group
+  const int sslot = lane & 7;            // 16-B slot in the 128-B LDS row
+  const half_t* a_src[4];
+  const half_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + srow;
+    const int chunk = sslot ^ (row & 7);
+    int gm = bm0 + row;
+    gm = gm < p.M ? gm : p.M - 1;        // clamp: rows past M are loaded but never stored
+    a_src[i] = p.A + (long)gm * p.lda + chunk * 8;
+    w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    char* abase = smem + buf * 2 * TILE_BYTES;
+    char* wbase = abase + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int grp = (wave * 4 + i) * 1024;   // wave-uniform LDS base of this 1-KiB piece
+      glds16(a_src[i] + k0, abase + grp);
+      glds16(w_src[i] + k0, wbase + grp);
+    }
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read offsets (bytes within a tile), swizzled
+  const int fr = lane & 15, fg = lane >> 4;
+  int a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = (wm * 64 + i * 16 + fr) * 128;
+    w_off[i] = (wn * 64 + i * 16 + fr) * 128;
+  }
+  const int sw = fr & 7;  // row&7 (tile-row offsets are multiples of 16)
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const char* abase = smem + cur * 2 * TILE_BYTES;
+    const char* wbase = abase + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + fg) ^ sw) << 4;
+      half8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const half8_t*)(abase + a_off[i] + coff);
+        wf[i] = *(const half8_t*)(wbase + w_off[i] + coff);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = fr][n = fg*4 + j] of each 16x16 tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = bn0 + wn * 64 + ni * 16 + fg * 4;
+      floatx4 v = acc[mi][ni];
+      if (p.bias) {
+        const floatx4 b = *(const floatx4*)(p.bias + n);
+        v += b;
+      }
+      if (p.act != CSAM_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = csam_apply_act(v[j], p.act);
+      }
+      if (p.colscale) {
+        const floatx4 s = *(const floatx4*)(p.colscale + n);
+        v *= s;
+      }
+      if (p.R) {
+        if (p.r_dt == CSAM_DT_F32) {
+          const floatx4 r = *(const floatx4*)((const float*)p.R + (long)m * p.ldr + n);
+          v += r;
+        } else {
+          const half4_t r = *(const half4_t*)((const half_t*)p.R + (long)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+      }
+      if (p.c_dt == CSAM_DT_F32) {
+        *(floatx4*)((float*)p.C + (long)m * p.ldc + n) = v;
+      } else {
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
+        *(half4_t*)((half_t*)p.C + (long)m * p.ldc + n) = h;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* W, long ldw,
+                             void* C, long ldc, int c_dtype, const float* bias,
+                             const float* colscale, const void* residual, long ldr, int r_dtype,
+                             int act, int M, int N, int K) {
+  CSAM_REQUIRE(A && W && C, "csam_gemm_f16: null operand");
+  CSAM_REQUIRE(M > 0 && N > 0 && K > 0, "csam_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
+  CSAM_REQUIRE(N % BN == 0, "csam_gemm_f16: N=%d must be a multiple of %d", N, BN);
+  CSAM_REQUIRE(K % BK == 0, "csam_gemm_f16: K=%d must be a multiple of %d", K, BK);
+  CSAM_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "csam_gemm_f16: ld alignment");
+  CSAM_REQUIRE(!residual || ldr % 4 == 0, "csam_gemm_f16: ldr alignment");
+  CSAM_REQUIRE(c_dtype == CSAM_DT_F16 || c_dtype == CSAM_DT_F32, "csam_gemm_f16: c_dtype");
+  GemmArgs p;
+  p.A = (const half_t*)A; p.lda = lda;
+  p.W = (const half_t*)W; p.ldw = ldw;
+  p.C = C; p.ldc = ldc; p.c_dt = c_dtype;
+  p.bias = bias; p.colscale = colscale;
+  p.R = residual; p.ldr = ldr; p.r_dt = r_dtype;
+  p.act = act; p.M = M; p.N = N; p.K = K;
+  dim3 grid(N / BN, csam_cdiv(M, BM));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        4 * TILE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_f16_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
+  CSAM_LAUNCH_CHECK("csam_gemm_f16");
+  return CSAM_OK;
+}
