@@ -1,0 +1,248 @@
+"""AUTHORING-CONTAINER ONLY: run the *reference itself* (imported in place from /root/reference)
+on seeded inputs and write the golden vectors committed under tests/golden/.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
+
+Inputs are all derivable from seeds (crowdsam_amd/synth.py weights, RandomState images), so the
+fixtures hold expected OUTPUTS only (strided samples + checksums where the tensor is large).
+Tier O1 (zero-shim): modeling.*, build_sam._build_sam, utils.amg.*.
+Tier O2 (shimmed): predictor.py + crowdsam/model.py end-to-end, with stand-ins (ours) for
+torchvision / cv2 / loguru / pycocotools and a stand-in DINO -- pins the reference-owned control
+flow (EPS loop, selection, filters), not the third-party arithmetic.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crowdsam_amd import synth  # noqa: E402
+from oracle import ref_import, pipeline_oracle as po  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+TEST_ARCH = "vit_test128"
+
+
+def load_ref_sam(arch, n_class=1, seed=0):
+    modeling, build, amg = ref_import.load_modeling()
+    D, depth, heads, gidx = synth.SAM_CONFIGS[arch]
+    sam = build._build_sam(D, depth, heads, n_class, list(gidx))
+    sd = synth.make_sam_state_dict(arch, n_class, seed)
+    sam.load_state_dict(sd, strict=True)
+    sam.eval()
+    return sam, sd, amg
+
+
+def golden_encoder():
+    sam, sd, _ = load_ref_sam(TEST_ARCH)
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+    with torch.no_grad():
+        y = sam.image_encoder(x)
+    np.savez_compressed(os.path.join(OUT, "encoder_test128.npz"),
+                        sample=y[:, ::4, ::4, ::4].numpy(), sum=np.float64(y.double().sum()),
+                        abs_sum=np.float64(y.double().abs().sum()))
+    print("encoder", y.shape, float(y.abs().mean()))
+
+
+def decoder_inputs():
+    rs = np.random.RandomState(11)
+    emb = torch.from_numpy(rs.standard_normal((1, 256, 64, 64)).astype(np.float32))
+    dino = torch.from_numpy(rs.standard_normal((1, 73, 73, 1024)).astype(np.float32))
+    pts = rs.randint(0, 1024, size=(5, 1, 2)).astype(np.float64)
+    return emb, dino, pts
+
+
+def golden_decoder():
+    sam, sd, _ = load_ref_sam(TEST_ARCH)
+    emb, dino, pts = decoder_inputs()
+    coords = torch.as_tensor(pts)
+    labels = torch.ones(5, 1, dtype=torch.int)
+    with torch.no_grad():
+        sparse, dense = sam.prompt_encoder(points=(coords, labels), boxes=None, masks=None)
+        pe = sam.prompt_encoder.get_dense_pe()
+        low, iou, cls = sam.mask_decoder(image_embeddings=emb, image_pe=pe,
+                                         sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                         multimask_output=True, dino_feats=dino)
+        m1 = sam.postprocess_masks(low, (1024, 768), (1024, 768))
+        m2 = sam.postprocess_masks(low, (683, 1024), (682, 1023))   # trap 9: 1023-side original
+        fg = torch.nn.functional.interpolate(
+            sam.mask_decoder.point_classifier(sam.mask_decoder.dino_proj(dino)).permute(0, 3, 1, 2),
+            (256, 256), mode="bilinear")
+    np.savez_compressed(os.path.join(OUT, "decoder_test128.npz"),
+                        sparse=sparse.numpy(), dense_pe_sample=pe[:, ::8, ::4, ::4].numpy(),
+                        low_sample=low[:, :, ::8, ::8].numpy(), low_sum=low.double().sum((2, 3)).numpy(),
+                        iou=iou.numpy(), cls=cls.numpy(),
+                        post1_sample=m1[:, :, ::32, ::32].numpy(), post2_sample=m2[:, :, ::31, ::31].numpy(),
+                        fg_sample=fg[:, :, ::8, ::8].numpy())
+    print("decoder", low.shape, iou.flatten()[:4], cls.flatten()[:4])
+
+
+def golden_amg():
+    _, _, amg = ref_import.load_modeling()
+    rs = np.random.RandomState(5)
+    logits = torch.from_numpy((rs.standard_normal((6, 40, 56)) * 2).astype(np.float32))
+    # smooth a little so there are real runs
+    logits = torch.nn.functional.avg_pool2d(logits[None], 5, 1, 2)[0] * 3
+    logits[4] = -5.0   # empty mask
+    logits[5] = 5.0    # full mask
+    stab = amg.calculate_stability_score(logits, 0.0, 1.0)
+    masks = logits > 0
+    boxes = amg.batched_mask_to_box(masks)
+    rles = amg.mask_to_rle_pytorch(masks)
+    crop = amg.generate_crop_boxes((445, 640), 2, 0.341)
+    md = amg.MaskData(a=torch.arange(6), b=np.arange(6) * 2, c=list("abcdef"))
+    md.filter(torch.tensor([True, False, True, True, False, True]))
+    np.savez_compressed(os.path.join(OUT, "amg.npz"), stab=stab.numpy(), boxes=boxes.numpy(),
+                        rle_counts=np.array([np.array(r["counts"]) for r in rles], dtype=object),
+                        crop_boxes=np.array(crop[0]), crop_layers=np.array(crop[1]),
+                        md_a=md["a"].numpy(), md_b=md["b"], md_c=np.array(md["c"]))
+    print("amg", stab, boxes[:2])
+
+
+# ------------------------------------------------------------------------------------------------
+# Tier O2: full CrowdSAM.generate with stand-ins
+# ------------------------------------------------------------------------------------------------
+def _install_shims():
+    from PIL import Image
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvo = types.ModuleType("torchvision.ops")
+    tvb = types.ModuleType("torchvision.ops.boxes")
+
+    def to_pil_image(a):
+        return Image.fromarray(a)
+
+    def resize(img, size):
+        return img.resize((size[1], size[0]), Image.BILINEAR)
+
+    tvf.resize, tvf.to_pil_image = resize, to_pil_image
+
+    def batched_nms(boxes, scores, idxs, iou_threshold):
+        assert int(idxs.abs().sum()) == 0
+        return po.nms(boxes, scores, iou_threshold)
+
+    def box_area(b):
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    tvb.batched_nms, tvb.box_area = batched_nms, box_area
+    tvo.boxes = tvb
+    tvo.box_iou = lambda a, b: None
+    tvo.batched_nms = batched_nms
+    tvt.functional = tvf
+    for n in ("Compose", "Resize", "ToTensor", "Normalize"):
+        setattr(tvt, n, object)
+    tv.transforms, tv.ops = tvt, tvo
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf, "torchvision.ops": tvo,
+                        "torchvision.ops.boxes": tvb})
+
+    cv2 = types.ModuleType("cv2")
+
+    def cv_resize(img, wh):
+        assert (img.shape[1], img.shape[0]) == tuple(wh), "goldens use pre-sized images"
+        return img.copy()
+
+    def cc(working, conn):
+        from scipy import ndimage
+        assert conn == 8
+        regions, n = ndimage.label(working, structure=np.ones((3, 3), dtype=np.uint8))
+        sizes = np.bincount(regions.reshape(-1), minlength=n + 1)
+        stats = np.zeros((n + 1, 5), dtype=np.int64)
+        stats[:, -1] = sizes
+        return n + 1, regions, stats, None
+
+    cv2.resize, cv2.connectedComponentsWithStats = cv_resize, cc
+    sys.modules["cv2"] = cv2
+
+    lg = types.ModuleType("loguru")
+
+    class _L:
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+
+    lg.logger = _L()
+    sys.modules["loguru"] = lg
+
+    pct = types.ModuleType("pycocotools")
+    pcm = types.ModuleType("pycocotools.mask")
+    pcm.frPyObjects = lambda rle, h, w: {"size": [h, w], "counts": po.coco_rle_string(rle["counts"]).encode()}
+    pct.mask = pcm
+    sys.modules.update({"pycocotools": pct, "pycocotools.mask": pcm})
+    for n in ("matplotlib", "matplotlib.pyplot"):
+        if n not in sys.modules:
+            try:
+                __import__(n)
+            except Exception:
+                sys.modules[n] = types.ModuleType(n)
+    torch.Tensor.cuda = lambda self, *a, **k: self   # trap 2
+
+
+class StandInDino:
+    """Seeded stand-in for DINOv2 (source not under /root/reference): a fixed random projection of
+    14x14 mean-pooled patches, so the features still depend on the image deterministically."""
+
+    def __init__(self, seed=1):
+        rs = np.random.RandomState(seed)
+        self.w = torch.from_numpy(rs.standard_normal((3, 1024)).astype(np.float32))
+        self.b = torch.from_numpy(rs.standard_normal((5329, 1024)).astype(np.float32))
+
+    def forward_features(self, x):
+        p = torch.nn.functional.avg_pool2d(x, 14, 14)            # [1,3,73,73]
+        t = p.flatten(2).transpose(1, 2) @ self.w + self.b      # [1,5329,1024]
+        return {"x_norm_patchtokens": t}
+
+    def __call__(self, x):
+        return self.forward_features(x)["x_norm_patchtokens"]
+
+    def to(self, *a, **k):
+        return self
+
+
+PIPE_CFG = dict(grid_size=8, pos_sim_thresh=-1.0, points_per_batch=8, max_prompts=24,
+                pred_iou_thresh=0.4, stability_score_thresh=0.004, filter_thresh=0.45,
+                min_mask_region_area=30, box_nms_thresh=1.0, crop_nms_thresh=1.0)
+
+
+def pipeline_image():
+    return synth.synthetic_crowd_frame(3, size=1024, n_ellipses=60)[:768]   # 768 x 1024 (h x w)
+
+
+def golden_pipeline():
+    import importlib
+    _install_shims()
+    ref_import.load_modeling()
+    predictor_mod = importlib.import_module("segment_anything_cs.predictor")
+    sys.path.insert(0, ref_import.REF)
+    model_mod = importlib.import_module("crowdsam.model")
+    sys.path.remove(ref_import.REF)
+    sam, sd, _ = load_ref_sam(TEST_ARCH)
+    predictor = predictor_mod.SamPredictor(sam, StandInDino())
+    cs = object.__new__(model_mod.CrowdSAM)
+    cfg = dict(po.DEFAULT_TEST_CFG)
+    cfg.update(PIPE_CFG)
+    cs.device = torch.device("cpu")
+    cs.train_free = False
+    cs.predictor = predictor
+    for k, v in cfg.items():
+        setattr(cs, k, v)
+    np.random.seed(42)
+    img = pipeline_image()
+    with torch.no_grad():
+        out = cs.generate(img)
+    res = {k: out[k] for k in ("boxes", "scores", "categories", "points", "stability_score")}
+    rle_counts = np.array([r["counts"] for r in out["rles"]], dtype=object)
+    np.savez_compressed(os.path.join(OUT, "pipeline_test128.npz"), rle_counts=rle_counts, **res)
+    print("pipeline", {k: v.shape for k, v in res.items()}, out["scores"][:5])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["amg", "decoder", "encoder", "pipeline"]
+    for w in which:
+        globals()["golden_" + w]()
