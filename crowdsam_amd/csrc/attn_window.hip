@@ -1,0 +1,208 @@
+// csam_win_attn: ViTDet 14x14 windowed attention with decomposed relative position bias.
+//
+// Reference: segment_anything_cs/modeling/image_encoder.py:224-240 (Attention.forward),
+// :243-289 (window_partition/unpartition), :325-361 (add_decomposed_rel_pos).
+//
+// One workgroup (4 waves) per (window, head).  The window gather/scatter is folded into the loads
+// and stores: qkv is the token-major [4096, 3*D] GEMM output over the 64x64 grid, and the 6 padded
+// rows/cols of the edge windows are synthesised in-kernel -- after LayerNorm the pad tokens are
+// zero, so their q/k/v equal the qkv bias (SURVEY.md trap 4: pad tokens ARE real keys, not masked).
+//
+// Relative-position bias without a materialised [196,196] add: S = scale*(q.k) + Th[q,kh] + Tw[q,kw]
+// is evaluated as ONE MFMA contraction over an extended K dimension
+//     [ q (64) | Th/scale hi (14) | Tw/scale hi (14) | Th/scale lo (14) | Tw/scale lo (14) | 0 (8) ]
+//   x [ k (64) | onehot(kh)       | onehot(kw)       | onehot(kh)       | onehot(kw)       | 0     ]
+// with Th[q,kh] = q . rel_pos_h[qh-kh+13] (unscaled q, image_encoder.py:349-359) split into
+// fp16 hi+lo parts so the bias keeps ~22 bits.  The one-hot key fragments are generated in
+// registers.  Softmax runs in the "swapped" MFMA orientation (keys on the accumulator rows) so a
+// lane owns 4 keys x 13 tiles of ONE query: row max/sum are in-lane plus two cross-lane shuffles.
+// P is converted to fp16 in registers and fed straight back as the B operand of P.V with V held
+// transposed in LDS.
+#include "csam_common.h"
+
+namespace {
+
+constexpr int WS = 14, NTOK = 196, NPAD = 208;      // 13 tiles of 16
+constexpr int QE_LD = 136;                          // halfs per Qe row: 128 + 8 pad (272 B)
+constexpr int KE_LD = 72;                           // halfs per K row: 64 + 8 pad (144 B)
+constexpr int VT_LD = 232;                          // halfs per Vt row: 224 + 8 pad (464 B)
+constexpr int QE_BYTES = NPAD * QE_LD * 2;          // 56576
+constexpr int KE_BYTES = NPAD * KE_LD * 2;          // 29952
+constexpr int VT_BYTES = 64 * VT_LD * 2;            // 29696
+constexpr int SMEM_BYTES = QE_BYTES + KE_BYTES + VT_BYTES;
+
+__global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict__ qkv,
+                                                       const float* __restrict__ qkv_bias,
+                                                       const float* __restrict__ rel_h,
+                                                       const float* __restrict__ rel_w,
+                                                       half_t* __restrict__ out, int D, int nH,
+                                                       float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Qe = (half_t*)smem;
+  half_t* Ke = (half_t*)(smem + QE_BYTES);
+  half_t* Vt = (half_t*)(smem + QE_BYTES + KE_BYTES);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int head = blockIdx.x % nH, win = blockIdx.x / nH;
+  const int wy = win / 5, wx = win % 5;
+  const long ld = 3L * D;
+
+  // ---- stage q, k (row-major) and v (transposed); pad tokens take the bias values
+  for (int it = tid; it < NPAD * 3 * 8; it += 256) {
+    const int i = it / 24, r = it % 24, which = r >> 3, ch = r & 7;
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < NTOK) {
+      const int y = wy * WS + i / WS, x = wx * WS + i % WS;
+      const int col = which * D + head * 64 + ch * 8;
+      if (y < 64 && x < 64) {
+        v = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)qkv_bias[col + e];
+      }
+    }
+    if (which == 0) {
+      *(half8_t*)(Qe + i * QE_LD + ch * 8) = v;
+    } else if (which == 1) {
+      *(half8_t*)(Ke + i * KE_LD + ch * 8) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VT_LD + i] = v[e];
+    }
+  }
+  // zero the key columns 208..231 of Vt (keys 196..207 were zero-filled above)
+  for (int it = tid; it < 64 * 24; it += 256) Vt[(it / 24) * VT_LD + NPAD + it % 24] = (half_t)0.f;
+  __syncthreads();
+
+  // ---- rel-pos extension columns of Qe: [64..77] Th hi, [78..91] Tw hi, [92..105] Th lo,
+  //      [106..119] Tw lo, [120..127] zero.  Values are T/scale so that S = scale * acc.
+  const float inv_scale = 1.0f / scale;
+  for (int it = tid; it < NPAD * 28; it += 256) {
+    const int i = it / 28, j = it % 28;
+    float t = 0.f;
+    if (i < NTOK) {
+      const int qh = i / WS, qw = i % WS;
+      const float* R = (j < WS) ? rel_h + (qh - j + WS - 1) * 64 : rel_w + (qw - (j - WS) + WS - 1) * 64;
+      const half_t* q = Qe + i * QE_LD;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) t += (float)q[c] * R[c];
+      t *= inv_scale;
+    }
+    const half_t hi = (half_t)t;
+    const half_t lo = (half_t)(t - (float)hi);
+    Qe[i * QE_LD + 64 + j] = hi;
+    Qe[i * QE_LD + 92 + j] = lo;
+  }
+  for (int it = tid; it < NPAD * 8; it += 256) Qe[(it >> 3) * QE_LD + 120 + (it & 7)] = (half_t)0.f;
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const float sl2 = scale * 1.4426950408889634f;  // work in base 2
+
+  for (int rt = wave; rt < 13; rt += 4) {
+    half8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(Qe + (rt * 16 + fr) * QE_LD + (ks * 4 + fg) * 8);
+
+    floatx4 p[14];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt) {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int key = kt * 16 + fr;          // the key this lane supplies as an A-operand row
+      const half_t* kr = Ke + key * KE_LD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8_t kf = *(const half8_t*)(kr + (ks * 4 + fg) * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], acc, 0, 0, 0);
+      }
+      const int kh = key / WS, kw = key % WS;
+      const bool kvalid = key < NTOK;
+#pragma unroll
+      for (int ks = 2; ks < 4; ++ks) {
+        half8_t kf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = (ks - 2) * 32 + fg * 8 + e;
+          const bool one = kvalid && (c == kh || c == 14 + kw || c == 28 + kh || c == 42 + kw);
+          kf[e] = one ? (half_t)1.0f : (half_t)0.0f;
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], acc, 0, 0, 0);
+      }
+      // lane now holds S_raw[key = kt*16 + fg*4 + j][query = rt*16 + fr]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kt * 16 + fg * 4 + j;
+        const float s = (kk < NTOK) ? acc[j] * sl2 : -INFINITY;
+        acc[j] = s;
+        mx = fmaxf(mx, s);
+      }
+      p[kt] = acc;
+    }
+    p[13] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 14; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = exp2f(p[kt][j] - mx);
+        p[kt][j] = e;
+        sum += e;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    half8_t pf[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[s][e] = (half_t)p[2 * s][e];
+        pf[s][4 + e] = (half_t)p[2 * s + 1][e];
+      }
+    }
+    const int qi = rt * 16 + fr;
+    const int y = wy * WS + qi / WS, x = wx * WS + qi % WS;
+    const bool store = qi < NTOK && y < 64 && x < 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      floatx4 o = {0.f, 0.f, 0.f, 0.f};
+      const half_t* vr = Vt + (dt * 16 + fr) * VT_LD + fg * 4;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        const half4_t v0 = *(const half4_t*)(vr + 32 * s);
+        const half4_t v1 = *(const half4_t*)(vr + 32 * s + 16);
+        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s], o, 0, 0, 0);
+      }
+      if (store) {
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[j] * inv);
+        *(half4_t*)(out + (long)(y * 64 + x) * D + head * 64 + dt * 16 + fg * 4) = h;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias,
+                             const float* rel_pos_h, const float* rel_pos_w, void* out_f16, int D,
+                             int nH, float scale) {
+  CSAM_REQUIRE(qkv_f16 && qkv_bias && rel_pos_h && rel_pos_w && out_f16, "csam_win_attn: null pointer");
+  CSAM_REQUIRE(nH > 0 && D == nH * 64, "csam_win_attn: head_dim must be 64 (D=%d nH=%d)", D, nH);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)win_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(win_attn_kernel, dim3(25 * nH), dim3(256), SMEM_BYTES, (hipStream_t)stream,
+                     (const half_t*)qkv_f16, qkv_bias, rel_pos_h, rel_pos_w, (half_t*)out_f16, D, nH, scale);
+  CSAM_LAUNCH_CHECK("csam_win_attn");
+  return CSAM_OK;
+}

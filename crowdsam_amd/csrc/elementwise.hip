@@ -1,0 +1,235 @@
+// HBM-bound helper kernels of the encoder path: LayerNorm, im2col (SAM 16x16 patches, DINOv2 14x14
+// patches with the fused 1024->1022 bilinear resample, 3x3 neck conv), casts/adds.
+// All are pure streaming kernels: 16-byte vector accesses, one wave per row for the reductions.
+#include "csam_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (nn.LayerNorm, and LayerNorm2d on token-major NHWC data):
+// reference image_encoder.py:168,180 (eps 1e-6), common.py:38-43, transformer.py norms (eps 1e-5).
+// One wave per row, D % 4 == 0, D <= 1280.  Two-pass (mean, centred variance) in registers.
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, long ldx,
+                                                        TO* __restrict__ y, long ldy,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int D,
+                                                        float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nchunk = D >> 2;
+  constexpr int MAXC = 5;
+  floatx4 v[MAXC];
+  const TI* xr = x + (long)row * ldx;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      if constexpr (sizeof(TI) == 4) {
+        v[j] = *(const floatx4*)(xr + c * 4);
+      } else {
+        const half4_t h = *(const half4_t*)(xr + c * 4);
+        v[j] = floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  const float mean = csam_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(csam_wave_sum(q) / (float)D + eps);
+  TO* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      const floatx4 g = *(const floatx4*)(gamma + c * 4);
+      const floatx4 b = *(const floatx4*)(beta + c * 4);
+      floatx4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];
+      if constexpr (sizeof(TO) == 4) {
+        *(floatx4*)(yr + c * 4) = o;
+      } else {
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)o[e];
+        *(half4_t*)(yr + c * 4) = h;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM patch-embed im2col with fused Sam.preprocess (sam.py:163-173): normalise with mean/std in
+// fp32, zero-pad bottom/right to 1024^2, emit A[4096, 768] f16 with k = c*256 + dy*16 + dx so the
+// conv weight [D,3,16,16] is used as the [D,768] GEMM operand unchanged (image_encoder.py:387-395).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sam_im2col_kernel(const float* __restrict__ img, int h, int w,
+                                                         floatx4 mean, floatx4 stdv,
+                                                         half_t* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 consecutive dx
+  if (idx >= 4096 * 96) return;
+  const int t = idx / 96, kc = idx % 96;
+  const int c = kc / 32, rem = kc % 32, dy = rem >> 1, dx0 = (rem & 1) * 8;
+  const int py = t >> 6, px = t & 63;
+  const int y = py * 16 + dy, x0 = px * 16 + dx0;
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int x = x0 + e;
+    float v = 0.f;
+    if (y < h && x < w) v = (img[((long)c * h + y) * w + x] - mean[c]) / stdv[c];
+    o[e] = (half_t)v;
+  }
+  *(half8_t*)(out + (long)t * 768 + kc * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DINOv2 input: bilinear (align_corners=False) resample of the normalised+padded 1024^2 tensor to
+// 1022^2 (predictor.py:104) fused with the 14x14 patch im2col: A[5329, 640] f16, k = c*196+dy*14+dx,
+// columns 588..639 zero (K padded to the GEMM's 64 multiple).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float norm_px(const float* img, int h, int w, int c, int y, int x,
+                                         float mean, float stdv) {
+  return (y < h && x < w) ? (img[((long)c * h + y) * w + x] - mean) / stdv : 0.f;
+}
+
+__global__ __launch_bounds__(256) void dino_im2col_kernel(const float* __restrict__ img, int h, int w,
+                                                          floatx4 mean, floatx4 stdv,
+                                                          half_t* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 5329L * 640) return;
+  const int t = (int)(idx / 640), k = (int)(idx % 640);
+  float v = 0.f;
+  if (k < 588) {
+    const int c = k / 196, r = k % 196, dy = r / 14, dx = r % 14;
+    const int Y = (t / 73) * 14 + dy, X = (t % 73) * 14 + dx;
+    const float sc = 1024.0f / 1022.0f;
+    float sy = sc * ((float)Y + 0.5f) - 0.5f;
+    float sx = sc * ((float)X + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < 1023 ? 1 : 0), x1 = x0 + (x0 < 1023 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float m = mean[c], s = stdv[c];
+    const float v00 = norm_px(img, h, w, c, y0, x0, m, s), v01 = norm_px(img, h, w, c, y0, x1, m, s);
+    const float v10 = norm_px(img, h, w, c, y1, x0, m, s), v11 = norm_px(img, h, w, c, y1, x1, m, s);
+    v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+  out[idx] = (half_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / pad 1 im2col on token-major [64,64,C] f16 (neck conv, image_encoder.py:96-102):
+// A[4096, 9*C], k = (ky*3+kx)*C + c.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const half_t* __restrict__ in, half_t* __restrict__ out,
+                                                        int C) {
+  const int cpt = C >> 3;  // 16-B chunks per tap
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4096L * 9 * cpt) return;
+  const int t = (int)(idx / (9 * cpt));
+  const int r = (int)(idx % (9 * cpt));
+  const int tap = r / cpt, ch = r % cpt;
+  const int y = (t >> 6) + tap / 3 - 1, x = (t & 63) + tap % 3 - 1;
+  half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (y >= 0 && y < 64 && x >= 0 && x < 64) v = *(const half8_t*)(in + ((long)(y * 64 + x)) * C + ch * 8);
+  *(half8_t*)(out + (long)t * 9 * C + (long)tap * C + ch * 8) = v;
+}
+
+// y[M,N] (f16) = a[M,N] (f32|f16) + b[N or M,N] (f32), generic small helper
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       long b_row_stride, half_t* __restrict__ y16,
+                                                       float* __restrict__ y32, long M, int N) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * (N >> 2)) return;
+  const long m = idx / (N >> 2);
+  const int n = (int)(idx % (N >> 2)) * 4;
+  floatx4 v = *(const floatx4*)(a + m * N + n);
+  if (b) v += *(const floatx4*)(b + m * b_row_stride + n);
+  if (y32) *(floatx4*)(y32 + m * N + n) = v;
+  if (y16) {
+    half4_t h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+    *(half4_t*)(y16 + m * N + n) = h;
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_layernorm(void* stream, const void* x, long ldx, int x_dtype, void* y, long ldy,
+                              int y_dtype, const float* gamma, const float* beta, int M, int D,
+                              float eps) {
+  CSAM_REQUIRE(x && y && gamma && beta, "csam_layernorm: null pointer");
+  CSAM_REQUIRE(D % 4 == 0 && D <= 1280 && D >= 4, "csam_layernorm: D=%d unsupported", D);
+  CSAM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "csam_layernorm: ld alignment");
+  dim3 grid(csam_cdiv(M, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == CSAM_DT_F32 && y_dtype == CSAM_DT_F16)
+    hipLaunchKernelGGL((layernorm_kernel<float, half_t>), grid, block, 0, s, (const float*)x, ldx, (half_t*)y, ldy, gamma, beta, M, D, eps);
+  else if (x_dtype == CSAM_DT_F32 && y_dtype == CSAM_DT_F32)
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, ldx, (float*)y, ldy, gamma, beta, M, D, eps);
+  else if (x_dtype == CSAM_DT_F16 && y_dtype == CSAM_DT_F16)
+    hipLaunchKernelGGL((layernorm_kernel<half_t, half_t>), grid, block, 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, M, D, eps);
+  else if (x_dtype == CSAM_DT_F16 && y_dtype == CSAM_DT_F32)
+    hipLaunchKernelGGL((layernorm_kernel<half_t, float>), grid, block, 0, s, (const half_t*)x, ldx, (float*)y, ldy, gamma, beta, M, D, eps);
+  else {
+    csam_set_error("csam_layernorm: bad dtypes");
+    return CSAM_ERR_ARG;
+  }
+  CSAM_LAUNCH_CHECK("csam_layernorm");
+  return CSAM_OK;
+}
+
+extern "C" int csam_sam_im2col(void* stream, const float* img_chw, int h, int w, const float* mean3,
+                               const float* std3, void* out_f16) {
+  CSAM_REQUIRE(img_chw && out_f16 && h > 0 && w > 0 && h <= 1024 && w <= 1024, "csam_sam_im2col: bad args");
+  floatx4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+  hipLaunchKernelGGL(sam_im2col_kernel, dim3(csam_cdiv(4096 * 96, 256)), dim3(256), 0, (hipStream_t)stream,
+                     img_chw, h, w, m, sd, (half_t*)out_f16);
+  CSAM_LAUNCH_CHECK("csam_sam_im2col");
+  return CSAM_OK;
+}
+
+extern "C" int csam_dino_im2col(void* stream, const float* img_chw, int h, int w, const float* mean3,
+                                const float* std3, void* out_f16) {
+  CSAM_REQUIRE(img_chw && out_f16 && h > 0 && w > 0 && h <= 1024 && w <= 1024, "csam_dino_im2col: bad args");
+  floatx4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+  hipLaunchKernelGGL(dino_im2col_kernel, dim3(csam_cdiv(5329L * 640, 256)), dim3(256), 0, (hipStream_t)stream,
+                     img_chw, h, w, m, sd, (half_t*)out_f16);
+  CSAM_LAUNCH_CHECK("csam_dino_im2col");
+  return CSAM_OK;
+}
+
+extern "C" int csam_im2col3x3(void* stream, const void* in_f16, void* out_f16, int C) {
+  CSAM_REQUIRE(in_f16 && out_f16 && C % 8 == 0, "csam_im2col3x3: bad args");
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(csam_cdiv(4096L * 9 * (C / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const half_t*)in_f16, (half_t*)out_f16, C);
+  CSAM_LAUNCH_CHECK("csam_im2col3x3");
+  return CSAM_OK;
+}
+
+extern "C" int csam_add_cast(void* stream, const float* a, const float* b, long b_row_stride, void* y_f16,
+                             float* y_f32, long M, int N) {
+  CSAM_REQUIRE(a && (y_f16 || y_f32) && N % 4 == 0, "csam_add_cast: bad args");
+  hipLaunchKernelGGL(add_cast_kernel, dim3(csam_cdiv(M * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, b_row_stride, (half_t*)y_f16, y_f32, M, N);
+  CSAM_LAUNCH_CHECK("csam_add_cast");
+  return CSAM_OK;
+}

@@ -1,0 +1,95 @@
+"""Host orchestration of the SAM ViTDet image encoder on the HIP kernels.
+
+Mirrors segment_anything_cs/modeling/image_encoder.py:106-116 (ImageEncoderViT.forward) of the
+reference; all arithmetic runs in libcsam_hip.so.  Data layout in HBM: token-major [4096, C] for
+the whole encoder (NHWC of the 64x64 grid) -- no permutes, no window-partition copies.
+Residual stream fp32, GEMM operands fp16, fp32 MFMA accumulation.
+"""
+import torch
+
+from . import hip
+
+
+class EncoderPlan:
+    """Device-resident fp16/fp32 operand copies + static activation workspace for one encoder."""
+
+    def __init__(self, sd, prefix, embed_dim, depth, heads, global_idx, device):
+        D = embed_dim
+        assert D % heads == 0 and D // heads == 64, "HIP attention kernels are specialised for head_dim 64"
+        assert D % 128 == 0, "GEMM tiles need embed_dim % 128 == 0"
+        self.D, self.depth, self.heads, self.global_idx = D, depth, heads, tuple(global_idx)
+        self.device = device
+        f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        P = prefix
+        self.patch_w = f16(sd[P + "patch_embed.proj.weight"].reshape(D, 768))
+        self.patch_b = f32(sd[P + "patch_embed.proj.bias"])
+        self.pos = f32(sd[P + "pos_embed"].reshape(4096, D))
+        self.blocks = []
+        for i in range(depth):
+            B = f"{P}blocks.{i}."
+            self.blocks.append(dict(
+                ln1_g=f32(sd[B + "norm1.weight"]), ln1_b=f32(sd[B + "norm1.bias"]),
+                qkv_w=f16(sd[B + "attn.qkv.weight"]), qkv_b=f32(sd[B + "attn.qkv.bias"]),
+                rel_h=f32(sd[B + "attn.rel_pos_h"]), rel_w=f32(sd[B + "attn.rel_pos_w"]),
+                proj_w=f16(sd[B + "attn.proj.weight"]), proj_b=f32(sd[B + "attn.proj.bias"]),
+                ln2_g=f32(sd[B + "norm2.weight"]), ln2_b=f32(sd[B + "norm2.bias"]),
+                lin1_w=f16(sd[B + "mlp.lin1.weight"]), lin1_b=f32(sd[B + "mlp.lin1.bias"]),
+                lin2_w=f16(sd[B + "mlp.lin2.weight"]), lin2_b=f32(sd[B + "mlp.lin2.bias"]),
+                is_global=i in self.global_idx))
+            L = 127 if i in self.global_idx else 27
+            assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, 64), "rel-pos table must be (2S-1, 64) at 1024^2"
+        self.neck0_w = f16(sd[P + "neck.0.weight"].reshape(256, D))
+        self.neck1_g, self.neck1_b = f32(sd[P + "neck.1.weight"]), f32(sd[P + "neck.1.bias"])
+        # [co, ci, ky, kx] -> [co, (ky*3+kx)*256 + ci] to match csam_im2col3x3
+        self.neck2_w = f16(sd[P + "neck.2.weight"].permute(0, 2, 3, 1).reshape(256, 2304))
+        self.neck3_g, self.neck3_b = f32(sd[P + "neck.3.weight"]), f32(sd[P + "neck.3.bias"])
+        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
+        self.ws = dict(
+            col=e(4096, 768), x=e(4096, D, dt=torch.float32), h=e(4096, D), qkv=e(4096, 3 * D),
+            attn=e(4096, D), mlp=e(4096, 4 * D), th=e(heads, 4096, 64, dt=torch.float32),
+            tw=e(heads, 4096, 64, dt=torch.float32), n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
+            col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32))
+
+    def forward(self, img_chw_f32, out=None):
+        """img f32 [3,h,w] raw 0..255 (long side <= 1024) -> features f32 [4096,256] token-major."""
+        D, nH = self.D, self.heads
+        ws = self.ws
+        scale = 64 ** -0.5
+        hip.sam_im2col(img_chw_f32, ws["col"])
+        x = hip.gemm_f16(ws["col"], self.patch_w, out=ws["x"], bias=self.patch_b, residual=self.pos)
+        for b in self.blocks:
+            hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
+            hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
+            if b["is_global"]:
+                hip.relpos_tables(ws["qkv"], b["rel_h"], b["rel_w"], ws["th"], ws["tw"], nH, scale)
+                hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, th=ws["th"], tw=ws["tw"])
+            else:
+                hip.win_attn(ws["qkv"], b["qkv_b"], b["rel_h"], b["rel_w"], ws["attn"], D, nH, scale)
+            hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)
+            hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"])
+            hip.gemm_f16(ws["h"], b["lin1_w"], out=ws["mlp"], bias=b["lin1_b"], act=hip.ACT_GELU)
+            hip.gemm_f16(ws["mlp"], b["lin2_w"], out=x, bias=b["lin2_b"], residual=x)
+        hip.add_cast(x, out16=ws["h"])
+        hip.gemm_f16(ws["h"], self.neck0_w, out=ws["n0"])
+        hip.layernorm(ws["n0"], self.neck1_g, self.neck1_b, 1e-6, out=ws["n1"])
+        hip.im2col3x3(ws["n1"], ws["col3"], 256)
+        hip.gemm_f16(ws["col3"], self.neck2_w, out=ws["n2"])
+        if out is None:
+            out = torch.empty(4096, 256, dtype=torch.float32, device=self.device)
+        hip.layernorm(ws["n2"], self.neck3_g, self.neck3_b, 1e-6, out=out)
+        return out
+
+    def flops(self):
+        """Required FLOPs per image (pad tokens of edge windows are not multiplied: their q/k/v are
+        the bias, so QKV/proj run on the 4096 real tokens only)."""
+        D, nH = self.D, self.heads
+        f = 2 * 4096 * 768 * D
+        for b in self.blocks:
+            f += 2 * 4096 * D * (3 * D + D + 8 * D)
+            if b["is_global"]:
+                f += 4 * 4096 * 4096 * 64 * nH + 2 * 4096 * 128 * 64 * nH
+            else:
+                f += 25 * nH * (4 * 196 * 196 * 64 + 2 * 196 * 28 * 64)
+        f += 2 * 4096 * D * 256 + 2 * 4096 * 2304 * 256
+        return f
