@@ -1,0 +1,91 @@
+"""DINOv2 ViT-L/14 forward on the HIP kernels (external dependency of the reference:
+facebookresearch/dinov2, loaded at crowdsam/model.py:33-36 and used only as
+``forward_features(x)['x_norm_patchtokens']`` on a 1022x1022 tensor, predictor.py:104-106).
+
+Architecture restated from the published model ("parity unpinned"): patch 14,
+cls token, learned 37x37 pos-embed bicubic-resized to 73x73, 24 pre-LN blocks with LayerScale,
+GELU MLP, final LayerNorm.  Sequence = 1 + 5329 tokens, rows padded to 5376 in HBM.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+T_DINO = 5330
+GRID = 73
+
+
+def interpolate_pos_embed(pos_embed, gh, gw, offset=0.1):
+    """Weight preprocessing (once per model, host): bicubic resize of the patch pos-embed.
+    ``offset=0.1`` is the Aug-2024 upstream default (scale_factor form); ``None`` selects size=."""
+    N = pos_embed.shape[1] - 1
+    M = int(math.sqrt(N))
+    cls_pe = pos_embed[:, :1].float()
+    patch_pe = pos_embed[:, 1:].float().reshape(1, M, M, -1).permute(0, 3, 1, 2)
+    if offset is not None:
+        patch_pe = F.interpolate(patch_pe, scale_factor=(float(gh + offset) / M, float(gw + offset) / M),
+                                 mode="bicubic", antialias=False)
+    else:
+        patch_pe = F.interpolate(patch_pe, size=(gh, gw), mode="bicubic", antialias=False)
+    assert patch_pe.shape[-2:] == (gh, gw)
+    return torch.cat([cls_pe, patch_pe.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], dim=1)
+
+
+class DinoPlan:
+    def __init__(self, sd, device, depth=24, heads=16, pos_offset=0.1):
+        D = sd["cls_token"].shape[-1]
+        assert D // heads == 64 and D % 128 == 0
+        self.D, self.depth, self.heads, self.device = D, depth, heads, device
+        f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        w = sd["patch_embed.proj.weight"].reshape(D, 588).float()
+        self.patch_w = f16(F.pad(w, (0, 640 - 588)))          # K padded to 640 with zeros
+        self.patch_b = f32(sd["patch_embed.proj.bias"])
+        pos = interpolate_pos_embed(sd["pos_embed"].cpu(), GRID, GRID, pos_offset)[0]   # [5330, D]
+        self.pos = f32(pos)
+        self.cls_row = f32(sd["cls_token"].reshape(1, D).float().cpu() + pos[:1])
+        self.blocks = []
+        for i in range(depth):
+            B = f"blocks.{i}."
+            self.blocks.append(dict(
+                ln1_g=f32(sd[B + "norm1.weight"]), ln1_b=f32(sd[B + "norm1.bias"]),
+                qkv_w=f16(sd[B + "attn.qkv.weight"]), qkv_b=f32(sd[B + "attn.qkv.bias"]),
+                proj_w=f16(sd[B + "attn.proj.weight"]), proj_b=f32(sd[B + "attn.proj.bias"]),
+                ls1=f32(sd[B + "ls1.gamma"]),
+                ln2_g=f32(sd[B + "norm2.weight"]), ln2_b=f32(sd[B + "norm2.bias"]),
+                fc1_w=f16(sd[B + "mlp.fc1.weight"]), fc1_b=f32(sd[B + "mlp.fc1.bias"]),
+                fc2_w=f16(sd[B + "mlp.fc2.weight"]), fc2_b=f32(sd[B + "mlp.fc2.bias"]),
+                ls2=f32(sd[B + "ls2.gamma"])))
+        self.norm_g, self.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
+        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
+        TP = 5376
+        self.ws = dict(col=e(5329, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
+                       attn=e(TP, D), mlp=e(TP, 4 * D))
+
+    def forward(self, img_chw_f32, out=None):
+        """raw f32 [3,h,w] image (0..255) -> x_norm_patchtokens f16 [5329, D]."""
+        D, nH, T = self.D, self.heads, T_DINO
+        ws = self.ws
+        x = ws["x"]
+        scale = 64 ** -0.5
+        hip.dino_im2col(img_chw_f32, ws["col"])
+        x[0:1].copy_(self.cls_row)
+        hip.gemm_f16(ws["col"], self.patch_w, out=x[1:], bias=self.patch_b, residual=self.pos[1:], M=5329)
+        for b in self.blocks:
+            hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"], M=T)
+            hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"], M=T)
+            hip.flash_attn(ws["qkv"], ws["attn"], T, nH, scale, D)
+            hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T)
+            hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"], M=T)
+            hip.gemm_f16(ws["h"], b["fc1_w"], out=ws["mlp"], bias=b["fc1_b"], act=hip.ACT_GELU, M=T)
+            hip.gemm_f16(ws["mlp"], b["fc2_w"], out=x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T)
+        if out is None:
+            out = torch.empty(5329, D, dtype=torch.float16, device=self.device)
+        hip.layernorm(x[1:], self.norm_g, self.norm_b, 1e-6, out=out, M=5329)
+        return out
+
+    def flops(self):
+        D, T = self.D, T_DINO
+        return self.depth * (2 * T * D * 12 * D + 4 * T * T * D) + 2 * 5329 * 588 * D
