@@ -32,8 +32,10 @@ struct GemmArgs {
   const float* bias;
   const float* colscale;
   const void* R; long ldr; int r_dt;
+  int res_mod;          // >0: residual row = m % res_mod (per-image constant broadcast over prompts)
   int act;
   int M, N, K;
+  long sA, sW, sC;      // batch strides in elements (grid.z)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -45,6 +47,10 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  p.A += (long)blockIdx.z * p.sA;
+  p.W += (long)blockIdx.z * p.sW;
+  p.C = (p.c_dt == CSAM_DT_F32) ? (void*)((float*)p.C + (long)blockIdx.z * p.sC)
+                                : (void*)((half_t*)p.C + (long)blockIdx.z * p.sC);
   // layout: [stage][A|W][128 rows][128 B]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -144,11 +150,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
         v *= s;
       }
       if (p.R) {
+        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
         if (p.r_dt == CSAM_DT_F32) {
-          const floatx4 r = *(const floatx4*)((const float*)p.R + (long)m * p.ldr + n);
+          const floatx4 r = *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
           v += r;
         } else {
-          const half4_t r = *(const half4_t*)((const half_t*)p.R + (long)m * p.ldr + n);
+          const half4_t r = *(const half4_t*)((const half_t*)p.R + (long)mr * p.ldr + n);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
         }
@@ -167,10 +174,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 
 }  // namespace
 
-extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* W, long ldw,
-                             void* C, long ldc, int c_dtype, const float* bias,
-                             const float* colscale, const void* residual, long ldr, int r_dtype,
-                             int act, int M, int N, int K) {
+static int gemm_launch(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                       int c_dtype, const float* bias, const float* colscale, const void* residual,
+                       long ldr, int r_dtype, int res_mod, int act, int M, int N, int K, int batch, long sA,
+                       long sW, long sC) {
   CSAM_REQUIRE(A && W && C, "csam_gemm_f16: null operand");
   CSAM_REQUIRE(M > 0 && N > 0 && K > 0, "csam_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
   CSAM_REQUIRE(N % BN == 0, "csam_gemm_f16: N=%d must be a multiple of %d", N, BN);
@@ -184,8 +191,11 @@ extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* 
   p.C = C; p.ldc = ldc; p.c_dt = c_dtype;
   p.bias = bias; p.colscale = colscale;
   p.R = residual; p.ldr = ldr; p.r_dt = r_dtype;
+  p.res_mod = res_mod;
   p.act = act; p.M = M; p.N = N; p.K = K;
-  dim3 grid(N / BN, csam_cdiv(M, BM));
+  p.sA = sA; p.sW = sW; p.sC = sC;
+  CSAM_REQUIRE(batch >= 1 && (batch == 1 || !residual), "csam_gemm_f16: batched call takes no residual");
+  dim3 grid(N / BN, csam_cdiv(M, BM), batch);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -195,4 +205,31 @@ extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* 
   hipLaunchKernelGGL(gemm_f16_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
   CSAM_LAUNCH_CHECK("csam_gemm_f16");
   return CSAM_OK;
+}
+
+extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* W, long ldw,
+                             void* C, long ldc, int c_dtype, const float* bias,
+                             const float* colscale, const void* residual, long ldr, int r_dtype,
+                             int act, int M, int N, int K) {
+  return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, colscale, residual, ldr, r_dtype, 0, act,
+                     M, N, K, 1, 0, 0, 0);
+}
+
+// residual row index taken modulo res_mod: adds a per-image [res_mod, N] constant to every prompt's
+// [res_mod, N] slab of a prompt-stacked M = B*res_mod GEMM (hoisted key_pe projections).
+extern "C" int csam_gemm_f16_resmod(void* stream, const void* A, long lda, const void* W, long ldw,
+                                    void* C, long ldc, int c_dtype, const float* bias,
+                                    const void* residual, long ldr, int r_dtype, int res_mod, int act,
+                                    int M, int N, int K) {
+  CSAM_REQUIRE(res_mod > 0, "csam_gemm_f16_resmod: res_mod must be > 0");
+  return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, nullptr, residual, ldr, r_dtype, res_mod,
+                     act, M, N, K, 1, 0, 0, 0);
+}
+
+// batch of independent GEMMs (grid.z) with element strides; no residual.
+extern "C" int csam_gemm_f16_batched(void* stream, const void* A, long lda, long strideA, const void* W,
+                                     long ldw, long strideW, void* C, long ldc, long strideC, int c_dtype,
+                                     const float* bias, int act, int M, int N, int K, int batch) {
+  return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, nullptr, nullptr, 0, 0, 0, act, M, N, K,
+                     batch, strideA, strideW, strideC);
 }

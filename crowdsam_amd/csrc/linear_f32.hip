@@ -1,0 +1,78 @@
+// csam_linear_f32: out[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual), everything fp32.
+//
+// For the decoder's small heads, whose outputs drive discrete decisions (argmax over the 4 fused
+// scores, score/stability thresholds) and therefore stay in fp32 on the VALU:
+//   mask_decoder.py:175-179 hyper-MLPs (256->256->256->32), :184 IoU head (256->256->256->4),
+//   :192 point_classifier (256->256->n_class), :194-198 parallel_iou_head (512->256->256->1),
+//   predictor.py:113-121 FG prior.  Arbitrary M, N, K and row strides (token gathers via lda).
+// 32x64 output tile per 256-thread block, BK = 32 staged through LDS.
+#include "csam_common.h"
+
+namespace {
+
+constexpr int LBM = 32, LBN = 64, LBK = 32;
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ W, long ldw,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ R, long ldr,
+                                                         float* __restrict__ C, long ldc, int M, int N,
+                                                         int K, int act) {
+  __shared__ float As[LBM][LBK + 1];
+  __shared__ float Ws[LBN][LBK + 1];
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;  // col, row-group (8 rows each)
+  const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += LBK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 5, c = e & 31;
+      const int m = m0 + r, k = k0 + c;
+      As[r][c] = (m < M && k < K) ? A[(long)m * lda + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 5, c = e & 31;
+      const int n = n0 + r, k = k0 + c;
+      Ws[r][c] = (n < N && k < K) ? W[(long)n * ldw + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < LBK; ++kk) {
+      const float w = Ws[tx][kk];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += As[ty * 8 + r][kk] * w;
+    }
+    __syncthreads();
+  }
+  const int n = n0 + tx;
+  if (n >= N) return;
+  const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = m0 + ty * 8 + r;
+    if (m < M) {
+      float v = csam_apply_act(acc[r] + b, act);
+      if (R) v += R[(long)m * ldr + n];
+      C[(long)m * ldc + n] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_linear_f32(void* stream, const float* A, long lda, const float* W, long ldw,
+                               const float* bias, const float* residual, long ldr, float* C, long ldc,
+                               int M, int N, int K, int act) {
+  CSAM_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "csam_linear_f32: bad args");
+  dim3 grid(csam_cdiv(N, LBN), csam_cdiv(M, LBM));
+  hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, bias, residual,
+                     ldr, C, ldc, M, N, K, act);
+  CSAM_LAUNCH_CHECK("csam_linear_f32");
+  return CSAM_OK;
+}

@@ -1,0 +1,269 @@
+// PWD-Net selection + fused mask post-processing + EPS occupancy lookup.
+//
+// Reference: crowdsam/model.py:351-358 (score fusion, select_mask 'max_iou'), sam.py:153-161
+// (postprocess_masks), crowdsam/model.py:371-389 (filters), amg.py:156-176 (stability score),
+// amg.py:303-346 (batched_mask_to_box), crowdsam/model.py:238-246 (occupancy pruning).
+//
+// The reference up-samples ALL four candidate masks to (B,4,H,W) fp32 twice (50 MB/prompt of HBM
+// traffic) and then discards three.  Here only the selected candidate's 256x256 logits are read
+// (256 KB/prompt, L2-resident) and each output pixel is produced once: bilinear x4 -> thresholds
+// -> u8 mask byte + wave-reduced stability counts and bbox extents (integer atomics, deterministic).
+#include "csam_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// score fusion + argmax (crowdsam/model.py:351,325,354): s_l = clamp(iou_l,0) * sigmoid(cls_l0);
+// sel = first argmax_l s_l; category = first argmax_c cls[sel,c].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ iou, const float* __restrict__ cls,
+                                                     int C, int* __restrict__ sel, float* __restrict__ score,
+                                                     int* __restrict__ category, float* __restrict__ fused, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float best = -INFINITY;
+  int bi = 0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const float i = fmaxf(iou[b * 4 + l], 0.f);
+    const float c = cls[((long)b * 4 + l) * C];
+    const float s = i * (1.0f / (1.0f + expf(-c)));
+    if (fused) fused[b * 4 + l] = s;
+    if (s > best) {
+      best = s;
+      bi = l;
+    }
+  }
+  sel[b] = bi;
+  score[b] = best;
+  int cat = 0;
+  float cb = cls[((long)b * 4 + bi) * C];
+  for (int c = 1; c < C; ++c) {
+    const float v = cls[((long)b * 4 + bi) * C + c];
+    if (v > cb) {
+      cb = v;
+      cat = c;
+    }
+  }
+  category[b] = cat;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear sample, torch upsample_bilinear2d(align_corners=False) semantics, fp32, no contraction
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& lam) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  lam = s - (float)i0;
+}
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ p, int sw, int y0, int y1, float ly, int x0,
+                                        int x1, float lx) {
+  const float w0x = 1.f - lx, w0y = 1.f - ly;
+  const float top = w0x * p[y0 * sw + x0] + lx * p[y0 * sw + x1];
+  const float bot = w0x * p[y1 * sw + x0] + lx * p[y1 * sw + x1];
+  return w0y * top + ly * bot;
+}
+
+// Output geometry: (H, W).  Source: per-prompt plane [sh, sw] at src + b*src_bstride + sel*plane
+// (sel == nullptr -> plane 0).  scale_y/x are the torch "in/out" ratios of THIS interpolate call:
+// fast path (original_size == input_size): source = low-res logits, scale = 256/1024 (crop is a
+// no-op on coordinates); general path stage 1 writes fp32 (mode 0), stage 2 thresholds (mode 1).
+struct PostArgs {
+  const float* src; long src_bstride; int plane; const int* sel;
+  int sh, sw; float scale_y, scale_x;
+  int H, W;
+  float thr, off;
+  float* out_f32;       // mode 0: [B,H,W] fp32 logits
+  uint8_t* out_mask;    // mode 1: [B,H,W] u8
+  int* inter; int* uni; int* box;   // mode 1: [B], [B], [B,4] = xmin,ymin,xmax,ymax (pre-initialised)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
+  const int b = blockIdx.z;
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;   // 4 pixels per thread
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const float* p = a.src + (long)b * a.src_bstride + (a.sel ? (long)a.sel[b] * a.plane : 0);
+  int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+  if (y < a.H && x4 < a.W) {
+    int y0, y1;
+    float ly;
+    src_index(a.scale_y, y, a.sh, y0, y1, ly);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = x4 + e;
+      if (x < a.W) {
+        int x0, x1;
+        float lx;
+        src_index(a.scale_x, x, a.sw, x0, x1, lx);
+        const float v = bilerp(p, a.sw, y0, y1, ly, x0, x1, lx);
+        if (MODE == 0) {
+          a.out_f32[((long)b * a.H + y) * a.W + x] = v;
+        } else {
+          cnt_i += v > (a.thr + a.off);
+          cnt_u += v > (a.thr - a.off);
+          if (v > a.thr) {
+            packed |= 1u << (8 * e);
+            xmin = min(xmin, x);
+            xmax = max(xmax, x);
+            ymin = y;
+            ymax = y;
+          }
+        }
+      }
+    }
+    if (MODE == 1) {
+      uint8_t* o = a.out_mask + ((long)b * a.H + y) * a.W + x4;
+      if (x4 + 3 < a.W && (((long)b * a.H + y) * a.W + x4) % 4 == 0) {
+        *(uint32_t*)o = packed;
+      } else {
+        for (int e = 0; e < 4 && x4 + e < a.W; ++e) o[e] = (packed >> (8 * e)) & 1;
+      }
+    }
+  }
+  if (MODE == 1) {
+    // wave reduction, one atomic set per wave (integer atomics: order-independent)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt_i += __shfl_xor(cnt_i, o, 64);
+      cnt_u += __shfl_xor(cnt_u, o, 64);
+      xmin = min(xmin, __shfl_xor(xmin, o, 64));
+      xmax = max(xmax, __shfl_xor(xmax, o, 64));
+      ymin = min(ymin, __shfl_xor(ymin, o, 64));
+      ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (cnt_i) atomicAdd(a.inter + b, cnt_i);
+      if (cnt_u) atomicAdd(a.uni + b, cnt_u);
+      if (xmax >= 0) {
+        atomicMin(a.box + b * 4 + 0, xmin);
+        atomicMin(a.box + b * 4 + 1, ymin);
+        atomicMax(a.box + b * 4 + 2, xmax);
+        atomicMax(a.box + b * 4 + 3, ymax);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void post_init_kernel(int* inter, int* uni, int* box, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  inter[b] = 0;
+  uni[b] = 0;
+  box[b * 4 + 0] = 1 << 30;
+  box[b * 4 + 1] = 1 << 30;
+  box[b * 4 + 2] = -1;
+  box[b * 4 + 3] = -1;
+}
+
+// keep = (score > pred_iou_thresh) && (inter/union >= stability_thresh); empty mask -> box zeros
+// (amg.py:341-343); occupancy flag = keep && score > filter_thresh (crowdsam/model.py:246).
+__global__ __launch_bounds__(256) void post_finalize_kernel(const float* __restrict__ score, const int* __restrict__ inter,
+                                                            const int* __restrict__ uni, int* __restrict__ box,
+                                                            float pred_iou_thresh, float stab_thresh,
+                                                            float filter_thresh, float* __restrict__ stability,
+                                                            uint8_t* __restrict__ keep, uint8_t* __restrict__ occ,
+                                                            int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float st = (float)inter[b] / (float)uni[b];
+  stability[b] = st;
+  bool k = true;
+  if (pred_iou_thresh > 0.f) k = k && (score[b] > pred_iou_thresh);
+  if (stab_thresh > 0.f) k = k && (st >= stab_thresh);
+  if (box[b * 4 + 2] < box[b * 4 + 0] || box[b * 4 + 3] < box[b * 4 + 1]) {
+    box[b * 4 + 0] = box[b * 4 + 1] = box[b * 4 + 2] = box[b * 4 + 3] = 0;
+  }
+  keep[b] = k;
+  occ[b] = k && (score[b] > filter_thresh);
+}
+
+// out[p] = OR_b occ[b] & mask[b, y_p, x_p]   (crowdsam/model.py:238,246)
+__global__ __launch_bounds__(256) void occupancy_kernel(const int* __restrict__ pts, int P,
+                                                        const uint8_t* __restrict__ masks,
+                                                        const uint8_t* __restrict__ occ, int B, int H, int W,
+                                                        uint8_t* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int x = pts[p * 2], y = pts[p * 2 + 1];
+  uint8_t r = 0;
+  if (x >= 0 && x < W && y >= 0 && y < H) {
+    for (int b = 0; b < B; ++b)
+      if (occ[b]) r |= masks[((long)b * H + y) * W + x];
+  }
+  out[p] = r;
+}
+
+}  // namespace
+
+extern "C" int csam_select_masks(void* stream, const float* iou, const float* cls, int n_class, int* sel,
+                                 float* score, int* category, float* fused_or_null, int B) {
+  CSAM_REQUIRE(iou && cls && sel && score && category && B > 0 && n_class > 0, "csam_select_masks: bad args");
+  hipLaunchKernelGGL(select_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, iou, cls, n_class,
+                     sel, score, category, fused_or_null, B);
+  CSAM_LAUNCH_CHECK("csam_select_masks");
+  return CSAM_OK;
+}
+
+// Fused path of sam.py:153-161 for original_size == input_size (the normal case) and the general
+// two-stage path otherwise (trap 9: 1023-sided frames).  tmp_f32 [B,in_h,in_w] is only needed when
+// (out_h,out_w) != (in_h,in_w).
+extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w,
+                              int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
+                              int* box, float* tmp_f32) {
+  CSAM_REQUIRE(lowres && sel && out_mask_u8 && inter && uni && box && B > 0, "csam_mask_post: bad args");
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0,
+               "csam_mask_post: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
+  PostArgs a;
+  a.thr = thr; a.off = off;
+  a.inter = inter; a.uni = uni; a.box = box;
+  if (in_h == out_h && in_w == out_w) {
+    a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
+    a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
+    a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
+    dim3 grid(csam_cdiv(out_w, 256), csam_cdiv(out_h, 4), B);
+    hipLaunchKernelGGL(mask_post_kernel<1>, grid, dim3(256), 0, s, a);
+  } else {
+    CSAM_REQUIRE(tmp_f32, "csam_mask_post: tmp buffer required when original_size != input_size");
+    a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
+    a.sh = 256; a.sw = 256; a.scale_y = 0.25f; a.scale_x = 0.25f;
+    a.H = in_h; a.W = in_w; a.out_f32 = tmp_f32; a.out_mask = nullptr;
+    dim3 g0(csam_cdiv(in_w, 256), csam_cdiv(in_h, 4), B);
+    hipLaunchKernelGGL(mask_post_kernel<0>, g0, dim3(256), 0, s, a);
+    a.src = tmp_f32; a.src_bstride = (long)in_h * in_w; a.plane = 0; a.sel = nullptr;
+    a.sh = in_h; a.sw = in_w; a.scale_y = (float)in_h / (float)out_h; a.scale_x = (float)in_w / (float)out_w;
+    a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
+    dim3 g1(csam_cdiv(out_w, 256), csam_cdiv(out_h, 4), B);
+    hipLaunchKernelGGL(mask_post_kernel<1>, g1, dim3(256), 0, s, a);
+  }
+  CSAM_LAUNCH_CHECK("csam_mask_post");
+  return CSAM_OK;
+}
+
+extern "C" int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
+                                  float pred_iou_thresh, float stability_thresh, float filter_thresh,
+                                  float* stability, void* keep_u8, void* occ_u8, int B) {
+  CSAM_REQUIRE(score && inter && uni && box && stability && keep_u8 && occ_u8 && B > 0, "csam_post_finalize: bad args");
+  hipLaunchKernelGGL(post_finalize_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, score, inter,
+                     uni, box, pred_iou_thresh, stability_thresh, filter_thresh, stability, (uint8_t*)keep_u8,
+                     (uint8_t*)occ_u8, B);
+  CSAM_LAUNCH_CHECK("csam_post_finalize");
+  return CSAM_OK;
+}
+
+extern "C" int csam_occupancy_lookup(void* stream, const int* points_xy, int P, const void* masks_u8,
+                                     const void* occ_u8, int B, int H, int W, void* out_u8) {
+  CSAM_REQUIRE(points_xy && masks_u8 && occ_u8 && out_u8 && P > 0 && B > 0, "csam_occupancy_lookup: bad args");
+  hipLaunchKernelGGL(occupancy_kernel, dim3(csam_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, points_xy, P,
+                     (const uint8_t*)masks_u8, (const uint8_t*)occ_u8, B, H, W, (uint8_t*)out_u8);
+  CSAM_LAUNCH_CHECK("csam_occupancy_lookup");
+  return CSAM_OK;
+}

@@ -1,0 +1,232 @@
+// csam_box_nms: greedy box NMS with torchvision semantics, plus csam_rle_*: column-major RLE.
+//
+// Reference call sites: crowdsam/model.py:257-262, 429-434, 171-176 (torchvision.ops.batched_nms with
+// all-zero category ids == plain nms): candidates in STABLE descending-score order; a box is
+// suppressed when IoU > thr with an earlier kept box; IoU = inter / (area_i + area_j - inter) with
+// area = (x2-x1)*(y2-y1), all fp32; kept indices are returned in descending-score order.
+//
+// Three kernels on one stream, no host sync:
+//   1. bitonic sort of 64-bit keys (~orderable(score) << 32 | index) in LDS (N <= 16384),
+//   2. upper-triangular IoU bitmask, one 64-bit word per (row, 64-column block) via per-lane loops,
+//   3. a single-wave sequential scan: the "removed" bitmap lives in registers (one 64-bit word per
+//      lane per 4096 boxes), rows are streamed through LDS 64 at a time.
+#include "csam_common.h"
+
+namespace {
+
+constexpr int NMS_MAX = 16384;
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending order of floats
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ scores, int N, int NP,
+                                                        int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = (uint64_t*)smem;
+  for (int i = threadIdx.x; i < NP; i += 1024) {
+    uint64_t k = ~0ull;  // padding sorts last
+    if (i < N) k = ((uint64_t)(~orderable(scores[i])) << 32) | (uint32_t)i;
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < NP; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < N; i += 1024) order[i] = (int)(keys[i] & 0xffffffffu);
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
+                                                      int N, int nw, float thr, uint64_t* __restrict__ mask) {
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (cb < rb) return;
+  __shared__ float cbx[64][4];
+  const int t = threadIdx.x;
+  const int cj = cb * 64 + t;
+  if (cj < N) {
+    const float* bp = boxes + (long)order[cj] * 4;
+    cbx[t][0] = bp[0]; cbx[t][1] = bp[1]; cbx[t][2] = bp[2]; cbx[t][3] = bp[3];
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= N) return;
+  const float* bi = boxes + (long)order[i] * 4;
+  const float x1 = bi[0], y1 = bi[1], x2 = bi[2], y2 = bi[3];
+  const float iarea = (x2 - x1) * (y2 - y1);
+  uint64_t w = 0;
+  const int jn = min(64, N - cb * 64);
+  for (int jj = 0; jj < jn; ++jj) {
+    const int j = cb * 64 + jj;
+    if (j <= i) continue;
+    const float xx1 = fmaxf(x1, cbx[jj][0]), yy1 = fmaxf(y1, cbx[jj][1]);
+    const float xx2 = fminf(x2, cbx[jj][2]), yy2 = fminf(y2, cbx[jj][3]);
+    const float ww = fmaxf(0.f, xx2 - xx1), hh = fmaxf(0.f, yy2 - yy1);
+    const float inter = ww * hh;
+    const float jarea = (cbx[jj][2] - cbx[jj][0]) * (cbx[jj][3] - cbx[jj][1]);
+    const float ovr = inter / (iarea + jarea - inter);
+    if (ovr > thr) w |= 1ull << jj;
+  }
+  mask[(long)i * nw + cb] = w;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ order,
+                                                      int N, int nw, long* __restrict__ keep, int* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* rows = (uint64_t*)smem;   // [64][nw]
+  const int lane = threadIdx.x;
+  uint64_t removed[4] = {0, 0, 0, 0};  // word index w = lane + 64*s
+  int nkeep = 0;
+  const int ntile = (N + 63) / 64;
+  for (int tile = 0; tile < ntile; ++tile) {
+    const int r0 = tile * 64;
+    const int nr = min(64, N - r0);
+    // stage rows r0..r0+nr-1, words >= tile only (lower words are never set)
+    for (int r = 0; r < nr; ++r)
+      for (int w = lane; w < nw; w += 64) rows[r * nw + w] = (w >= tile) ? mask[(long)(r0 + r) * nw + w] : 0ull;
+    __syncthreads();
+    uint64_t cur = __shfl(removed[tile >> 6], tile & 63, 64);
+    for (int r = 0; r < nr; ++r) {
+      if (!((cur >> r) & 1ull)) {
+        if (lane == 0) keep[nkeep] = (long)order[r0 + r];
+        ++nkeep;
+        cur |= rows[r * nw + tile];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int w = lane + 64 * s;
+          if (w < nw) removed[s] |= rows[r * nw + w];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) *count = nkeep;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-major RLE (amg.py:107-135 mask_to_rle_pytorch): positions i in [1, H*W) of the
+// Fortran-order flattening (i = x*H + y) where the value changes.  Thread = column; pass 1 counts
+// per column, pass 2 writes the sorted positions at the exclusive-scan offsets.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restrict__ masks, int H, int W,
+                                                        int* __restrict__ col_counts) {
+  const int n = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const uint8_t* m = masks + (long)n * H * W;
+  uint8_t prev = x > 0 ? m[(long)(H - 1) * W + x - 1] : m[x];   // x==0: no change at i==0
+  int c = 0;
+  for (int y = 0; y < H; ++y) {
+    const uint8_t v = m[(long)y * W + x];
+    c += (v != prev);
+    prev = v;
+  }
+  col_counts[(long)n * W + x] = c;
+}
+
+__global__ __launch_bounds__(1024) void rle_scan_kernel(int* __restrict__ col_counts, int W, int* __restrict__ totals) {
+  // in-place exclusive scan over the W (<= 4096) columns of mask n
+  __shared__ int buf[4096];
+  const int n = blockIdx.x;
+  int* c = col_counts + (long)n * W;
+  for (int i = threadIdx.x; i < 4096; i += 1024) buf[i] = i < W ? c[i] : 0;
+  __syncthreads();
+  for (int off = 1; off < 4096; off <<= 1) {
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + k * 1024;
+      v[k] = i >= off ? buf[i - off] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) buf[threadIdx.x + k * 1024] += v[k];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < W; i += 1024) c[i] = i > 0 ? buf[i - 1] : 0;
+  if (threadIdx.x == 0) totals[n] = buf[W - 1];
+}
+
+__global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restrict__ masks, int H, int W,
+                                                        const int* __restrict__ col_offsets,
+                                                        const long* __restrict__ mask_offsets,
+                                                        uint32_t* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const uint8_t* m = masks + (long)n * H * W;
+  uint32_t* o = out + mask_offsets[n] + col_offsets[(long)n * W + x];
+  uint8_t prev = x > 0 ? m[(long)(H - 1) * W + x - 1] : m[x];
+  for (int y = 0; y < H; ++y) {
+    const uint8_t v = m[(long)y * W + x];
+    if (v != prev) *o++ = (uint32_t)(x * H + y);
+    prev = v;
+  }
+}
+
+}  // namespace
+
+extern "C" long csam_box_nms_workspace_bytes(int N) {
+  const long nw = (N + 63) / 64;
+  return (long)N * sizeof(int) + (long)N * nw * sizeof(uint64_t) + 64;
+}
+
+extern "C" int csam_box_nms(void* stream, const float* boxes, const float* scores, int N, float thr, long* out_keep,
+                            int* out_count, void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(boxes && scores && out_keep && out_count && workspace, "csam_box_nms: null pointer");
+  CSAM_REQUIRE(N > 0 && N <= NMS_MAX, "csam_box_nms: N=%d out of range (1..%d)", N, NMS_MAX);
+  if (workspace_bytes < csam_box_nms_workspace_bytes(N)) {
+    csam_set_error("csam_box_nms: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nw = (N + 63) / 64;
+  int NP = 1;
+  while (NP < N) NP <<= 1;
+  uint64_t* mask = (uint64_t*)workspace;
+  int* order = (int*)((char*)workspace + (long)N * nw * sizeof(uint64_t));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX * 8);
+    hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), NP * 8, s, scores, N, NP, order);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s, boxes, order, N, nw, thr, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 64 * nw * 8, s, mask, order, N, nw, out_keep, out_count);
+  CSAM_LAUNCH_CHECK("csam_box_nms");
+  return CSAM_OK;
+}
+
+extern "C" int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals) {
+  CSAM_REQUIRE(masks_u8 && col_offsets && totals && N > 0 && H > 0 && W > 0 && W <= 4096, "csam_rle_count: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rle_count_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, s, (const uint8_t*)masks_u8, H, W,
+                     col_offsets);
+  hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(1024), 0, s, col_offsets, W, totals);
+  CSAM_LAUNCH_CHECK("csam_rle_count");
+  return CSAM_OK;
+}
+
+extern "C" int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
+                              const long* mask_offsets, uint32_t* out_positions) {
+  CSAM_REQUIRE(masks_u8 && col_offsets && mask_offsets && out_positions && N > 0, "csam_rle_write: bad args");
+  hipLaunchKernelGGL(rle_write_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)masks_u8, H, W, col_offsets, mask_offsets, out_positions);
+  CSAM_LAUNCH_CHECK("csam_rle_write");
+  return CSAM_OK;
+}

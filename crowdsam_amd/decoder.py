@@ -1,0 +1,287 @@
+"""Host orchestration of the prompt encoder + two-way mask decoder + PWD-Net heads on HIP kernels.
+
+Mirrors segment_anything_cs/modeling/{prompt_encoder,transformer,mask_decoder}.py of the reference
+for the dense-prompt path (point prompts only, multimask_output=True), batched over B prompts.
+
+What is hoisted (per image, not per prompt/batch), because it only depends on the shared image
+embedding:
+  * src = image_emb + no_mask_embed;  layer-0 token->image K/V and layer-0 image->token Q,
+  * dino_proj(dino tokens) (the reference recomputes it every batch, mask_decoder.py:187),
+and per model (constant): dense PE, and key_pe's contribution to every later K/Q projection
+((keys+pe)W = keys W + pe W, added as a row-modulo residual in the GEMM epilogue).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+
+T_IMG = 4096
+N_DINO = 5329
+N_DINO_PAD = 5376
+
+
+def _adjoint_taps(n_in=73, n_out=256):
+    """U^T in ELL form for the align_corners=False bilinear n_in -> n_out up-sampling (fp32 weights
+    exactly as upsample_bilinear2d builds them): for coarse index t, the fine indices that touch it."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    lists = [[] for _ in range(n_in)]
+    for X in range(n_out):
+        s = np.float32(scale * (np.float32(X) + np.float32(0.5)) - np.float32(0.5))
+        s = np.float32(max(s, np.float32(0.0)))
+        x0 = int(s)
+        x1 = x0 + (1 if x0 < n_in - 1 else 0)
+        lam = np.float32(s - np.float32(x0))
+        if x1 == x0 or lam == 0:
+            lists[x0].append((X, np.float32(1.0)))
+        else:
+            lists[x0].append((X, np.float32(1.0) - lam))
+            lists[x1].append((X, lam))
+    x0s = np.zeros(73, np.int32)
+    ns = np.zeros(73, np.int32)
+    ws = np.zeros((73, 8), np.float32)
+    for t, lst in enumerate(lists):
+        xs = [x for x, _ in lst]
+        assert xs == list(range(xs[0], xs[0] + len(xs))) and len(xs) <= 8
+        x0s[t], ns[t] = xs[0], len(xs)
+        ws[t, :len(xs)] = [w for _, w in lst]
+    buf = np.concatenate([x0s.view(np.uint8), ns.view(np.uint8), ws.reshape(-1).view(np.uint8)])
+    assert buf.size == hip.lib().csam_adj_taps_bytes()
+    return torch.from_numpy(buf.copy())
+
+
+class DecoderPlan:
+    def __init__(self, sd, device, n_class=1, max_batch=256):
+        self.device, self.n_class, self.maxB = device, n_class, max_batch
+        f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        M, T = "mask_decoder.", "mask_decoder.transformer."
+        P = "prompt_encoder."
+        self.gauss = f32(sd[P + "pe_layer.positional_encoding_gaussian_matrix"])
+        self.point_embed1 = f32(sd[P + "point_embeddings.1.weight"].reshape(256))
+        self.not_a_point = f32(sd[P + "not_a_point_embed.weight"].reshape(256))
+        self.no_mask = f32(sd[P + "no_mask_embed.weight"].reshape(1, 256))
+        self.out_tokens5 = f32(torch.cat([sd[M + "iou_token.weight"], sd[M + "mask_tokens.weight"]], 0))
+        # dense PE (model constant): grid point (j+0.5)/64 == pixel 16j+7.5
+        ys, xs = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+        pts = torch.stack([xs.reshape(-1) * 16 + 7.5, ys.reshape(-1) * 16 + 7.5], 1).float().to(device)
+        self.pe = hip.pe_points(pts.contiguous(), self.gauss, torch.empty(T_IMG, 256, device=device))
+        self.pe16 = self.pe.half()
+
+        def attn(prefix):
+            g = lambda n: sd[prefix + n]
+            return dict(q_w=g("q_proj.weight"), q_b=g("q_proj.bias"), k_w=g("k_proj.weight"), k_b=g("k_proj.bias"),
+                        v_w=g("v_proj.weight"), v_b=g("v_proj.bias"), o_w=g("out_proj.weight"), o_b=g("out_proj.bias"))
+
+        def pe_proj(w):  # pe @ w^T (no bias) as fp32 [4096, n] via the fp16 GEMM
+            return hip.gemm_f16(self.pe16, f16(w), out_dtype=torch.float32)
+
+        self.layers = []
+        for i in range(2):
+            L = f"{T}layers.{i}."
+            sa, t2i, i2t = attn(L + "self_attn."), attn(L + "cross_attn_token_to_image."), attn(L + "cross_attn_image_to_token.")
+            d = dict(
+                sa_qk_w=f16(torch.cat([sa["q_w"], sa["k_w"]], 0)), sa_qk_b=f32(torch.cat([sa["q_b"], sa["k_b"]], 0)),
+                sa_v_w=f16(sa["v_w"]), sa_v_b=f32(sa["v_b"]), sa_o_w=f16(sa["o_w"]), sa_o_b=f32(sa["o_b"]),
+                t2i_q_w=f16(t2i["q_w"]), t2i_q_b=f32(t2i["q_b"]),
+                t2i_kv_w=f16(torch.cat([t2i["k_w"], t2i["v_w"]], 0)), t2i_kv_b=f32(torch.cat([t2i["k_b"], t2i["v_b"]], 0)),
+                t2i_o_w=f16(t2i["o_w"]), t2i_o_b=f32(t2i["o_b"]),
+                i2t_q_w=f16(i2t["q_w"]), i2t_q_b=f32(i2t["q_b"]),
+                i2t_kv_w=f16(torch.cat([i2t["k_w"], i2t["v_w"]], 0)), i2t_kv_b=f32(torch.cat([i2t["k_b"], i2t["v_b"]], 0)),
+                i2t_k_w=f16(i2t["k_w"]), i2t_k_b=f32(i2t["k_b"]), i2t_v_w=f16(i2t["v_w"]), i2t_v_b=f32(i2t["v_b"]),
+                i2t_o_w=f16(i2t["o_w"]), i2t_o_b=f32(i2t["o_b"]),
+                mlp1_w=f16(sd[L + "mlp.lin1.weight"]), mlp1_b=f32(sd[L + "mlp.lin1.bias"]),
+                mlp2_w=f16(sd[L + "mlp.lin2.weight"]), mlp2_b=f32(sd[L + "mlp.lin2.bias"]))
+            for n in ("norm1", "norm2", "norm3", "norm4"):
+                d[n + "_g"], d[n + "_b"] = f32(sd[L + n + ".weight"]), f32(sd[L + n + ".bias"])
+            # key_pe contributions (model constants): [pe Wk^T | 0] for the K|V GEMM and pe Wq^T
+            pk = pe_proj(t2i["k_w"])
+            d["t2i_kv_pe"] = torch.cat([pk, torch.zeros_like(pk)], 1).contiguous()
+            d["i2t_q_pe"] = pe_proj(i2t["q_w"])
+            self.layers.append(d)
+        fa = attn(T + "final_attn_token_to_image.")
+        pk = pe_proj(fa["k_w"])
+        self.final = dict(q_w=f16(fa["q_w"]), q_b=f32(fa["q_b"]),
+                          kv_w=f16(torch.cat([fa["k_w"], fa["v_w"]], 0)), kv_b=f32(torch.cat([fa["k_b"], fa["v_b"]], 0)),
+                          kv_pe=torch.cat([pk, torch.zeros_like(pk)], 1).contiguous(),
+                          o_w=f16(fa["o_w"]), o_b=f32(fa["o_b"]),
+                          norm_g=f32(sd[T + "norm_final_attn.weight"]), norm_b=f32(sd[T + "norm_final_attn.bias"]))
+        # upscaler: ConvTranspose2d(k=2,s=2) as GEMMs; weight [ci, co, di, dj] -> rows n = (di*2+dj)*co_n + co
+        w1 = sd[M + "output_upscaling.0.weight"]          # [256, 64, 2, 2]
+        self.up1_w = f16(w1.permute(2, 3, 1, 0).reshape(256, 256))
+        self.up1_b = f32(sd[M + "output_upscaling.0.bias"].repeat(4))
+        self.up_ln_g, self.up_ln_b = f32(sd[M + "output_upscaling.1.weight"]), f32(sd[M + "output_upscaling.1.bias"])
+        w2 = sd[M + "output_upscaling.3.weight"]          # [64, 32, 2, 2]
+        self.up2_w = f16(w2.permute(2, 3, 1, 0).reshape(128, 64))
+        self.up2_b = f32(sd[M + "output_upscaling.3.bias"].repeat(4))
+
+        def mlp(prefix, n):
+            return [(f32(sd[f"{prefix}.layers.{i}.weight"]), f32(sd[f"{prefix}.layers.{i}.bias"])) for i in range(n)]
+
+        self.hyper = [mlp(f"{M}output_hypernetworks_mlps.{i}", 3) for i in range(4)]   # index 4 unused (trap 5)
+        self.iou_head = mlp(M + "iou_prediction_head", 3)
+        self.par_iou_head = mlp(M + "parallel_iou_head", 3)
+        self.classifier = mlp(M + "point_classifier", 2)
+        self.dino_proj_w = f16(sd[M + "dino_proj.weight"])
+        self.dino_proj_b = f32(sd[M + "dino_proj.bias"])
+        self.taps = _adjoint_taps().to(device)
+        self._alloc(max_batch)
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc(self, B):
+        dev = self.device
+        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=dev)
+        f = torch.float32
+        BT = B * T_IMG
+        self.ws = dict(
+            coords=e(B, 2, dt=f), tokens0=e(B * 7, 256, dt=f), queries=e(B * 7, 256, dt=f), tmp32=e(B * 7, 256, dt=f),
+            q16=e(B * 7, 256), qpe16=e(B * 7, 256), sa_qk=e(B * 7, 512), sa_v=e(B * 7, 256), sa_o=e(B * 7, 256),
+            t2i_q=e(B * 7, 128), t2i_o=e(B * 7, 128), mlp_h=e(B * 7, 2048),
+            i2t_kv=e(B * 7, 256), i2t_k=e(B * 7, 128), i2t_v=e(B * 7, 128),
+            keysA=e(BT, 256), keysB=e(BT, 256), kv=e(BT, 256), qi=e(BT, 128), att=e(BT, 128),
+            up2=e(BT * 4, 128), masks=e(B, 4, 256, 256, dt=f),
+            hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
+            iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512, dt=f), cls=e(B * 4, self.n_class, dt=f),
+            stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
+            pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
+            t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev))
+        self.allocB = B
+
+    # ------------------------------------------------------------------------------------------
+    def set_image(self, feat_tok, dino_tok16):
+        """feat_tok f32 [4096,256] (encoder output, token-major); dino_tok16 f16 [>=5329 rows,1024]
+        inside a buffer with N_DINO_PAD rows.  Builds the per-image constants."""
+        dev = self.device
+        L0 = self.layers[0]
+        st = {}
+        src16 = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
+        srcpe16 = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
+        src32 = torch.empty(T_IMG, 256, dtype=torch.float32, device=dev)
+        hip.add_cast(feat_tok, self.no_mask, 0, out16=src16, out32=src32)
+        hip.add_cast(src32, self.pe, 256, out16=srcpe16)
+        st["src16"] = src16
+        st["kv0"] = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
+        hip.gemm_f16(srcpe16, L0["t2i_kv_w"][:128], out=st["kv0"][:, :128], bias=L0["t2i_kv_b"][:128])
+        hip.gemm_f16(src16, L0["t2i_kv_w"][128:], out=st["kv0"][:, 128:], bias=L0["t2i_kv_b"][128:])
+        st["qi0"] = hip.gemm_f16(srcpe16, L0["i2t_q_w"], bias=L0["i2t_q_b"])
+        # dino_proj, both orientations: G f32 [5329,256] (+bias) for the FG prior and
+        # G^T f16 [256, 5376] (no bias; added after pooling) as the K-contiguous pooling operand.
+        st["G"] = hip.gemm_f16(dino_tok16, self.dino_proj_w, bias=self.dino_proj_b, out_dtype=torch.float32, M=N_DINO)
+        st["GT"] = hip.gemm_f16(self.dino_proj_w, dino_tok16, out_dtype=torch.float16, M=256)
+        self.state = st
+        return st
+
+    def fg_logits(self):
+        """predictor.py:113-121 up to the classifier: [5329, n_class] fp32 logits on the 73x73 grid."""
+        G = self.state["G"]
+        (w1, b1), (w2, b2) = self.classifier
+        h = hip.linear_f32(G, w1, b1, act=hip.ACT_RELU)
+        return hip.linear_f32(h, w2, b2)
+
+    # ------------------------------------------------------------------------------------------
+    def run_batch(self, coords_f32):
+        """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C])."""
+        B = coords_f32.shape[0]
+        if B > self.allocB:
+            self._alloc(B)
+        ws, st = self.ws, self.state
+        M7 = B * 7
+        BT = B * T_IMG
+        nsplit_t2i = max(1, min(8, 256 // B)) if B < 256 else 1
+        nsplit_i2t = max(1, min(16, 512 // B))
+        tokens0, queries = ws["tokens0"][:M7], ws["queries"][:M7]
+        q16, qpe16 = ws["q16"][:M7], ws["qpe16"][:M7]
+        hip.point_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed1, self.not_a_point, tokens0)
+        keys_in, keys_out = None, ws["keysA"]
+
+        def cast_queries():
+            hip.add_cast(queries, out16=q16)
+            hip.add_cast(queries, tokens0, 256, out16=qpe16)
+
+        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b):
+            hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
+            hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
+            hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
+            hip.layernorm(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, out=queries)
+
+        for li, L in enumerate(self.layers):
+            # ---- token self-attention (transformer.py:164-170)
+            if li == 0:
+                hip.add_cast(tokens0, out16=q16)
+                hip.gemm_f16(q16, L["sa_qk_w"], out=ws["sa_qk"][:M7], bias=L["sa_qk_b"])
+            else:
+                cast_queries()
+                hip.gemm_f16(qpe16, L["sa_qk_w"], out=ws["sa_qk"][:M7], bias=L["sa_qk_b"])
+            hip.gemm_f16(q16, L["sa_v_w"], out=ws["sa_v"][:M7], bias=L["sa_v_b"])
+            hip.token_self_attn(ws["sa_qk"], ws["sa_v"], ws["sa_o"], B)
+            hip.gemm_f16(ws["sa_o"][:M7], L["sa_o_w"], out=ws["tmp32"][:M7], bias=L["sa_o_b"],
+                         residual=None if li == 0 else queries)
+            hip.layernorm(ws["tmp32"][:M7], L["norm1_g"], L["norm1_b"], 1e-5, out=queries)
+            # ---- token -> image cross attention (:173-177)
+            cast_queries()
+            if li == 0:
+                t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
+            else:
+                hip.gemm_f16_resmod(keys_in, L["t2i_kv_w"], ws["kv"][:BT], L["t2i_kv_b"], L["t2i_kv_pe"], T_IMG, M=BT)
+                t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
+            # ---- MLP (:180-183)
+            hip.add_cast(queries, out16=q16)
+            hip.gemm_f16(q16, L["mlp1_w"], out=ws["mlp_h"][:M7], bias=L["mlp1_b"], act=hip.ACT_RELU)
+            hip.gemm_f16(ws["mlp_h"][:M7], L["mlp2_w"], out=ws["tmp32"][:M7], bias=L["mlp2_b"], residual=queries)
+            hip.layernorm(ws["tmp32"][:M7], L["norm3_g"], L["norm3_b"], 1e-5, out=queries)
+            # ---- image -> token cross attention (:186-190): keys = LN4(keys + out_proj(attn))
+            cast_queries()
+            hip.gemm_f16(qpe16, L["i2t_k_w"], out=ws["i2t_k"][:M7], bias=L["i2t_k_b"])
+            hip.gemm_f16(q16, L["i2t_v_w"], out=ws["i2t_v"][:M7], bias=L["i2t_v_b"])
+            if li == 0:
+                hip.attn_i2t(st["qi0"], 128, 0, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
+                hip.gemm_f16_resmod(ws["att"][:BT], L["i2t_o_w"], keys_out[:BT], L["i2t_o_b"], st["src16"], T_IMG, M=BT)
+            else:
+                hip.gemm_f16_resmod(keys_in, L["i2t_q_w"], ws["qi"][:BT], L["i2t_q_b"], L["i2t_q_pe"], T_IMG, M=BT)
+                hip.attn_i2t(ws["qi"], 128, T_IMG * 128, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
+                hip.gemm_f16(ws["att"][:BT], L["i2t_o_w"], out=keys_out[:BT], bias=L["i2t_o_b"], residual=keys_in[:BT])
+            hip.layernorm(keys_out[:BT], L["norm4_g"], L["norm4_b"], 1e-5, out=keys_out[:BT])
+            keys_in, keys_out = keys_out, ws["keysB"]
+        # ---- final token -> image attention (transformer.py:105-112)
+        F = self.final
+        cast_queries()
+        hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
+        t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])
+        # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
+        up1 = ws["kv"]                                   # reuse [BT,256] f16
+        hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
+        hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
+        hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
+        hs = queries.view(B, 7, 256)
+        for i in range(4):
+            tok = hs[:, 1 + i]                           # strided rows (lda = 7*256)
+            h1 = hip.linear_f32(tok, self.hyper[i][0][0], self.hyper[i][0][1], out=ws["h1"][:B], act=hip.ACT_RELU, M=B, lda=7 * 256)
+            h2 = hip.linear_f32(h1, self.hyper[i][1][0], self.hyper[i][1][1], out=ws["h2"][:B], act=hip.ACT_RELU)
+            hip.linear_f32(h2, self.hyper[i][2][0], self.hyper[i][2][1], out=ws["hyper"][:B, i], M=B)
+        masks = ws["masks"][:B]
+        hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
+        # ---- IoU head (:184) + parallel residual head (:194-198)
+        iou_tok = hs[:, 0]
+        h1 = hip.linear_f32(iou_tok, self.iou_head[0][0], self.iou_head[0][1], out=ws["h1"][:B], act=hip.ACT_RELU, M=B, lda=7 * 256)
+        h2 = hip.linear_f32(h1, self.iou_head[1][0], self.iou_head[1][1], out=ws["h2"][:B], act=hip.ACT_RELU)
+        iou0 = hip.linear_f32(h2, self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
+        fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
+        fused[:, :, :256] = iou_tok.unsqueeze(1)         # plumbing: concat [iou_tok | mask_tok_l]
+        fused[:, :, 256:] = hs[:, 1:5]
+        ft = ws["fused_tok"][:B * 4]
+        h1 = hip.linear_f32(ft, self.par_iou_head[0][0], self.par_iou_head[0][1], out=ws["h1"][:B * 4], act=hip.ACT_RELU)
+        h2 = hip.linear_f32(h1, self.par_iou_head[1][0], self.par_iou_head[1][1], out=ws["h2"][:B * 4], act=hip.ACT_RELU)
+        iou = hip.linear_f32(h2, self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
+                             residual=iou0.view(B * 4, 1))
+        # ---- PWD-Net pooling + classifier (:186-192)
+        R = B * 4
+        hip.softmax_stats(masks, ws["stats"], R)
+        hip.pool_adjoint(masks, ws["stats"], self.taps, ws["wadj"], R)
+        hip.gemm_f16(ws["wadj"][:R], st["GT"], out=ws["pooled_raw"][:R])
+        hip.rowscale_bias(ws["pooled_raw"], ws["stats"], self.dino_proj_b, ws["pooled"], R, 256)
+        (w1, b1), (w2, b2) = self.classifier
+        h1 = hip.linear_f32(ws["pooled"][:R], w1, b1, out=ws["h1"][:R], act=hip.ACT_RELU)
+        cls = hip.linear_f32(h1, w2, b2, out=ws["cls"][:R])
+        return masks, iou.view(B, 4), cls.view(B, 4, self.n_class)

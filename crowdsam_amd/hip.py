@@ -31,6 +31,30 @@ SIGNATURES = {
     "csam_win_attn": [_P, _P, _P, _P, _P, _P, _I, _I, _F],
     "csam_relpos_tables": [_P, _P, _L, _P, _P, _P, _P, _I, _F],
     "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _F],
+    "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
+    "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _I, _I, _I, _I, _I],
+    "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
+    "csam_point_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
+    "csam_pe_points": [_P, _P, _P, _P, _I],
+    "csam_token_self_attn": [_P, _P, _P, _P, _I],
+    "csam_attn_t2i": [_P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _P, _L],
+    "csam_attn_i2t": [_P, _P, _L, _L, _P, _P, _P, _I, _I, _I],
+    "csam_ln64_gelu": [_P, _P, _P, _P, _L, _F],
+    "csam_hyper_masks": [_P, _P, _P, _P, _I],
+    "csam_softmax_stats": [_P, _P, _P, _I],
+    "csam_pool_adjoint": [_P, _P, _P, _P, _P, _L, _I],
+    "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
+    "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
+    "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
+    "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
+    "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
+    "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+}
+LONG_RETURNS = {
+    "csam_attn_t2i_workspace_bytes": [_I, _I],
+    "csam_box_nms_workspace_bytes": [_I],
 }
 
 _lib = None
@@ -51,6 +75,11 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argt
             fn.restype = _I
+        for name, argt in LONG_RETURNS.items():
+            fn = getattr(L, name)
+            fn.argtypes = argt
+            fn.restype = _L
+        L.csam_adj_taps_bytes.restype = _I
         _lib = L
     return _lib
 
@@ -165,3 +194,134 @@ def flash_attn(qkv, out, T, nH, scale, D, th=None, tw=None):
     call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(th), _ptr(tw), _ptr(out),
          out.stride(0), T, nH, float(scale))
     return out
+
+
+def gemm_f16_resmod(a, w, out, bias, residual, res_mod, act=ACT_NONE, M=None):
+    """Prompt-stacked GEMM whose residual is a per-image [res_mod, N] constant (row m %% res_mod)."""
+    if M is None:
+        M = a.shape[0]
+    K, N = a.shape[1], w.shape[0]
+    call("csam_gemm_f16_resmod", _stream(), _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0),
+         _dt(out.dtype), _ptr(bias), _ptr(residual), residual.stride(0), _dt(residual.dtype), res_mod, act, M, N, K)
+    return out
+
+
+def gemm_f16_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None, act=ACT_NONE):
+    call("csam_gemm_f16_batched", _stream(), _ptr(a), lda, sa, _ptr(w), ldw, sw, _ptr(out), ldc, sc, _dt(out.dtype),
+         _ptr(bias), act, M, N, K, batch)
+    return out
+
+
+def linear_f32(a, w, bias=None, out=None, act=ACT_NONE, residual=None, M=None, lda=None):
+    """fp32 out[M,N] = act(a[M,K] @ w[N,K]^T + bias) (+ residual).  ``lda`` allows strided row gathers."""
+    N, K = w.shape
+    if M is None:
+        M = a.shape[0]
+    if lda is None:
+        lda = a.stride(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+    call("csam_linear_f32", _stream(), _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual),
+         0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, N, K, act)
+    return out
+
+
+def point_tokens(coords, gauss, out_tokens5, point_embed1, not_a_point, tokens):
+    B = coords.shape[0]
+    call("csam_point_tokens", _stream(), _ptr(coords), _ptr(gauss), _ptr(out_tokens5), _ptr(point_embed1),
+         _ptr(not_a_point), _ptr(tokens), B)
+    return tokens
+
+
+def pe_points(coords, gauss, out):
+    call("csam_pe_points", _stream(), _ptr(coords), _ptr(gauss), _ptr(out), coords.shape[0])
+    return out
+
+
+def token_self_attn(qk, v, out, B):
+    call("csam_token_self_attn", _stream(), _ptr(qk), _ptr(v), _ptr(out), B)
+    return out
+
+
+def attn_t2i_workspace_bytes(B, nsplit):
+    return lib().csam_attn_t2i_workspace_bytes(B, nsplit)
+
+
+def attn_t2i(q, K, V, ldkv, kv_prompt_stride, out, B, T, nsplit, workspace):
+    call("csam_attn_t2i", _stream(), _ptr(q), _ptr(K), _ptr(V), ldkv, kv_prompt_stride, _ptr(out), B, T, nsplit,
+         _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out
+
+
+def attn_i2t(Qi, ldq, q_prompt_stride, k, v, out, B, T, nsplit):
+    call("csam_attn_i2t", _stream(), _ptr(Qi), ldq, q_prompt_stride, _ptr(k), _ptr(v), _ptr(out), B, T, nsplit)
+    return out
+
+
+def ln64_gelu(x, gamma, beta, rows, eps=1e-6):
+    call("csam_ln64_gelu", _stream(), _ptr(x), _ptr(gamma), _ptr(beta), rows, float(eps))
+
+
+def hyper_masks(up2, hyper, masks, B):
+    call("csam_hyper_masks", _stream(), _ptr(up2), _ptr(hyper), _ptr(masks), B)
+
+
+def softmax_stats(masks, stats, rows):
+    call("csam_softmax_stats", _stream(), _ptr(masks), _ptr(stats), rows)
+
+
+def pool_adjoint(masks, stats, taps, w, rows):
+    call("csam_pool_adjoint", _stream(), _ptr(masks), _ptr(stats), _ptr(taps), _ptr(w), w.stride(0), rows)
+
+
+def rowscale_bias(P, stats, bias, out, rows, N):
+    call("csam_rowscale_bias", _stream(), _ptr(P), _ptr(stats), _ptr(bias), _ptr(out), rows, N)
+
+
+def select_masks(iou, cls, n_class, sel, score, category, fused, B):
+    call("csam_select_masks", _stream(), _ptr(iou), _ptr(cls), n_class, _ptr(sel), _ptr(score), _ptr(category),
+         _ptr(fused), B)
+
+
+def mask_post(lowres, sel, B, in_hw, out_hw, thr, off, out_mask, inter, uni, box, tmp=None):
+    call("csam_mask_post", _stream(), _ptr(lowres), _ptr(sel), B, in_hw[0], in_hw[1], out_hw[0], out_hw[1],
+         float(thr), float(off), _ptr(out_mask), _ptr(inter), _ptr(uni), _ptr(box), _ptr(tmp))
+
+
+def post_finalize(score, inter, uni, box, pred_iou_thresh, stab_thresh, filter_thresh, stability, keep, occ, B):
+    call("csam_post_finalize", _stream(), _ptr(score), _ptr(inter), _ptr(uni), _ptr(box), float(pred_iou_thresh),
+         float(stab_thresh), float(filter_thresh), _ptr(stability), _ptr(keep), _ptr(occ), B)
+
+
+def occupancy_lookup(points, masks, occ, B, H, W, out):
+    call("csam_occupancy_lookup", _stream(), _ptr(points), points.shape[0], _ptr(masks), _ptr(occ), B, H, W, _ptr(out))
+
+
+def box_nms(boxes, scores, thr):
+    """Greedy NMS (torchvision semantics).  boxes f32 [N,4], scores f32 [N] -> kept indices int64 (device)."""
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.zeros(0, dtype=torch.int64, device=boxes.device)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    nbytes = lib().csam_box_nms_workspace_bytes(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device)
+    keep = torch.empty(N, dtype=torch.int64, device=boxes.device)
+    count = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    call("csam_box_nms", _stream(), _ptr(boxes), _ptr(scores), N, float(thr), _ptr(keep), _ptr(count), _ptr(ws), nbytes)
+    return keep[: int(count.item())]
+
+
+def rle_encode(masks):
+    """Column-major change positions of u8 masks [N,H,W] -> (positions uint32 (device), offsets int64 (host, N+1))."""
+    N, H, W = masks.shape
+    col = torch.empty((N, W), dtype=torch.int32, device=masks.device)
+    totals = torch.empty(N, dtype=torch.int32, device=masks.device)
+    call("csam_rle_count", _stream(), _ptr(masks), N, H, W, _ptr(col), _ptr(totals))
+    tot = totals.cpu().to(torch.int64)
+    offs = torch.zeros(N + 1, dtype=torch.int64)
+    offs[1:] = torch.cumsum(tot, 0)
+    out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int32, device=masks.device)
+    offs_dev = offs[:-1].to(masks.device)
+    call("csam_rle_write", _stream(), _ptr(masks), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
+    return out, offs

@@ -1,0 +1,77 @@
+"""GPU parity of the HIP prompt-encoder + two-way decoder + PWD-Net heads against the reference's own
+outputs (tests/golden/decoder_test128.npz, captured by oracle/make_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _inputs():
+    rs = np.random.RandomState(11)
+    emb = torch.from_numpy(rs.standard_normal((1, 256, 64, 64)).astype(np.float32))
+    dino = torch.from_numpy(rs.standard_normal((1, 73, 73, 1024)).astype(np.float32))
+    pts = rs.randint(0, 1024, size=(5, 1, 2)).astype(np.float64)
+    return emb, dino, pts
+
+
+@pytest.fixture(scope="module")
+def plan(cuda):
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    sd = synth.make_sam_state_dict("vit_test128")
+    return DecoderPlan(sd, cuda, n_class=1, max_batch=8)
+
+
+def _set_image(plan, cuda):
+    emb, dino, pts = _inputs()
+    feat = emb[0].permute(1, 2, 0).reshape(4096, 256).contiguous().to(cuda)
+    dtok = torch.zeros(5376, 1024, dtype=torch.float16, device=cuda)
+    dtok[:5329] = dino.reshape(5329, 1024).to(cuda).half()
+    plan.set_image(feat, dtok)
+    return torch.from_numpy(pts[:, 0, :].astype(np.float32)).to(cuda).contiguous()
+
+
+def test_decoder_vs_reference_golden(plan, cuda):
+    g = np.load(os.path.join(G, "decoder_test128.npz"))
+    coords = _set_image(plan, cuda)
+    masks, iou, cls = plan.run_batch(coords)
+    torch.cuda.synchronize()
+    low = masks.cpu().numpy()
+    ref = g["low_sample"]
+    err = np.abs(low[:, :, ::8, ::8] - ref)
+    scale = np.abs(ref).mean()
+    print("low-res logits: mean|ref|=%.3f max err=%.4f mean err=%.5f" % (scale, err.max(), err.mean()))
+    assert err.mean() < 0.02 * scale and err.max() < 0.25 * scale
+    np.testing.assert_allclose(low.astype(np.float64).sum((2, 3)), g["low_sum"], rtol=0, atol=0.02 * scale * 65536)
+    e_iou = np.abs(iou.cpu().numpy() - g["iou"]).max()
+    e_cls = np.abs(cls.cpu().numpy() - g["cls"]).max()
+    print("iou err %.5f  cls err %.5f" % (e_iou, e_cls))
+    assert e_iou < 2e-2 and e_cls < 2e-2
+    # dense PE and point tokens are fp32 kernels: tight tolerance
+    pe = plan.pe.view(64, 64, 256).permute(2, 0, 1)[None].cpu().numpy()
+    np.testing.assert_allclose(pe[:, ::8, ::4, ::4], g["dense_pe_sample"], rtol=0, atol=2e-5)
+    tok = plan.ws["tokens0"][:35].view(5, 7, 256)[:, 5:7].cpu().numpy()
+    np.testing.assert_allclose(tok, g["sparse"], rtol=0, atol=2e-5)
+
+
+def test_fg_prior_vs_reference_golden(plan, cuda):
+    g = np.load(os.path.join(G, "decoder_test128.npz"))
+    _set_image(plan, cuda)
+    logits = plan.fg_logits()                                    # [5329, 1]
+    fg = torch.nn.functional.interpolate(logits.view(1, 73, 73, 1).permute(0, 3, 1, 2).cpu(), (256, 256),
+                                         mode="bilinear")      # test-side resample of the reference's 2nd step
+    err = np.abs(fg[:, :, ::8, ::8].numpy() - g["fg_sample"]).max()
+    assert err < 2e-2, err
+
+
+def test_batch_invariance(plan, cuda):
+    """The same prompt must decode identically alone and inside a larger batch (no cross-prompt leakage)."""
+    coords = _set_image(plan, cuda)
+    m_all, iou_all, cls_all = [t.clone() for t in plan.run_batch(coords)]
+    m_one, iou_one, cls_one = plan.run_batch(coords[2:3].contiguous())
+    assert (m_all[2] - m_one[0]).abs().max().item() < 1e-3
+    assert (iou_all[2] - iou_one[0]).abs().max().item() < 1e-4
