@@ -1,0 +1,286 @@
+"""CrowdSAM driver (reference: crowdsam/model.py:24-450) on the MI355X HIP path.
+
+Same constructor / ``generate`` contract and the same ``MaskData`` result fields as the reference
+(``boxes, scores, categories, rles, rles_info, points, stability_score, crop_boxes, fboxes``) for
+``sam_arch == 'crowdsam'``, ``trainfree == False``.  Control flow restates the Efficient Prompt
+Sampler exactly (global NumPy RNG shuffle, ``astype('int')`` truncation, occupancy REPLACED per
+batch, permanently shrinking batch size -- SURVEY.md traps 7/8), but the data movement is
+re-designed for the GPU:
+
+* per image ONE H2D (the uint8 frame); per EPS batch one small H2D (<=B point coordinates) and one
+  small D2H (scores / counts / boxes / keep flags and the occupancy bits of the REMAINING POINTS --
+  never the masks);
+* only the PWD-Net-selected candidate of each prompt is up-sampled, thresholded, counted and boxed,
+  in one fused kernel (csam_mask_post) -- the (B,4,H,W) fp32 tensors of the reference never exist;
+* when pruning is impossible (``filter_thresh`` = inf: the dense-sweep benchmark mode) the whole
+  sweep is queued without any host synchronisation.
+"""
+import logging
+import math
+
+import numpy as np
+import torch
+
+import crowdsam.utils as utils
+from crowdsam_amd import hip
+from crowdsam_amd.dino import DinoV2
+from segment_anything_cs.utils.amg import (MaskData, batched_mask_to_box, coco_encode_rle, generate_crop_boxes,
+                                           mask_to_rle_pytorch, remove_small_regions)
+
+
+def box_area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms for the single-category use of the reference (all idxs zero)."""
+    return hip.box_nms(boxes, scores, iou_threshold)
+
+
+class CrowdSAM:
+    vis_img_id = 0
+
+    def __init__(self, config, logger=None, sam_state_dict=None, dino_state_dict=None, dino_depth=24,
+                 dino_model=None):
+        """``config`` is the reference's YAML dict.  Checkpoints are read from the config paths as in
+        the reference (crowdsam/model.py:33-42, 88-115); ``sam_state_dict`` / ``dino_state_dict``
+        override them (synthetic weights: there are no checkpoints on the benchmark box)."""
+        self.logger = logger or logging.getLogger("crowdsam")
+        self.device = torch.device(config["environ"]["device"])
+        self.train_free = False
+        if config["model"].get("trainfree", False):
+            raise NotImplementedError("train-free branch is out of scope (SURVEY.md §2 #11)")
+        m = config["model"]
+        if dino_model is None:
+            dino_model = DinoV2(depth=dino_depth)
+            if dino_state_dict is None:
+                dino_state_dict = torch.load(m["dino_checkpoint"], map_location="cpu")
+            dino_model.load_state_dict(dino_state_dict)
+            dino_model = dino_model.to(self.device)
+        self.predictor = self.load_sam_model(m["sam_model"], m.get("sam_arch", "crowdsam"), m.get("sam_checkpoint"),
+                                             m.get("sam_adapter_checkpoint"), dino_model, m["n_class"],
+                                             sam_state_dict)
+        t = config["test"]
+        self.mask_selection = t["mask_selection"]
+        self.apply_box_offsets = t["apply_box_offsets"]
+        self.max_prompts = t["max_prompts"]
+        self.filter_thresh = t["filter_thresh"]
+        self.max_size = t["max_size"]
+        self.grid_size = t["grid_size"]
+        self.pred_iou_thresh = t["pred_iou_thresh"]
+        self.fuse_simmap = t["fuse_simmap"]
+        self.stability_score_thresh = t["stability_score_thresh"]
+        self.stability_score_offset = t["stability_score_offset"]
+        self.box_nms_thresh = t["box_nms_thresh"]
+        self.points_per_batch = t["points_per_batch"]
+        self.crop_n_layers = t["crop_n_layers"]
+        self.crop_nms_thresh = t["crop_nms_thresh"]
+        self.crop_overlap_ratio = t["crop_overlap_ratio"]
+        self.min_mask_region_area = t["min_mask_region_area"]
+        self.pos_sim_thresh = t["pos_sim_thresh"]
+        self.output_rles = t["output_rles"]
+        if self.mask_selection != "max_iou":
+            raise NotImplementedError("only mask_selection='max_iou' (the shipped config) runs on the fused HIP path")
+        if self.apply_box_offsets or self.fuse_simmap:
+            raise NotImplementedError("apply_box_offsets / fuse_simmap are off in the shipped config and not built")
+        self.timings = {}
+
+    def load_sam_model(self, sam_model, sam_arch, sam_checkpoint, sam_adapter_checkpoint, dino_model, n_class,
+                       sam_state_dict=None):
+        if sam_arch != "crowdsam":
+            raise NotImplementedError(f"sam_arch '{sam_arch}' imports packages outside the reference tree")
+        from segment_anything_cs import SamPredictor, sam_model_registry
+        sam = sam_model_registry[sam_model](checkpoint=None if sam_state_dict is not None else sam_checkpoint,
+                                            n_class=n_class)
+        if sam_state_dict is not None:
+            sam.load_state_dict(sam_state_dict, strict=False)
+        elif sam_adapter_checkpoint:
+            sam.mask_decoder.load_state_dict(torch.load(sam_adapter_checkpoint, map_location="cpu"), strict=False)
+        sam = sam.to(self.device)
+        return SamPredictor(sam, dino_model)
+
+    # ------------------------------------------------------------------------------------------
+    def crop_image(self, image, crop_box, sim_map=None):
+        x0, y0, x1, y1 = crop_box
+        if not isinstance(image, np.ndarray):
+            image = np.array(image, dtype=np.uint8)
+        self.orig_image = image
+        image, r = utils.resize_image(image[y0:y1, x0:x1, :], self.max_size)
+        self.image = image
+        self.downscale = r
+
+    @torch.no_grad()
+    def generate(self, image):
+        """image: HWC uint8 RGB ndarray (or PIL image) -> MaskData of numpy fields."""
+        return self._generate_masks(image)
+
+    def _generate_masks(self, image):
+        img_size = np.array(image).shape[:2]
+        crop_boxes, _ = generate_crop_boxes(img_size, self.crop_n_layers, self.crop_overlap_ratio)
+        data = MaskData()
+        for crop_box in crop_boxes:
+            crop_data = self._process_crop(image, crop_box)
+            if crop_data is not None:
+                data.cat(crop_data)
+        if len(crop_boxes) > 1 and "crop_boxes" in data and len(data["crop_boxes"]) > 0:
+            scores = (1 / box_area(data["crop_boxes"])).to(data["boxes"].device)   # prefer small crops
+            keep = batched_nms(data["boxes"].float(), scores, None, self.crop_nms_thresh)
+            rles_info = data["rles_info"]
+            del data["rles_info"]            # per-crop list: not a per-mask field (reference crashes here)
+            data.filter(keep)
+            data["rles_info"] = rles_info
+            del data["crop_boxes"]
+        if len(data._stats.keys()) > 0:
+            del data["iou_preds"]
+        else:
+            data["boxes"] = torch.zeros(0, 4)
+            data["scores"] = torch.zeros(0, 4)
+        data["rles"] = [coco_encode_rle(r) for r in data["rles"]] if "rles" in data else []
+        data.to_numpy()
+        return data
+
+    # ------------------------------------------------------------------------------------------
+    def sample_prompts(self):
+        """FG prior -> grid -> threshold -> pixel coordinates (crowdsam/model.py:196-223)."""
+        h, w = self.image.shape[:2]
+        g = self.grid_size
+        img_size = torch.tensor([h, w])
+        feat_size = (img_size * min(g / img_size)).int()
+        sim = self.predictor.predict_fg_map(img_size)                    # [1,C,256,256]
+        sim = hip.bilinear_f32(sim[0], (g, g))                           # [C,g,g]
+        sim = hip.sigmoid_max(sim.view(sim.shape[0], g * g)).view(g, g)
+        self.sim_map = sim
+        sim_c = sim[: int(feat_size[0]), : int(feat_size[1])].cpu()      # one small D2H
+        coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
+        inv_factor = torch.tensor([feat_size[1] / w, feat_size[0] / h])
+        return (coords / inv_factor).numpy()
+
+    def _process_crop(self, image, crop_box):
+        self.crop_image(image, crop_box)
+        self.predictor.set_image(self.image)
+        H, W = self.image.shape[:2]
+        orig_h, orig_w = self.orig_image.shape[:2]
+        points_for_image = self.sample_prompts()
+        dev = self.device
+        prune = math.isfinite(self.filter_thresh)
+        chunks = []                                  # per batch: dict of device tensors (+ host keep if synced)
+        occupy_bits = None
+
+        points = points_for_image.astype("int")      # :230 truncation
+        np.random.shuffle(points)                    # :231 global RNG (seeded by the harness)
+        count = 0
+        batch_size = self.points_per_batch
+        while len(points) > 0 and count < self.max_prompts:
+            batch_size = min(len(points), batch_size)
+            sel_pts, points = points[:batch_size], points[batch_size:]
+            bd = self._process_batch(sel_pts, self.predictor.original_size, crop_box)
+            if prune and len(points) > 0:
+                rem = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+                occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
+                hip.occupancy_lookup(rem, bd["masks_all"], bd["occ"], batch_size, H, W, occupy_bits)
+                points = points[~occupy_bits.cpu().numpy().astype(bool)]      # the per-batch sync
+            chunks.append(bd)
+            count += batch_size
+        self.predictor.reset_image()
+        if not chunks:
+            return None
+        data = self._gather_batches(chunks)
+        if data is None or len(data["masks"]) == 0:
+            return None
+
+        keep = batched_nms(data["boxes"].float(), data["iou_preds"], None, self.box_nms_thresh)
+        data.filter(keep)
+        if self.min_mask_region_area > 0:
+            data = self.postprocess_small_regions(data, self.min_mask_region_area,
+                                                  max(self.box_nms_thresh, self.crop_nms_thresh))
+        data["scores"] = data["iou_preds"]
+        data["rles"] = mask_to_rle_pytorch(data["masks"])
+        data["rles_info"] = [crop_box, [orig_h, orig_w]]
+        del data["masks"]
+        data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, self.downscale)
+        data["points"] = utils.uncrop_points(data["points"], crop_box, self.downscale)
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["boxes"]))])
+        data["fboxes"] = data["boxes"]
+        return data
+
+    def _gather_batches(self, chunks):
+        """Concatenate the kept prompts of every batch (one sync for the keep flags)."""
+        keep = torch.cat([c["keep"] for c in chunks]).bool()
+        if self.crop_n_layers > 0:
+            boxes_all = torch.cat([c["boxes"] for c in chunks])
+            orig_h, orig_w = self.orig_image.shape[:2]
+            keep &= ~utils.is_box_near_crop_edge(boxes_all, self._crop_box, [0, 0, orig_w, orig_h], self.downscale)
+        idx = keep.nonzero()[:, 0]
+        if idx.numel() == 0:
+            return None
+        cat = lambda k: torch.cat([c[k] for c in chunks])[idx]
+        masks = torch.cat([c["masks_all"] for c in chunks])[idx] if len(chunks) > 1 else chunks[0]["masks_all"][idx]
+        return MaskData(masks=masks.bool(), iou_preds=cat("score"), points=cat("points"),
+                        categories=cat("category").long(), stability_score=cat("stability"),
+                        boxes=cat("boxes").long())
+
+    def select_mask(self, masks, iou_preds):
+        if self.mask_selection != "max_iou":
+            raise NotImplementedError
+        return torch.arange(len(masks)), iou_preds.max(dim=-1)[1]
+
+    def _process_batch(self, points, im_size, crop_box):
+        """One EPS batch: decode B prompts, PWD-Net selection, fused post-processing.
+        Returns device tensors for ALL B prompts plus keep / occupancy flags (filtering is deferred
+        to ``_gather_batches`` so that no host sync is needed here)."""
+        self._crop_box = crop_box
+        p = self.predictor
+        dev = self.device
+        B = len(points)
+        H, W = p.original_size
+        tp = p.transform.apply_coords(points, im_size)                       # float64 on the host (trap 6)
+        in_points = torch.as_tensor(tp)[:, None, :]
+        low, iou, cls = p.decode_points(in_points, None)
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+        sel, category = i32(B), i32(B)
+        score = torch.empty(B, dtype=torch.float32, device=dev)
+        hip.select_masks(iou, cls, cls.shape[-1], sel, score, category, None, B)
+        masks = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+        inter, uni, box = i32(B), i32(B), i32(B, 4)
+        tmp = None
+        if tuple(p.input_size) != (H, W):
+            tmp = torch.empty(B, p.input_size[0], p.input_size[1], dtype=torch.float32, device=dev)
+        hip.mask_post(low, sel, B, p.input_size, (H, W), p.model.mask_threshold, self.stability_score_offset,
+                      masks, inter, uni, box, tmp)
+        stability = torch.empty(B, dtype=torch.float32, device=dev)
+        keep = torch.empty(B, dtype=torch.uint8, device=dev)
+        occ = torch.empty(B, dtype=torch.uint8, device=dev)
+        hip.post_finalize(score, inter, uni, box, self.pred_iou_thresh, self.stability_score_thresh,
+                          self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
+                          stability, keep, occ, B)
+        return dict(masks_all=masks, score=score, category=category, stability=stability, boxes=box, keep=keep,
+                    occ=occ, points=torch.as_tensor(points).to(dev))
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def postprocess_small_regions(mask_data, min_area, nms_thresh):
+        """Hole filling / island removal on the host (as the reference: crowdsam/model.py:394-443) and
+        a second NMS that prefers untouched masks."""
+        if len(mask_data["masks"]) == 0:
+            return mask_data
+        dev = mask_data["masks"].device
+        new_masks, scores = [], []
+        for mask in mask_data["masks"].cpu().numpy():
+            mask, changed = remove_small_regions(mask, min_area, mode="holes")
+            unchanged = not changed
+            mask, changed = remove_small_regions(mask, min_area, mode="islands")
+            unchanged = unchanged and not changed
+            new_masks.append(torch.as_tensor(mask).unsqueeze(0))
+            scores.append(float(unchanged))
+        masks = torch.cat(new_masks, dim=0)
+        boxes = batched_mask_to_box(masks)
+        keep = batched_nms(boxes.float().to(dev), torch.as_tensor(scores, device=dev), None, nms_thresh)
+        for i in keep.tolist():
+            if scores[i] == 0.0:
+                mask_data["boxes"][i] = boxes[i].to(dev)
+                mask_data["masks"][i] = masks[i].to(dev)
+        mask_data.filter(keep)
+        return mask_data
+
+    def match_ref(self, sim_map, pos_sim_thresh):
+        return (sim_map > pos_sim_thresh).nonzero()[:, [1, 0]]

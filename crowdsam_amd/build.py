@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
                         for h in os.listdir(CSRC) if h.endswith(".h"))):
             continue
         cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-               "-Wno-unused-result", "-c", src, "-o", obj]
+               "-Wno-unused-result", "-Wno-unused-value", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

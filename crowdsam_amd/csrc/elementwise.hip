@@ -108,7 +108,7 @@ __device__ __forceinline__ float norm_px(const float* img, int h, int w, int c, 
   return (y < h && x < w) ? (img[((long)c * h + y) * w + x] - mean) / stdv : 0.f;
 }
 
-__global__ __launch_bounds__(256) void dino_im2col_kernel(const float* __restrict__ img, int h, int w,
+__global__ __launch_bounds__(256) void dino_im2col_kernel(const float* __restrict__ img, int h, int w, int S,
                                                           floatx4 mean, floatx4 stdv,
                                                           half_t* __restrict__ out) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -118,13 +118,13 @@ __global__ __launch_bounds__(256) void dino_im2col_kernel(const float* __restric
   if (k < 588) {
     const int c = k / 196, r = k % 196, dy = r / 14, dx = r % 14;
     const int Y = (t / 73) * 14 + dy, X = (t % 73) * 14 + dx;
-    const float sc = 1024.0f / 1022.0f;
+    const float sc = (float)S / 1022.0f;   // frame size S (1024: padded SAM frame; 1022: already resized)
     float sy = sc * ((float)Y + 0.5f) - 0.5f;
     float sx = sc * ((float)X + 0.5f) - 0.5f;
     sy = sy < 0.f ? 0.f : sy;
     sx = sx < 0.f ? 0.f : sx;
     const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < 1023 ? 1 : 0), x1 = x0 + (x0 < 1023 ? 1 : 0);
+    const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
     const float m = mean[c], s = stdv[c];
     const float v00 = norm_px(img, h, w, c, y0, x0, m, s), v01 = norm_px(img, h, w, c, y0, x1, m, s);
@@ -171,7 +171,43 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
   }
 }
 
+// Sam.preprocess (sam.py:163-173) materialised: (x-mean)/std, zero pad to [3,1024,1024] fp32.
+__global__ __launch_bounds__(256) void preprocess_pad_kernel(const float* __restrict__ img, int h, int w,
+                                                             floatx4 mean, floatx4 stdv, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 3 * 1024 * 1024) return;
+  const int c = idx >> 20, y = (idx >> 10) & 1023, x = idx & 1023;
+  out[idx] = (y < h && x < w) ? (img[((long)c * h + y) * w + x] - mean[c]) / stdv[c] : 0.f;
+}
+
+// out[i] = max_c sigmoid(x[c, i])   (crowdsam/model.py:203)
+__global__ __launch_bounds__(256) void sigmoid_max_kernel(const float* __restrict__ x, int C, int N,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float m = -INFINITY;
+  for (int c = 0; c < C; ++c) m = fmaxf(m, 1.0f / (1.0f + expf(-x[(long)c * N + i])));
+  out[i] = m;
+}
+
 }  // namespace
+
+extern "C" int csam_preprocess_pad(void* stream, const float* img_chw, int h, int w, const float* mean3,
+                                   const float* std3, float* out) {
+  CSAM_REQUIRE(img_chw && out && h > 0 && w > 0 && h <= 1024 && w <= 1024, "csam_preprocess_pad: bad args");
+  floatx4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+  hipLaunchKernelGGL(preprocess_pad_kernel, dim3(3 * 1024 * 1024 / 256), dim3(256), 0, (hipStream_t)stream, img_chw,
+                     h, w, m, sd, out);
+  CSAM_LAUNCH_CHECK("csam_preprocess_pad");
+  return CSAM_OK;
+}
+
+extern "C" int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out) {
+  CSAM_REQUIRE(x && out && C > 0 && N > 0, "csam_sigmoid_max: bad args");
+  hipLaunchKernelGGL(sigmoid_max_kernel, dim3(csam_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, x, C, N, out);
+  CSAM_LAUNCH_CHECK("csam_sigmoid_max");
+  return CSAM_OK;
+}
 
 extern "C" int csam_layernorm(void* stream, const void* x, long ldx, int x_dtype, void* y, long ldy,
                               int y_dtype, const float* gamma, const float* beta, int M, int D,
@@ -207,12 +243,13 @@ extern "C" int csam_sam_im2col(void* stream, const float* img_chw, int h, int w,
   return CSAM_OK;
 }
 
-extern "C" int csam_dino_im2col(void* stream, const float* img_chw, int h, int w, const float* mean3,
+extern "C" int csam_dino_im2col(void* stream, const float* img_chw, int h, int w, int frame, const float* mean3,
                                 const float* std3, void* out_f16) {
-  CSAM_REQUIRE(img_chw && out_f16 && h > 0 && w > 0 && h <= 1024 && w <= 1024, "csam_dino_im2col: bad args");
+  CSAM_REQUIRE(img_chw && out_f16 && h > 0 && w > 0 && h <= frame && w <= frame && (frame == 1024 || frame == 1022),
+               "csam_dino_im2col: bad args");
   floatx4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
   hipLaunchKernelGGL(dino_im2col_kernel, dim3(csam_cdiv(5329L * 640, 256)), dim3(256), 0, (hipStream_t)stream,
-                     img_chw, h, w, m, sd, (half_t*)out_f16);
+                     img_chw, h, w, frame, m, sd, (half_t*)out_f16);
   CSAM_LAUNCH_CHECK("csam_dino_im2col");
   return CSAM_OK;
 }

@@ -248,6 +248,22 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
   return CSAM_OK;
 }
 
+// Generic bilinear resize (align_corners=False) of fp32 planes [n, sh, sw] -> [n, H, W]:
+// predictor.py:116 (FG logits 73->256), crowdsam/model.py:202 (256 -> grid), predictor.py:104
+// (1024 -> 1022 for third-party DINO models), and the API-compatible full postprocess_masks.
+extern "C" int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W) {
+  CSAM_REQUIRE(src && dst && n > 0 && sh > 0 && sw > 0 && H > 0 && W > 0, "csam_bilinear_f32: bad args");
+  PostArgs a;
+  a.src = src; a.src_bstride = (long)sh * sw; a.plane = 0; a.sel = nullptr;
+  a.sh = sh; a.sw = sw; a.scale_y = (float)sh / (float)H; a.scale_x = (float)sw / (float)W;
+  a.H = H; a.W = W; a.thr = 0.f; a.off = 0.f;
+  a.out_f32 = dst; a.out_mask = nullptr; a.inter = nullptr; a.uni = nullptr; a.box = nullptr;
+  dim3 grid(csam_cdiv(W, 256), csam_cdiv(H, 4), n);
+  hipLaunchKernelGGL(mask_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  CSAM_LAUNCH_CHECK("csam_bilinear_f32");
+  return CSAM_OK;
+}
+
 extern "C" int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
                                   float pred_iou_thresh, float stability_thresh, float filter_thresh,
                                   float* stability, void* keep_u8, void* occ_u8, int B) {

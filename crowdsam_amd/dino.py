@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from . import hip
 
 T_DINO = 5330
+N_PATCH = 5329
 GRID = 73
 
 
@@ -64,13 +65,13 @@ class DinoPlan:
         self.ws = dict(col=e(5329, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
                        attn=e(TP, D), mlp=e(TP, 4 * D))
 
-    def forward(self, img_chw_f32, out=None):
+    def forward(self, img_chw_f32, out=None, normalized_1022=False):
         """raw f32 [3,h,w] image (0..255) -> x_norm_patchtokens f16 [5329, D]."""
         D, nH, T = self.D, self.heads, T_DINO
         ws = self.ws
         x = ws["x"]
         scale = 64 ** -0.5
-        hip.dino_im2col(img_chw_f32, ws["col"])
+        hip.dino_im2col(img_chw_f32, ws["col"], normalized_1022)
         x[0:1].copy_(self.cls_row)
         hip.gemm_f16(ws["col"], self.patch_w, out=x[1:], bias=self.patch_b, residual=self.pos[1:], M=5329)
         for b in self.blocks:
@@ -89,3 +90,51 @@ class DinoPlan:
     def flops(self):
         D, T = self.D, T_DINO
         return self.depth * (2 * T * D * 12 * D + 4 * T * T * D) + 2 * 5329 * 588 * D
+
+
+class DinoV2(torch.nn.Module):
+    """Parameter container with the facebookresearch/dinov2 ViT-L/14 checkpoint keys and a HIP
+    forward.  Stands where the reference calls ``torch.hub.load(dino_repo, 'dinov2_vitl14', ...)``
+    (crowdsam/model.py:33-36): same ``load_state_dict`` / ``.to`` / ``forward_features`` surface."""
+
+    def __init__(self, embed_dim=1024, depth=24, num_heads=16, pos_offset=0.1):
+        super().__init__()
+        from . import synth
+        self.embed_dim, self.depth, self.num_heads, self.pos_offset = embed_dim, depth, num_heads, pos_offset
+        for name, shape, _k, _f in synth.dino_param_specs(embed_dim, depth):
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, torch.nn.Module())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], torch.nn.Parameter(torch.zeros(shape), requires_grad=False))
+        self._plan = None
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def plan(self):
+        if self._plan is None:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("crowdsam_amd runs on MI355X only: move DinoV2 to 'cuda' first")
+            self._plan = DinoPlan(self.state_dict(), dev, self.depth, self.num_heads, self.pos_offset)
+        return self._plan
+
+    @torch.no_grad()
+    def patch_tokens16(self, raw_chw_f32, out):
+        """Fast path: raw image -> x_norm_patchtokens fp16 written into out[:5329]."""
+        return self.plan().forward(raw_chw_f32, out=out[:N_PATCH])
+
+    @torch.no_grad()
+    def forward_features(self, x):
+        """API path (predictor.py:105): x [1,3,1022,1022] normalised -> {'x_norm_patchtokens': [1,5329,D]}."""
+        assert x.shape[0] == 1 and tuple(x.shape[1:]) == (3, 1022, 1022)
+        t = self.plan().forward(x[0].float().contiguous(), normalized_1022=True)
+        return {"x_norm_patchtokens": t.float().unsqueeze(0)}

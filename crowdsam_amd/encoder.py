@@ -51,12 +51,14 @@ class EncoderPlan:
             tw=e(heads, 4096, 64, dt=torch.float32), n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
             col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32))
 
-    def forward(self, img_chw_f32, out=None):
-        """img f32 [3,h,w] raw 0..255 (long side <= 1024) -> features f32 [4096,256] token-major."""
+    def forward(self, img_chw_f32, out=None, skip_im2col=False):
+        """img f32 [3,h,w] raw 0..255 (long side <= 1024) -> features f32 [4096,256] token-major.
+        ``skip_im2col``: ws['col'] was already filled (API path with a pre-normalised tensor)."""
         D, nH = self.D, self.heads
         ws = self.ws
         scale = 64 ** -0.5
-        hip.sam_im2col(img_chw_f32, ws["col"])
+        if not skip_im2col:
+            hip.sam_im2col(img_chw_f32, ws["col"])
         x = hip.gemm_f16(ws["col"], self.patch_w, out=ws["x"], bias=self.patch_b, residual=self.pos)
         for b in self.blocks:
             hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])

@@ -25,7 +25,7 @@ SIGNATURES = {
     "csam_gemm_f16": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I],
     "csam_layernorm": [_P, _P, _L, _I, _P, _L, _I, _P, _P, _I, _I, _F],
     "csam_sam_im2col": [_P, _P, _I, _I, _P, _P, _P],
-    "csam_dino_im2col": [_P, _P, _I, _I, _P, _P, _P],
+    "csam_dino_im2col": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_im2col3x3": [_P, _P, _P, _I],
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
     "csam_win_attn": [_P, _P, _P, _P, _P, _P, _I, _I, _F],
@@ -51,6 +51,9 @@ SIGNATURES = {
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
+    "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
+    "csam_sigmoid_max": [_P, _P, _I, _I, _P],
 }
 LONG_RETURNS = {
     "csam_attn_t2i_workspace_bytes": [_I, _I],
@@ -153,17 +156,29 @@ _MEAN = (_F * 3)(123.675, 116.28, 103.53)   # sam.py:38-39 pixel_mean / pixel_st
 _STD = (_F * 3)(58.395, 57.12, 57.375)
 
 
-def sam_im2col(img_chw, out):
-    """Sam.preprocess + 16x16 patch im2col: img f32 [3,h,w] (0..255) -> out f16 [4096,768]."""
+_ZERO3 = (_F * 3)(0.0, 0.0, 0.0)
+_ONE3 = (_F * 3)(1.0, 1.0, 1.0)
+
+
+def sam_im2col(img_chw, out, normalized=False):
+    """Sam.preprocess + 16x16 patch im2col: img f32 [3,h,w] (0..255) -> out f16 [4096,768].
+    ``normalized=True``: the input is already (x-mean)/std (API path: image_encoder(preprocessed))."""
     assert img_chw.dtype == torch.float32 and img_chw.is_contiguous()
-    call("csam_sam_im2col", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2], _MEAN, _STD, _ptr(out))
+    call("csam_sam_im2col", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2],
+         _ZERO3 if normalized else _MEAN, _ONE3 if normalized else _STD, _ptr(out))
     return out
 
 
-def dino_im2col(img_chw, out):
-    """preprocess + bilinear 1024->1022 + 14x14 patch im2col: -> out f16 [5329,640]."""
+def dino_im2col(img_chw, out, normalized_1022=False):
+    """preprocess + bilinear 1024->1022 + 14x14 patch im2col: -> out f16 [5329,640].
+    ``normalized_1022=True``: the input is the already normalised/resized [3,1022,1022] tensor (API path)."""
     assert img_chw.dtype == torch.float32 and img_chw.is_contiguous()
-    call("csam_dino_im2col", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2], _MEAN, _STD, _ptr(out))
+    if normalized_1022:
+        assert tuple(img_chw.shape) == (3, 1022, 1022)
+        call("csam_dino_im2col", _stream(), _ptr(img_chw), 1022, 1022, 1022, _ZERO3, _ONE3, _ptr(out))
+    else:
+        call("csam_dino_im2col", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2], 1024, _MEAN, _STD,
+             _ptr(out))
     return out
 
 
@@ -325,3 +340,26 @@ def rle_encode(masks):
     offs_dev = offs[:-1].to(masks.device)
     call("csam_rle_write", _stream(), _ptr(masks), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
     return out, offs
+
+
+def bilinear_f32(src, out_hw):
+    """fp32 [n, sh, sw] -> [n, H, W], torch F.interpolate(mode='bilinear', align_corners=False) semantics."""
+    n, sh, sw = src.shape
+    out = torch.empty((n, out_hw[0], out_hw[1]), dtype=torch.float32, device=src.device)
+    call("csam_bilinear_f32", _stream(), _ptr(src), n, sh, sw, _ptr(out), out_hw[0], out_hw[1])
+    return out
+
+
+def preprocess_pad(img_chw):
+    """Sam.preprocess: raw f32 [3,h,w] -> normalised, zero-padded f32 [3,1024,1024]."""
+    out = torch.empty((3, 1024, 1024), dtype=torch.float32, device=img_chw.device)
+    call("csam_preprocess_pad", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2], _MEAN, _STD, _ptr(out))
+    return out
+
+
+def sigmoid_max(x):
+    """x f32 [C, N] -> max_c sigmoid(x) f32 [N]."""
+    C, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    call("csam_sigmoid_max", _stream(), _ptr(x), C, N, _ptr(out))
+    return out

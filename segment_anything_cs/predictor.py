@@ -1,0 +1,157 @@
+"""SamPredictor facade (reference: segment_anything_cs/predictor.py:14-318) on the HIP path.
+
+Same constructor, methods, attributes and errors as the reference for the Crowd-SAM usage:
+``set_image / set_torch_image / predict_fg_map / predict / predict_torch / get_image_embedding /
+reset_image`` and ``model, dino_model, transform, features, dino_feats, original_size, input_size,
+is_image_set, device``.  Per image: ONE H2D copy of the uint8 frame; the encoder, DINOv2 and the
+hoisted decoder constants stay resident in HBM until ``reset_image``.
+"""
+import numpy as np
+import torch
+
+from crowdsam_amd import hip
+from crowdsam_amd.decoder import N_DINO, N_DINO_PAD
+from crowdsam_amd.dino import DinoV2
+
+from .utils.transforms import ResizeLongestSide
+
+
+class SamPredictor:
+    def __init__(self, sam_model, dino_model):
+        self.model = sam_model
+        self.dino_model = dino_model
+        self.transform = ResizeLongestSide(sam_model.image_encoder.img_size)
+        self._dtok16 = None
+        self.reset_image()
+
+    # ------------------------------------------------------------------------------------------
+    def set_image(self, image, mask=None, image_format="RGB", cal_image=True):
+        assert image_format in ["RGB", "BGR"], f"image_format must be in ['RGB', 'BGR'], is {image_format}."
+        if image_format != self.model.image_format:
+            image = image[..., ::-1]
+        input_image = self.transform.apply_image(image)
+        t = torch.as_tensor(np.ascontiguousarray(input_image)).to(self.device, non_blocking=True)
+        t = t.permute(2, 0, 1).contiguous()[None, :, :, :]
+        tm = None
+        if mask is not None:
+            m = torch.as_tensor(np.ascontiguousarray(self.transform.apply_image(mask)), device=self.device)
+            tm = m.permute(2, 0, 1).contiguous()[None, :, :, :]
+        return self.set_torch_image(t, image.shape[:2], transformed_mask=tm, cal_image=cal_image)
+
+    @torch.no_grad()
+    def set_torch_image(self, transformed_image, original_image_size, transformed_mask=None, cal_image=True):
+        size = self.model.image_encoder.img_size
+        assert (len(transformed_image.shape) == 4 and transformed_image.shape[1] == 3
+                and max(*transformed_image.shape[2:]) == size), \
+            f"set_torch_image input must be BCHW with long side {size}."
+        if cal_image:
+            self.reset_image()
+            self.original_size = tuple(original_image_size)
+            self.input_size = tuple(transformed_image.shape[-2:])
+            raw = transformed_image[0].to(self.device).float().contiguous()      # [3,h,w], 0..255
+            self._feat_tok = self.model.image_encoder.forward_tokens(raw)
+            if self._dtok16 is None or self._dtok16.device != raw.device:
+                self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
+            if isinstance(self.dino_model, DinoV2):
+                self.dino_model.patch_tokens16(raw, self._dtok16)
+            else:   # third-party DINO object: feed it the reference's tensor (predictor.py:104-106)
+                x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
+                tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
+                self._dtok16[:N_DINO].copy_(tok.reshape(N_DINO, -1))
+            self._plan = self.model.decoder_plan()
+            self._plan.set_image(self._feat_tok, self._dtok16)
+            self.is_image_set = True
+        if transformed_mask is not None:
+            return self.model.preprocess(transformed_mask)
+
+    # lazily materialised API views of the resident state
+    @property
+    def features(self):
+        if self._feat_tok is None:
+            return None
+        return self._feat_tok.view(64, 64, 256).permute(2, 0, 1).unsqueeze(0)
+
+    @features.setter
+    def features(self, v):
+        self._feat_tok = None if v is None else v[0].permute(1, 2, 0).reshape(4096, 256).contiguous()
+
+    @property
+    def dino_feats(self):
+        if not self.is_image_set:
+            return None
+        return self._dtok16[:N_DINO].float().view(1, 73, 73, -1)
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_fg_map(self, img_size=None):
+        """[1,n_class,256,256] foreground logits (predictor.py:113-121)."""
+        self._require_image()
+        logits = self._plan.fg_logits()                               # [5329, C]
+        planes = logits.t().contiguous().view(-1, 73, 73)
+        return hip.bilinear_f32(planes, (256, 256)).unsqueeze(0)
+
+    def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
+                return_logits=False, attn_sim=None, target_embedding=None):
+        """Numpy front-end of predict_torch (predictor.py:133-212)."""
+        self._require_image()
+        coords_t = labels_t = None
+        if point_coords is not None:
+            assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
+            pc = self.transform.apply_coords(point_coords, self.original_size)
+            coords_t = torch.as_tensor(pc, dtype=torch.float, device=self.device)[None, :, :]
+            labels_t = torch.as_tensor(point_labels, dtype=torch.int, device=self.device)[None, :]
+        if box is not None or mask_input is not None:
+            raise NotImplementedError("box / mask prompts are not on Crowd-SAM's inference path")
+        masks, iou, cls, low = self.predict_torch(coords_t, labels_t, None, None, multimask_output,
+                                                  return_logits=return_logits)
+        return masks[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy(), masks[0]
+
+    @torch.no_grad()
+    def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output=True,
+                      return_logits=False, attn_sim=None, target_embedding=None):
+        """(masks [B,C,H,W], iou [B,C], class_scores [B,C,n_class], low_res [B,C,256,256])."""
+        self._require_image()
+        low, iou, cls = self.decode_points(point_coords, point_labels, boxes, mask_input, attn_sim, target_embedding)
+        if not multimask_output:
+            low, iou, cls = low[:, :1], iou[:, :1], cls[:, :1]
+        masks = self.model.postprocess_masks(low, self.input_size, self.original_size)
+        if not return_logits:
+            masks = masks > self.model.mask_threshold
+        return masks, iou, cls, low
+
+    @torch.no_grad()
+    def decode_points(self, point_coords, point_labels, boxes=None, mask_input=None, attn_sim=None,
+                      target_embedding=None):
+        """Prompt encoder + mask decoder for one-point prompts: coords [B,1,2] in the input frame.
+        Returns views into the plan's workspace (valid until the next decode)."""
+        self._require_image()
+        if boxes is not None or mask_input is not None or attn_sim is not None or target_embedding is not None:
+            raise NotImplementedError("only point prompts are on Crowd-SAM's inference path")
+        if point_coords is None or point_coords.dim() != 3 or point_coords.shape[1] != 1:
+            raise NotImplementedError("the HIP decoder takes exactly one positive point per prompt")
+        if point_labels is not None and not bool((torch.as_tensor(point_labels) == 1).all()):
+            raise NotImplementedError("only foreground (label 1) point prompts are supported")
+        # trap 6: the frame scaling was done by the caller in float64; (x+0.5)/1024 is exact in fp32
+        c = torch.as_tensor(point_coords)[:, 0, :].to(device=self.device, dtype=torch.float32).contiguous()
+        return self._plan.run_batch(c)
+
+    def get_image_embedding(self):
+        if not self.is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) to generate an embedding.")
+        return self.features
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def reset_image(self):
+        self.is_image_set = False
+        self._feat_tok = None
+        self._plan = None
+        self.original_size = None
+        self.input_size = None
+        self.orig_h = self.orig_w = self.input_h = self.input_w = None
+
+    def _require_image(self):
+        if not self.is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")

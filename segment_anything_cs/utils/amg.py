@@ -1,0 +1,222 @@
+"""Mask-data utilities of the reference's AMG module that Crowd-SAM uses
+(reference: segment_anything_cs/utils/amg.py; imported at crowdsam/model.py:13-22).
+
+``MaskData`` is the API type ``CrowdSAM.generate`` returns.  The tensor reductions
+(stability score, mask->box, RLE) run as HIP kernels when handed CUDA tensors; the driver's hot loop
+does not even call them -- it uses the fused csam_mask_post kernel -- they exist for API parity.
+Host-side pieces (connected components, COCO string packing) are host code in the reference too
+(cv2 / pycocotools there; scipy / an own encoder here).
+"""
+import math
+from copy import deepcopy
+from itertools import product
+
+import numpy as np
+import torch
+
+from crowdsam_amd import hip
+
+
+class MaskData:
+    """Dict of per-mask fields (lists, ndarrays or tensors) with batched filter / cat."""
+
+    def __init__(self, **kwargs):
+        for v in kwargs.values():
+            self._check(v)
+        self._stats = dict(**kwargs)
+
+    @staticmethod
+    def _check(v):
+        assert isinstance(v, (list, np.ndarray, torch.Tensor)), \
+            "MaskData only supports list, numpy arrays, and torch tensors."
+
+    def __setitem__(self, key, item):
+        self._check(item)
+        self._stats[key] = item
+
+    def __delitem__(self, key):
+        del self._stats[key]
+
+    def __getitem__(self, key):
+        return self._stats[key]
+
+    def __contains__(self, key):
+        return key in self._stats
+
+    def items(self):
+        return self._stats.items()
+
+    def filter(self, keep):
+        for k, v in self._stats.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v[torch.as_tensor(keep, device=v.device)]
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = v[keep.detach().cpu().numpy()]
+            elif isinstance(v, list):
+                if keep.dtype == torch.bool:
+                    self._stats[k] = [a for a, f in zip(v, keep.tolist()) if f]
+                else:
+                    self._stats[k] = [v[i] for i in keep.tolist()]
+            else:
+                raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
+
+    def cat(self, new_stats):
+        for k, v in new_stats.items():
+            if k not in self._stats or self._stats[k] is None:
+                self._stats[k] = deepcopy(v)
+            elif isinstance(v, torch.Tensor):
+                self._stats[k] = torch.cat([self._stats[k], v], dim=0)
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = np.concatenate([self._stats[k], v], axis=0)
+            elif isinstance(v, list):
+                self._stats[k] = self._stats[k] + deepcopy(v)
+            else:
+                raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
+
+    def to_numpy(self):
+        for k, v in self._stats.items():
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v.detach().cpu().numpy()
+
+
+def batch_iterator(batch_size, *args):
+    assert len(args) > 0 and all(len(a) == len(args[0]) for a in args), \
+        "Batched iteration must have inputs of all the same size."
+    for start in range(0, len(args[0]), batch_size):
+        yield [a[start:start + batch_size] for a in args]
+
+
+def generate_crop_boxes(im_size, n_layers, overlap_ratio):
+    """Layer i has (2**i)**2 crops; layer 0 is the whole image (amg.py:200-234)."""
+    im_h, im_w = im_size
+    short_side = min(im_h, im_w)
+    crop_boxes, layer_idxs = [[0, 0, im_w, im_h]], [0]
+
+    def span(length, n, overlap):
+        return int(math.ceil((overlap * (n - 1) + length) / n))
+
+    for layer in range(n_layers):
+        n = 2 ** (layer + 1)
+        overlap = int(overlap_ratio * short_side * (2 / n))
+        cw, ch = span(im_w, n, overlap), span(im_h, n, overlap)
+        x0s = [int((cw - overlap) * i) for i in range(n)]
+        y0s = [int((ch - overlap) * i) for i in range(n)]
+        for x0, y0 in product(x0s, y0s):
+            crop_boxes.append([x0, y0, min(x0 + cw, im_w), min(y0 + ch, im_h)])
+            layer_idxs.append(layer + 1)
+    return crop_boxes, layer_idxs
+
+
+def calculate_stability_score(masks, mask_threshold, threshold_offset):
+    """IoU of the masks thresholded at +-offset (amg.py:156-176); int32 counts -> fp32 ratio."""
+    hi = (masks > (mask_threshold + threshold_offset)).flatten(-2).sum(-1, dtype=torch.int32)
+    lo = (masks > (mask_threshold - threshold_offset)).flatten(-2).sum(-1, dtype=torch.int32)
+    return hi / lo
+
+
+def batched_mask_to_box(masks):
+    """XYXY boxes (inclusive max index) around boolean masks [..., H, W]; empty -> zeros."""
+    if masks.numel() == 0:
+        return torch.zeros(*masks.shape[:-2], 4, device=masks.device)
+    shape = masks.shape
+    h, w = shape[-2:]
+    m = masks.reshape(-1, h, w).bool()
+    rows, cols = m.any(-1), m.any(-2)
+    ar_h = torch.arange(h, device=m.device)
+    ar_w = torch.arange(w, device=m.device)
+    bottom = (rows * ar_h).amax(-1)
+    top = torch.where(rows, ar_h, h).amin(-1)
+    right = (cols * ar_w).amax(-1)
+    left = torch.where(cols, ar_w, w).amin(-1)
+    out = torch.stack([left, top, right, bottom], -1)
+    out = out * ~((right < left) | (bottom < top)).unsqueeze(-1)
+    return out.reshape(*shape[:-2], 4)
+
+
+def _runs_from_positions(pos, first_set, hw):
+    idx = np.concatenate([[0], pos, [hw]])
+    counts = [0] if first_set else []
+    counts.extend(np.diff(idx).tolist())
+    return counts
+
+
+def mask_to_rle_pytorch(tensor):
+    """Uncompressed column-major RLE per mask (amg.py:107-135).  CUDA input: HIP csam_rle_* kernels
+    with one D2H of the change positions (the reference syncs once per mask)."""
+    b, h, w = tensor.shape
+    if b == 0:
+        return []
+    if tensor.is_cuda:
+        m8 = tensor.to(torch.uint8).contiguous()
+        pos, offs = hip.rle_encode(m8)
+        pos = pos.cpu().numpy().astype(np.int64)
+        first = m8[:, 0, 0].cpu().numpy()
+        return [{"size": [h, w], "counts": _runs_from_positions(pos[offs[i]:offs[i + 1]], bool(first[i]), h * w)}
+                for i in range(b)]
+    arr = tensor.numpy().astype(bool)
+    out = []
+    for i in range(b):
+        flat = arr[i].T.reshape(-1)
+        pos = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+        out.append({"size": [h, w], "counts": _runs_from_positions(pos, bool(flat[0]), h * w)})
+    return out
+
+
+def rle_to_mask(rle):
+    h, w = rle["size"]
+    flat = np.zeros(h * w, dtype=bool)
+    idx, val = 0, False
+    for c in rle["counts"]:
+        if val:
+            flat[idx:idx + c] = True
+        idx += c
+        val = not val
+    return flat.reshape(w, h).T
+
+
+def area_from_rle(rle):
+    return sum(rle["counts"][1::2])
+
+
+def remove_small_regions(mask, area_thresh, mode):
+    """Fill holes / drop islands smaller than area_thresh, 8-connectivity (amg.py:267-291; host
+    connected components: scipy here, cv2 in the reference).  Returns (mask, modified)."""
+    from scipy import ndimage
+    assert mode in ["holes", "islands"]
+    holes = mode == "holes"
+    work = np.logical_xor(holes, mask)
+    labels, n = ndimage.label(work, structure=np.ones((3, 3), dtype=np.uint8))
+    sizes = np.bincount(labels.ravel(), minlength=n + 1)[1:]
+    small = np.flatnonzero(sizes < area_thresh) + 1
+    if small.size == 0:
+        return mask, False
+    if holes:
+        fill = np.concatenate([[0], small])
+    else:
+        fill = np.setdiff1d(np.arange(1, n + 1), small)
+        if fill.size == 0:
+            fill = np.array([int(np.argmax(sizes)) + 1])
+    return np.isin(labels, fill), True
+
+
+def coco_rle_string(counts):
+    """COCO compressed-RLE string of run lengths (pycocotools rleToString: 5 data bits + continuation
+    per char offset by 48, runs after the third delta-coded against counts[i-2])."""
+    chars = []
+    for i, c in enumerate(counts):
+        x = int(c) - (int(counts[i - 2]) if i > 2 else 0)
+        while True:
+            low = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (low & 0x10) else (x != 0)
+            chars.append(chr((low | (0x20 if more else 0)) + 48))
+            if not more:
+                break
+    return "".join(chars)
+
+
+def coco_encode_rle(uncompressed_rle):
+    h, w = uncompressed_rle["size"]
+    return {"size": [h, w], "counts": coco_rle_string(uncompressed_rle["counts"])}
