@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""bench.py -- Crowd-SAM dense-prompt inference throughput on MI355X (contract in the task brief).
+
+One "step" = one synthetic 1024x1024 crowd frame through the whole hot path (SAM ViT-L encoder +
+DINOv2-L + dense sweep of a 64x64 prompt grid = 4096 prompts through the two-way decoder, PWD-Net
+selection, fused mask post-processing, NMS, small-region clean-up, RLE) -> final numpy result.
+Weights are synthetic (seeded, reference key layout): there are no checkpoints on the box.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 2
+
+Images shard across ranks (one process per GPU, weak scaling); no collective on the data path, one
+RCCL all_reduce(MAX) of the elapsed time + the final detection gather (crowdsam_amd.distributed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default="vit_l")
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--points-per-batch", type=int, default=256)
+    ap.add_argument("--mode", default="dense", choices=["dense", "eps"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import hip, synth
+    from oracle.pipeline_oracle import DEFAULT_TEST_CFG      # config defaults only (configs/crowdhuman.yaml values)
+
+    D, depth, heads, gidx = synth.SAM_CONFIGS[args.arch]
+    sam_sd = synth.make_sam_state_dict(args.arch, seed=0)
+    dino_sd = synth.make_dino_state_dict(seed=1)
+    tcfg = dict(DEFAULT_TEST_CFG)
+    n_prompts = args.grid * args.grid
+    tcfg.update(grid_size=args.grid, points_per_batch=args.points_per_batch)
+    if args.mode == "dense":   # data-independent prompt count
+        tcfg.update(pos_sim_thresh=-float("inf"), filter_thresh=float("inf"), max_prompts=n_prompts)
+    config = {"environ": {"device": f"cuda:{local_rank}"},
+              "model": {"sam_model": args.arch, "sam_arch": "crowdsam", "n_class": 1, "trainfree": False},
+              "test": tcfg}
+    model = CrowdSAM(config, sam_state_dict=sam_sd, dino_state_dict=dino_sd)
+
+    def frame(i):
+        return synth.synthetic_crowd_frame(1000 * rank + i, 1024, 150)
+
+    frames = [frame(i) for i in range(args.warmup + args.steps)]
+    np.random.seed(42 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_kept = 0
+    for i in range(args.warmup):
+        model.generate(frames[i])
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = hip.KernelTimer(["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"])
+        hip.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out = model.generate(frames[i])
+        n_kept += len(out["boxes"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hip.set_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = args.steps * world
+        value = images / elapsed
+        res = {
+            "metric": "images/sec (Crowd-SAM dense-prompt inference, 1024^2 image, 64x64 prompt grid, ViT-L)",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": ("full pipeline per image: SAM %s encoder + DINOv2 ViT-L/14 + %s sweep of a %dx%d "
+                                    "prompt grid (%d prompts, %d per decoder batch) + PWD-Net selection + fused mask "
+                                    "post + NMS + small-region clean-up + RLE; synthetic 1024x1024 crowd frames, "
+                                    "seeded random weights" % (args.arch, args.mode, args.grid, args.grid,
+                                                               n_prompts, args.points_per_batch)),
+                       "masks_per_sec": value * n_prompts if args.mode == "dense" else None,
+                       "kept_masks_per_image": n_kept / args.steps, "parallelism": f"image-sharded x{world}"},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            ms = sum(v["ms"] for v in summ.values())
+            work = sum(v["work"] for v in summ.values())
+            calls = sum(v["calls"] for v in summ.values())
+            achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (csam_gemm_f16*)", "achieved": achieved,
+                               "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
+                               "traffic": None, "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
+                               "gemm_ms_per_step": ms / args.steps,
+                               "note": "algorithmic 2*M*N*K of every GEMM launch in the timed region / HIP-event time"}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import cpu_baseline
+            cb = cpu_baseline.measure(sam_sd, dino_sd, (depth, heads, gidx), frames[0], n_prompts_full=n_prompts)
+            res["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            res["config"]["speedup_vs_cpu_port"] = value / cb["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

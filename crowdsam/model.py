@@ -210,11 +210,19 @@ class CrowdSAM:
             boxes_all = torch.cat([c["boxes"] for c in chunks])
             orig_h, orig_w = self.orig_image.shape[:2]
             keep &= ~utils.is_box_near_crop_edge(boxes_all, self._crop_box, [0, 0, orig_w, orig_h], self.downscale)
-        idx = keep.nonzero()[:, 0]
-        if idx.numel() == 0:
+        keep_host = keep.cpu()                       # the one sync of a dense sweep
+        if not bool(keep_host.any()):
             return None
+        idx = keep_host.nonzero()[:, 0].to(self.device)
         cat = lambda k: torch.cat([c[k] for c in chunks])[idx]
-        masks = torch.cat([c["masks_all"] for c in chunks])[idx] if len(chunks) > 1 else chunks[0]["masks_all"][idx]
+        parts, off = [], 0
+        for c in chunks:                             # gather kept masks chunk by chunk (no 4 GB concat)
+            n = c["masks_all"].shape[0]
+            loc = keep_host[off:off + n].nonzero()[:, 0]
+            if loc.numel():
+                parts.append(c["masks_all"][loc.to(self.device)])
+            off += n
+        masks = torch.cat(parts) if len(parts) > 1 else parts[0]
         return MaskData(masks=masks.bool(), iou_preds=cat("score"), points=cat("points"),
                         categories=cat("category").long(), stability_score=cat("stability"),
                         boxes=cat("boxes").long())

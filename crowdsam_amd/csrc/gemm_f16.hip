@@ -35,7 +35,7 @@ struct GemmArgs {
   int res_mod;          // >0: residual row = m % res_mod (per-image constant broadcast over prompts)
   int act;
   int M, N, K;
-  long sA, sW, sC;      // batch strides in elements (grid.z)
+  long sA, sW, sC, sB;  // batch strides in elements (grid.z); sB: bias stride
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   p.A += (long)blockIdx.z * p.sA;
   p.W += (long)blockIdx.z * p.sW;
+  if (p.bias) p.bias += (long)blockIdx.z * p.sB;
   p.C = (p.c_dt == CSAM_DT_F32) ? (void*)((float*)p.C + (long)blockIdx.z * p.sC)
                                 : (void*)((half_t*)p.C + (long)blockIdx.z * p.sC);
   // layout: [stage][A|W][128 rows][128 B]
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 static int gemm_launch(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                        int c_dtype, const float* bias, const float* colscale, const void* residual,
                        long ldr, int r_dtype, int res_mod, int act, int M, int N, int K, int batch, long sA,
-                       long sW, long sC) {
+                       long sW, long sC, long sB = 0) {
   CSAM_REQUIRE(A && W && C, "csam_gemm_f16: null operand");
   CSAM_REQUIRE(M > 0 && N > 0 && K > 0, "csam_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
   CSAM_REQUIRE(N % BN == 0, "csam_gemm_f16: N=%d must be a multiple of %d", N, BN);
@@ -193,7 +194,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   p.R = residual; p.ldr = ldr; p.r_dt = r_dtype;
   p.res_mod = res_mod;
   p.act = act; p.M = M; p.N = N; p.K = K;
-  p.sA = sA; p.sW = sW; p.sC = sC;
+  p.sA = sA; p.sW = sW; p.sC = sC; p.sB = sB;
   CSAM_REQUIRE(batch >= 1 && (batch == 1 || !residual), "csam_gemm_f16: batched call takes no residual");
   dim3 grid(N / BN, csam_cdiv(M, BM), batch);
   static bool attr_set = false;
@@ -229,7 +230,8 @@ extern "C" int csam_gemm_f16_resmod(void* stream, const void* A, long lda, const
 // batch of independent GEMMs (grid.z) with element strides; no residual.
 extern "C" int csam_gemm_f16_batched(void* stream, const void* A, long lda, long strideA, const void* W,
                                      long ldw, long strideW, void* C, long ldc, long strideC, int c_dtype,
-                                     const float* bias, int act, int M, int N, int K, int batch) {
+                                     const float* bias, long strideBias, int act, int M, int N, int K,
+                                     int batch) {
   return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, nullptr, nullptr, 0, 0, 0, act, M, N, K,
-                     batch, strideA, strideW, strideC);
+                     batch, strideA, strideW, strideC, strideBias);
 }

@@ -83,52 +83,66 @@ struct PostArgs {
   int* inter; int* uni; int* box;   // mode 1: [B], [B], [B,4] = xmin,ymin,xmax,ymax (pre-initialised)
 };
 
+constexpr int POST_ROWS = 16;   // output rows per workgroup
+
 template <int MODE>
 __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
+  // grid: (row chunks of POST_ROWS, 1, B); 256 threads x 4 pixels cover a row of up to 1024 pixels.
   const int b = blockIdx.z;
-  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;   // 4 pixels per thread
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (a.sel ? (long)a.sel[b] * a.plane : 0);
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
-  if (y < a.H && x4 < a.W) {
+  int x0[4], x1[4];
+  float lx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) src_index(a.scale_x, x4 + e, a.sw, x0[e], x1[e], lx[e]);
+  const int yend = min(a.H, (int)(blockIdx.x + 1) * POST_ROWS);
+  for (int y = blockIdx.x * POST_ROWS; y < yend; ++y) {
+    if (x4 >= a.W) break;
     int y0, y1;
     float ly;
     src_index(a.scale_y, y, a.sh, y0, y1, ly);
     uint32_t packed = 0;
+    float vv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int x = x4 + e;
+      vv[e] = 0.f;
       if (x < a.W) {
-        int x0, x1;
-        float lx;
-        src_index(a.scale_x, x, a.sw, x0, x1, lx);
-        const float v = bilerp(p, a.sw, y0, y1, ly, x0, x1, lx);
-        if (MODE == 0) {
-          a.out_f32[((long)b * a.H + y) * a.W + x] = v;
-        } else {
+        const float v = bilerp(p, a.sw, y0, y1, ly, x0[e], x1[e], lx[e]);
+        vv[e] = v;
+        if (MODE == 1) {
           cnt_i += v > (a.thr + a.off);
           cnt_u += v > (a.thr - a.off);
           if (v > a.thr) {
             packed |= 1u << (8 * e);
             xmin = min(xmin, x);
             xmax = max(xmax, x);
-            ymin = y;
-            ymax = y;
+            ymin = min(ymin, y);
+            ymax = max(ymax, y);
           }
         }
       }
     }
-    if (MODE == 1) {
-      uint8_t* o = a.out_mask + ((long)b * a.H + y) * a.W + x4;
-      if (x4 + 3 < a.W && (((long)b * a.H + y) * a.W + x4) % 4 == 0) {
-        *(uint32_t*)o = packed;
+    const long o = ((long)b * a.H + y) * a.W + x4;
+    if (MODE == 0) {
+      if (x4 + 3 < a.W && (o & 3) == 0) {
+        *(floatx4*)(a.out_f32 + o) = floatx4{vv[0], vv[1], vv[2], vv[3]};
       } else {
-        for (int e = 0; e < 4 && x4 + e < a.W; ++e) o[e] = (packed >> (8 * e)) & 1;
+        for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_f32[o + e] = vv[e];
+      }
+    } else {
+      if (x4 + 3 < a.W && (o & 3) == 0) {
+        *(uint32_t*)(a.out_mask + o) = packed;
+      } else {
+        for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_mask[o + e] = (packed >> (8 * e)) & 1;
       }
     }
   }
   if (MODE == 1) {
-    // wave reduction, one atomic set per wave (integer atomics: order-independent)
+    // block reduction -> ONE set of integer atomics per workgroup (order-independent, deterministic)
+    __shared__ int red[4][6];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       cnt_i += __shfl_xor(cnt_i, o, 64);
@@ -138,7 +152,17 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
       ymin = min(ymin, __shfl_xor(ymin, o, 64));
       ymax = max(ymax, __shfl_xor(ymax, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((tid & 63) == 0) {
+      int* r = red[tid >> 6];
+      r[0] = cnt_i; r[1] = cnt_u; r[2] = xmin; r[3] = ymin; r[4] = xmax; r[5] = ymax;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w) {
+        cnt_i += red[w][0]; cnt_u += red[w][1];
+        xmin = min(xmin, red[w][2]); ymin = min(ymin, red[w][3]);
+        xmax = max(xmax, red[w][4]); ymax = max(ymax, red[w][5]);
+      }
       if (cnt_i) atomicAdd(a.inter + b, cnt_i);
       if (cnt_u) atomicAdd(a.uni + b, cnt_u);
       if (xmax >= 0) {
@@ -218,7 +242,7 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
                               int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
                               int* box, float* tmp_f32) {
   CSAM_REQUIRE(lowres && sel && out_mask_u8 && inter && uni && box && B > 0, "csam_mask_post: bad args");
-  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0,
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
                "csam_mask_post: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
@@ -229,19 +253,19 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
-    dim3 grid(csam_cdiv(out_w, 256), csam_cdiv(out_h, 4), B);
+    dim3 grid(csam_cdiv(out_h, POST_ROWS), 1, B);
     hipLaunchKernelGGL(mask_post_kernel<1>, grid, dim3(256), 0, s, a);
   } else {
     CSAM_REQUIRE(tmp_f32, "csam_mask_post: tmp buffer required when original_size != input_size");
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 0.25f; a.scale_x = 0.25f;
     a.H = in_h; a.W = in_w; a.out_f32 = tmp_f32; a.out_mask = nullptr;
-    dim3 g0(csam_cdiv(in_w, 256), csam_cdiv(in_h, 4), B);
+    dim3 g0(csam_cdiv(in_h, POST_ROWS), 1, B);
     hipLaunchKernelGGL(mask_post_kernel<0>, g0, dim3(256), 0, s, a);
     a.src = tmp_f32; a.src_bstride = (long)in_h * in_w; a.plane = 0; a.sel = nullptr;
     a.sh = in_h; a.sw = in_w; a.scale_y = (float)in_h / (float)out_h; a.scale_x = (float)in_w / (float)out_w;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
-    dim3 g1(csam_cdiv(out_w, 256), csam_cdiv(out_h, 4), B);
+    dim3 g1(csam_cdiv(out_h, POST_ROWS), 1, B);
     hipLaunchKernelGGL(mask_post_kernel<1>, g1, dim3(256), 0, s, a);
   }
   CSAM_LAUNCH_CHECK("csam_mask_post");
@@ -258,7 +282,8 @@ extern "C" int csam_bilinear_f32(void* stream, const float* src, int n, int sh, 
   a.sh = sh; a.sw = sw; a.scale_y = (float)sh / (float)H; a.scale_x = (float)sw / (float)W;
   a.H = H; a.W = W; a.thr = 0.f; a.off = 0.f;
   a.out_f32 = dst; a.out_mask = nullptr; a.inter = nullptr; a.uni = nullptr; a.box = nullptr;
-  dim3 grid(csam_cdiv(W, 256), csam_cdiv(H, 4), n);
+  CSAM_REQUIRE(W <= 1024, "csam_bilinear_f32: W=%d > 1024", W);
+  dim3 grid(csam_cdiv(H, POST_ROWS), 1, n);
   hipLaunchKernelGGL(mask_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_bilinear_f32");
   return CSAM_OK;

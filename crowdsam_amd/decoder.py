@@ -121,9 +121,19 @@ class DecoderPlan:
             return [(f32(sd[f"{prefix}.layers.{i}.weight"]), f32(sd[f"{prefix}.layers.{i}.bias"])) for i in range(n)]
 
         self.hyper = [mlp(f"{M}output_hypernetworks_mlps.{i}", 3) for i in range(4)]   # index 4 unused (trap 5)
+        # hidden layers of the small heads run on the MFMA GEMM (fp16 operands, fp32 accumulate), batched
+        # over the 4 hyper-networks; the last (N = 32 / 4 / 1 / n_class) layers stay fp32 VALU.
+        self.hyper_w0 = f16(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.0.weight"] for i in range(4)]))
+        self.hyper_b0 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.0.bias"] for i in range(4)]))
+        self.hyper_w1 = f16(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.1.weight"] for i in range(4)]))
+        self.hyper_b1 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.1.bias"] for i in range(4)]))
+        h16 = lambda pre, i: f16(sd[f"{pre}.layers.{i}.weight"])
         self.iou_head = mlp(M + "iou_prediction_head", 3)
         self.par_iou_head = mlp(M + "parallel_iou_head", 3)
         self.classifier = mlp(M + "point_classifier", 2)
+        self.iou_w16 = [h16(M + "iou_prediction_head", 0), h16(M + "iou_prediction_head", 1)]
+        self.par_w16 = [h16(M + "parallel_iou_head", 0), h16(M + "parallel_iou_head", 1)]
+        self.cls_w16 = h16(M + "point_classifier", 0)
         self.dino_proj_w = f16(sd[M + "dino_proj.weight"])
         self.dino_proj_b = f32(sd[M + "dino_proj.bias"])
         self.taps = _adjoint_taps().to(device)
@@ -143,7 +153,9 @@ class DecoderPlan:
             keysA=e(BT, 256), keysB=e(BT, 256), kv=e(BT, 256), qi=e(BT, 128), att=e(BT, 128),
             up2=e(BT * 4, 128), masks=e(B, 4, 256, 256, dt=f),
             hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
-            iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512, dt=f), cls=e(B * 4, self.n_class, dt=f),
+            iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512), cls=e(B * 4, self.n_class, dt=f),
+            hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f),
+            pooled16=e(B * 4, 256),
             stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
             t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev))
@@ -177,7 +189,9 @@ class DecoderPlan:
         """predictor.py:113-121 up to the classifier: [5329, n_class] fp32 logits on the 73x73 grid."""
         G = self.state["G"]
         (w1, b1), (w2, b2) = self.classifier
-        h = hip.linear_f32(G, w1, b1, act=hip.ACT_RELU)
+        g16 = torch.empty(N_DINO, 256, dtype=torch.float16, device=self.device)
+        hip.add_cast(G, out16=g16)
+        h = hip.gemm_f16(g16, self.cls_w16, bias=b1, act=hip.ACT_RELU, out_dtype=torch.float32)
         return hip.linear_f32(h, w2, b2)
 
     # ------------------------------------------------------------------------------------------
@@ -255,25 +269,31 @@ class DecoderPlan:
         hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
         hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
         hs = queries.view(B, 7, 256)
+        hs16 = ws["hs16"][:M7]
+        hip.add_cast(queries, out16=hs16)
+        tok16 = hs16.view(B, 7, 256)
+        # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
+        hh1, hh2 = ws["hh1"], ws["hh2"]
+        hip.gemm_f16_batched(tok16[:, 1], 7 * 256, 256, self.hyper_w0, 256, 256 * 256, hh1, 256, hh1.stride(0),
+                             B, 256, 256, 4, bias=self.hyper_b0, sbias=256, act=hip.ACT_RELU)
+        hip.gemm_f16_batched(hh1, 256, hh1.stride(0), self.hyper_w1, 256, 256 * 256, hh2, 256, hh2.stride(0),
+                             B, 256, 256, 4, bias=self.hyper_b1, sbias=256, act=hip.ACT_RELU)
         for i in range(4):
-            tok = hs[:, 1 + i]                           # strided rows (lda = 7*256)
-            h1 = hip.linear_f32(tok, self.hyper[i][0][0], self.hyper[i][0][1], out=ws["h1"][:B], act=hip.ACT_RELU, M=B, lda=7 * 256)
-            h2 = hip.linear_f32(h1, self.hyper[i][1][0], self.hyper[i][1][1], out=ws["h2"][:B], act=hip.ACT_RELU)
-            hip.linear_f32(h2, self.hyper[i][2][0], self.hyper[i][2][1], out=ws["hyper"][:B, i], M=B)
+            hip.linear_f32(hh2[i], self.hyper[i][2][0], self.hyper[i][2][1], out=ws["hyper"][:B, i], M=B)
         masks = ws["masks"][:B]
         hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
         # ---- IoU head (:184) + parallel residual head (:194-198)
-        iou_tok = hs[:, 0]
-        h1 = hip.linear_f32(iou_tok, self.iou_head[0][0], self.iou_head[0][1], out=ws["h1"][:B], act=hip.ACT_RELU, M=B, lda=7 * 256)
-        h2 = hip.linear_f32(h1, self.iou_head[1][0], self.iou_head[1][1], out=ws["h2"][:B], act=hip.ACT_RELU)
-        iou0 = hip.linear_f32(h2, self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
+        g1, g2 = ws["g1"], ws["g2"]
+        hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)
+        hip.gemm_f16(g1[:B], self.iou_w16[1], out=g2[:B], bias=self.iou_head[1][1], act=hip.ACT_RELU)
+        iou0 = hip.linear_f32(g2[:B], self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
         fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
-        fused[:, :, :256] = iou_tok.unsqueeze(1)         # plumbing: concat [iou_tok | mask_tok_l]
-        fused[:, :, 256:] = hs[:, 1:5]
+        fused[:, :, :256] = tok16[:, 0].unsqueeze(1)     # plumbing: concat [iou_tok | mask_tok_l]
+        fused[:, :, 256:] = tok16[:, 1:5]
         ft = ws["fused_tok"][:B * 4]
-        h1 = hip.linear_f32(ft, self.par_iou_head[0][0], self.par_iou_head[0][1], out=ws["h1"][:B * 4], act=hip.ACT_RELU)
-        h2 = hip.linear_f32(h1, self.par_iou_head[1][0], self.par_iou_head[1][1], out=ws["h2"][:B * 4], act=hip.ACT_RELU)
-        iou = hip.linear_f32(h2, self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
+        hip.gemm_f16(ft, self.par_w16[0], out=g1[:B * 4], bias=self.par_iou_head[0][1], act=hip.ACT_RELU)
+        hip.gemm_f16(g1[:B * 4], self.par_w16[1], out=g2[:B * 4], bias=self.par_iou_head[1][1], act=hip.ACT_RELU)
+        iou = hip.linear_f32(g2[:B * 4], self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
                              residual=iou0.view(B * 4, 1))
         # ---- PWD-Net pooling + classifier (:186-192)
         R = B * 4
@@ -282,6 +302,7 @@ class DecoderPlan:
         hip.gemm_f16(ws["wadj"][:R], st["GT"], out=ws["pooled_raw"][:R])
         hip.rowscale_bias(ws["pooled_raw"], ws["stats"], self.dino_proj_b, ws["pooled"], R, 256)
         (w1, b1), (w2, b2) = self.classifier
-        h1 = hip.linear_f32(ws["pooled"][:R], w1, b1, out=ws["h1"][:R], act=hip.ACT_RELU)
-        cls = hip.linear_f32(h1, w2, b2, out=ws["cls"][:R])
+        hip.add_cast(ws["pooled"][:R], out16=ws["pooled16"][:R])
+        hip.gemm_f16(ws["pooled16"][:R], self.cls_w16, out=g2[:R], bias=b1, act=hip.ACT_RELU)
+        cls = hip.linear_f32(g2[:R], w2, b2, out=ws["cls"][:R])
         return masks, iou.view(B, 4), cls.view(B, 4, self.n_class)

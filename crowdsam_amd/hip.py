@@ -32,7 +32,7 @@ SIGNATURES = {
     "csam_relpos_tables": [_P, _P, _L, _P, _P, _P, _P, _I, _F],
     "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _F],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
-    "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _I, _I, _I, _I, _I],
+    "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
     "csam_point_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
     "csam_pe_points": [_P, _P, _P, _P, _I],
@@ -109,8 +109,51 @@ def _dt(dtype):
     raise ValueError(f"unsupported dtype {dtype}")
 
 
+class KernelTimer:
+    """Optional HIP-event timing of selected entry points on the launch stream (bench.py roofline leg).
+    Events are recorded around each call on torch's current stream (the stream the kernels are launched
+    on) and only read after the caller synchronises."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (name, start_event, end_event, work)
+
+    @staticmethod
+    def gemm_flops(name, args):
+        if name == "csam_gemm_f16_batched":
+            M, N, K, batch = args[-4:]
+            return 2.0 * M * N * K * batch
+        M, N, K = args[-3:]
+        return 2.0 * M * N * K
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, work in self.records:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, work=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
 def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+    if _timer is not None and name in _timer.names:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib(), name)(*args)
+        e1.record()
+        _timer.records.append((name, e0, e1, KernelTimer.gemm_flops(name, args) if "gemm" in name else 0.0))
+    else:
+        rc = getattr(lib(), name)(*args)
     _check(rc, name)
 
 
@@ -221,9 +264,10 @@ def gemm_f16_resmod(a, w, out, bias, residual, res_mod, act=ACT_NONE, M=None):
     return out
 
 
-def gemm_f16_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None, act=ACT_NONE):
+def gemm_f16_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None, sbias=0, act=ACT_NONE):
+    """batch independent GEMMs (grid.z): element strides sa/sw/sc/sbias between problems."""
     call("csam_gemm_f16_batched", _stream(), _ptr(a), lda, sa, _ptr(w), ldw, sw, _ptr(out), ldc, sc, _dt(out.dtype),
-         _ptr(bias), act, M, N, K, batch)
+         _ptr(bias), sbias, act, M, N, K, batch)
     return out
 
 

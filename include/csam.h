@@ -1,0 +1,154 @@
+/* csam.h -- C ABI of libcsam_hip.so: MI355X (gfx950) kernels for Crowd-SAM's dense-prompt path.
+ *
+ * The reference (FelixCaae/CrowdSAM, pure Python/PyTorch) has no FFI: the boundary the hot path
+ * sits behind is the Python API `segment_anything_cs.{sam_model_registry,SamPredictor}` /
+ * `crowdsam.model.CrowdSAM`.  This header is the boundary one level below
+ * it: what the build's own `segment_anything_cs/` + `crowdsam/` modules bind through ctypes
+ * (crowdsam_amd/hip.py), and what a maintainer of the reference would bind to replace the
+ * `nn.Module.forward` bodies cited at each entry (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller unless noted
+ *     "host"; the library never frees or retains them; no hidden allocations: scratch is passed in
+ *     (see *_workspace_bytes);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous w.r.t. the host and
+ *     performs no device synchronisation;
+ *   - returns 0 on success, <0 on error (CSAM_ERR_*); csam_last_error() returns a thread-local
+ *     message; no C++ exception crosses the ABI;
+ *   - "f16" = IEEE half, "f32" = float.  GEMM-shaped work: fp16 operands, fp32 MFMA accumulate.
+ *   - reference file:line citations are relative to /root/reference.
+ */
+#ifndef CSAM_H
+#define CSAM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSAM_OK 0
+#define CSAM_ERR_ARG (-1)
+#define CSAM_ERR_HIP (-2)
+#define CSAM_ERR_WORKSPACE (-3)
+#define CSAM_ACT_NONE 0
+#define CSAM_ACT_GELU 1 /* exact erf GELU (nn.GELU default) */
+#define CSAM_ACT_RELU 2
+#define CSAM_DT_F16 0
+#define CSAM_DT_F32 1
+
+int csam_abi_version(void);
+const char* csam_last_error(void);
+
+/* ---- GEMM with fused epilogue: C[M,N] = act(A[M,K] W[N,K]^T + bias[N]) * colscale[N] + R[m,N].
+ * Replaces every nn.Linear / 1x1 conv / im2col'd conv / ConvTranspose2d(k2,s2) on the path:
+ * image_encoder.py:227,238 (qkv, proj), common.py:25-26 (MLP), image_encoder.py:88-104 (neck),
+ * transformer.py:228-254 (decoder projections), mask_decoder.py:56-62 (upscaler), :187 (dino_proj).
+ * W is the PyTorch Linear layout.  N % 128 == 0, K % 64 == 0, any M. */
+int csam_gemm_f16(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc,
+                  int c_dtype, const float* bias, const float* colscale, const void* residual, long ldr,
+                  int r_dtype, int act, int M, int N, int K);
+/* residual row = m % res_mod: adds a per-image [res_mod,N] constant to every prompt's slab of a
+ * prompt-stacked GEMM ((keys + key_pe) W = keys W + key_pe W, transformer.py:173-175,186-188). */
+int csam_gemm_f16_resmod(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc,
+                         int c_dtype, const float* bias, const void* residual, long ldr, int r_dtype, int res_mod,
+                         int act, int M, int N, int K);
+/* `batch` independent GEMMs (grid.z) with element strides (4 hyper-MLPs, mask_decoder.py:175-179). */
+int csam_gemm_f16_batched(void* stream, const void* A_f16, long lda, long strideA, const void* W_f16, long ldw,
+                          long strideW, void* C, long ldc, long strideC, int c_dtype, const float* bias,
+                          long strideBias, int act, int M, int N, int K, int batch);
+/* fp32 VALU linear for the decision-driving last layers of the small heads
+ * (mask_decoder.py:175-198 hyper / IoU / parallel IoU / classifier, predictor.py:113-121). */
+int csam_linear_f32(void* stream, const float* A, long lda, const float* W, long ldw, const float* bias,
+                    const float* residual, long ldr, float* C, long ldc, int M, int N, int K, int act);
+
+/* ---- encoder-side streaming kernels */
+/* nn.LayerNorm / LayerNorm2d on token-major rows (image_encoder.py:168,180; common.py:38-43;
+ * transformer.py norm1-4). One wave per row, D % 4 == 0, D <= 1280. */
+int csam_layernorm(void* stream, const void* x, long ldx, int x_dtype, void* y, long ldy, int y_dtype,
+                   const float* gamma, const float* beta, int M, int D, float eps);
+/* Sam.preprocess (sam.py:163-173) + PatchEmbed im2col (image_encoder.py:387-395): raw f32 CHW image
+ * (h,w <= 1024) -> A f16 [4096,768]. mean3/std3 are HOST pointers to 3 floats. */
+int csam_sam_im2col(void* stream, const float* img_chw, int h, int w, const float* mean3, const float* std3,
+                    void* out_f16);
+/* preprocess + bilinear 1024->1022 (predictor.py:104) + DINOv2 14x14 patch im2col -> f16 [5329,640];
+ * frame = 1024 (raw SAM frame) or 1022 (already resized + normalised tensor). */
+int csam_dino_im2col(void* stream, const float* img_chw, int h, int w, int frame, const float* mean3,
+                     const float* std3, void* out_f16);
+int csam_im2col3x3(void* stream, const void* in_f16, void* out_f16, int C); /* neck 3x3 conv, image_encoder.py:96-102 */
+int csam_add_cast(void* stream, const float* a, const float* b, long b_row_stride, void* y_f16, float* y_f32,
+                  long M, int N);
+int csam_preprocess_pad(void* stream, const float* img_chw, int h, int w, const float* mean3, const float* std3,
+                        float* out_3x1024x1024); /* Sam.preprocess materialised (API path) */
+int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out); /* crowdsam/model.py:203 */
+
+/* ---- attention */
+/* 14x14 windowed attention + decomposed rel-pos; window partition/unpartition folded into the
+ * addressing; pad tokens are REAL keys whose q/k/v equal the qkv bias (image_encoder.py:224-289,
+ * 325-361; SURVEY.md trap 4). qkv f16 [4096,3D] laid out [3][nH][64]; out f16 [4096,D]. */
+int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const float* rel_pos_h,
+                  const float* rel_pos_w, void* out_f16, int D, int nH, float scale);
+/* Th/Tw tables of the 4 global blocks: T[h][q][k] = (q . rel_pos[q-k+63]) / scale (image_encoder.py:349-350) */
+int csam_relpos_tables(void* stream, const void* qkv_f16, long ld, const float* rel_pos_h, const float* rel_pos_w,
+                       float* th, float* tw, int nH, float scale);
+/* flash-style global attention, head_dim 64: SAM global blocks (th/tw != NULL, T == 4096) and every
+ * DINOv2 block (th == tw == NULL, ragged T). */
+int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off, const float* th,
+                    const float* tw, void* out_f16, long ldo, int T, int nH, float scale);
+
+/* ---- prompt encoder + two-way decoder (all prompts of a batch at once) */
+/* prompt_encoder.py:75-93,189-218 + mask_decoder.py:153-155: tokens f32 [B,7,256] =
+ * [iou; mask0..3; PE(point)+point_embed[1]; not_a_point]; coords f32 [B,2] in the 1024 frame. */
+int csam_point_tokens(void* stream, const float* coords, const float* gauss_2x128, const float* out_tokens5,
+                      const float* point_embed1, const float* not_a_point, float* tokens, int B);
+int csam_pe_points(void* stream, const float* coords, const float* gauss_2x128, float* out, int P); /* dense PE */
+int csam_token_self_attn(void* stream, const void* qk_f16, const void* v_f16, void* out_f16, int B); /* transformer.py:164-169 */
+long csam_attn_t2i_workspace_bytes(int B, int nsplit);
+/* token->image attention (transformer.py:173-177,105-112): 7 queries x T keys x 8 heads x 16 */
+int csam_attn_t2i(void* stream, const void* q_f16, const void* K_f16, const void* V_f16, long ldkv,
+                  long kv_prompt_stride, void* out_f16, int B, int T, int nsplit, void* workspace,
+                  long workspace_bytes);
+/* image->token attention (transformer.py:186-190): T image queries x 7 token keys */
+int csam_attn_i2t(void* stream, const void* Qi_f16, long ldq, long q_prompt_stride, const void* k_f16,
+                  const void* v_f16, void* out_f16, int B, int T, int nsplit);
+int csam_ln64_gelu(void* stream, void* x_f16, const float* gamma, const float* beta, long rows, float eps); /* mask_decoder.py:58-59 */
+int csam_hyper_masks(void* stream, const void* up2_f16, const float* hyper, float* masks, int B); /* mask_decoder.py:181 */
+/* PWD-Net pooling (mask_decoder.py:186-190), re-associated through the adjoint of the 73->256 bilinear */
+int csam_softmax_stats(void* stream, const float* masks, float* stats, int rows);
+int csam_adj_taps_bytes(void);
+int csam_pool_adjoint(void* stream, const float* masks, const float* stats, const void* taps_dev, void* w_f16,
+                      long ldw, int rows);
+int csam_rowscale_bias(void* stream, const float* P, const float* stats, const float* bias, float* out, int rows,
+                       int N);
+
+/* ---- PWD-Net selection, fused mask post-processing, EPS occupancy */
+/* crowdsam/model.py:351,325,354: s = clamp(iou,0)*sigmoid(cls[...,0]); sel = first argmax over 4 */
+int csam_select_masks(void* stream, const float* iou, const float* cls, int n_class, int* sel, float* score,
+                      int* category, float* fused_or_null, int B);
+/* sam.py:153-161 + amg.py:156-176,303-346 on the SELECTED candidate only: bilinear x4 (+ second resize
+ * when original != input size), >thr mask bytes, stability counts, bbox extents. */
+int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w, int out_h,
+                   int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni, int* box,
+                   float* tmp_f32);
+int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W);
+/* crowdsam/model.py:371-389,246: keep / occupancy flags, stability = inter/union, empty box -> 0 */
+int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
+                       float pred_iou_thresh, float stability_thresh, float filter_thresh, float* stability,
+                       void* keep_u8, void* occ_u8, int B);
+/* crowdsam/model.py:238: occupancy bits of the remaining points (never the mask itself goes D2H) */
+int csam_occupancy_lookup(void* stream, const int* points_xy, int P, const void* masks_u8, const void* occ_u8,
+                          int B, int H, int W, void* out_u8);
+
+/* ---- NMS + RLE */
+long csam_box_nms_workspace_bytes(int N);
+/* torchvision.ops.batched_nms semantics (crowdsam/model.py:171,257,429): stable descending scores,
+ * suppress IoU > thr; kept indices (int64) in descending-score order; N <= 16384. */
+int csam_box_nms(void* stream, const float* boxes, const float* scores, int N, float thr, long* out_keep,
+                 int* out_count, void* workspace, long workspace_bytes);
+/* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes */
+int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals);
+int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
+                   const long* mask_offsets, uint32_t* out_positions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSAM_H */
