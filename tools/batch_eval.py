@@ -35,7 +35,7 @@ def convert_to_coco(rows, names):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("-c", "--config_file", default="./configs/crowdhuman.yaml")
+    ap.add_argument("-c", "--config_file", default="./configs/crowdhuman_mi355x.yaml")
     ap.add_argument("-n", "--num_nodes", type=int, default=1, help="number of GPUs (processes)")
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("-o", "--output", default="test.json")

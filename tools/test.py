@@ -23,7 +23,7 @@ from crowdsam.utils import (data_meta, load_config, load_coco_index, load_img_an
 
 def environ_init(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("-c", "--config_file", default="./configs/crowdhuman.yaml")
+    ap.add_argument("-c", "--config_file", default="./configs/crowdhuman_mi355x.yaml")
     ap.add_argument("--start_idx", type=int, default=0)
     ap.add_argument("--end_idx", type=int, default=-1)
     ap.add_argument("-r", "--local_rank", type=int, default=0)
