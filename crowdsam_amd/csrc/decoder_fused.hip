@@ -1,0 +1,286 @@
+// Fused decoder kernels (prompt-batch fused, one pass over the per-prompt key state each).
+//
+// csam_i2t_fused: the whole image->token half of a TwoWayAttentionBlock (transformer.py:186-190)
+//     keys_out = LayerNorm4( keys + out_proj( softmax( q(keys+pe) . k(tokens)^T / 4 ) v(tokens) ) )
+// for every prompt of the batch in ONE kernel: per 128-token tile
+//     [Q = X Wq^T (+ pe Wq^T + bq)]  MFMA, K = 256          (QMODE 1; QMODE 0 loads the hoisted layer-0 Q)
+//     -> 7-key attention per (token, head) entirely in the accumulator registers
+//     -> out-proj MFMA, K = 128, the fp16 O registers are fed straight back as the B operand
+//     -> + bias + residual -> LayerNorm over 256 channels (in-lane + 2 shuffles) -> fp16 store.
+// HBM traffic per prompt: read keys (2 MB) + write keys (2 MB) -- SURVEY.md section 8(d)'s R2+W2 --
+// instead of the unfused Q-GEMM / attention / out-proj GEMM / LayerNorm chain (14 MB).
+//
+// Wave layout: 4 waves x 32 tokens, every wave owns ALL output channels of its tokens, so the
+// per-head attention (head == one 16-wide N tile) and the 256-wide LayerNorm never cross waves.
+// MFMA "swapped" orientation as in gemm_f16.hip: lane (fr = lane&15, fg = lane>>4) holds 4
+// consecutive channels fg*4..+3 of N-tile ni for token fr of M-tile mi.  The O->out-proj register
+// feed needs the out-proj weight columns permuted on the host:
+//     k' = s*32 + g*8 + e   <->   k = (2s + (e>=4))*16 + g*4 + (e&3).
+#include "csam_common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+constexpr int I2T_TOK = 128;                 // tokens per workgroup
+constexpr int I2T_STAGE = 64 * 1024;         // operand staging region (bytes)
+constexpr int I2T_KV = 2 * 8 * 64 * 8;       // per-head MFMA A-fragment tables of the prompt's k and v^T
+constexpr int I2T_SMEM = I2T_STAGE + I2T_KV;
+
+struct I2tArgs {
+  const half_t* X; long x_bstride;           // keys in  [.,256] (per-prompt stride; 0 = shared src)
+  const half_t* Q; long q_bstride;           // QMODE 0: hoisted Q [4096,128] (bias included)
+  const half_t* Wq;                          // QMODE 1: [128,256]
+  const float* qpe;                          // QMODE 1: pe Wq^T + bq  fp32 [4096,128]
+  const half_t* kv_k; const half_t* kv_v;    // [B,7,128] token-side k / v projections
+  const half_t* Wo;                          // [256,128], columns permuted (see header)
+  const float* bo;                           // [256]
+  const float* gamma; const float* beta; float eps;
+  half_t* out;                               // keys out [B*4096, 256]
+  int T;                                     // 4096
+};
+
+template <int QMODE>
+__global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half4_t* kfr = (half4_t*)(smem + I2T_STAGE);   // [8 heads][64 lanes]: K_h   rows j,   k = dims fg*4..+3
+  half4_t* vfr = kfr + 8 * 64;                   // [8 heads][64 lanes]: V_h^T rows d,   k = keys fg*4..+3
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * I2T_TOK;
+  const half_t* Xb = p.X + (long)b * p.x_bstride + (long)t0 * 256;
+
+  // prompt's token-side k, v -> ready-made 16x16x16 MFMA A fragments (zero rows beyond the 7 keys)
+  for (int i = tid; i < 8 * 64; i += 256) {
+    const int h = i >> 6, l = i & 63, r16 = l & 15, g4 = (l >> 4) * 4;
+    half4_t ka = {0, 0, 0, 0}, va = {0, 0, 0, 0};
+    if (r16 < 7) ka = *(const half4_t*)(p.kv_k + ((long)b * 7 + r16) * 128 + h * 16 + g4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (g4 + r < 7) va[r] = p.kv_v[((long)b * 7 + g4 + r) * 128 + h * 16 + r16];
+    kfr[i] = ka;
+    vfr[i] = va;
+  }
+
+  floatx4 q[2][8];
+  if (QMODE == 1) {
+    // ---- phase 1: Q^T = Wq X^T  (tile 128 tokens x 128 n, K = 256), glds double-buffered
+    const int srow = lane >> 3, sslot = lane & 7;
+    const half_t* x_src[4];
+    const half_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + srow;
+      const int chunk = sslot ^ (row & 7);
+      x_src[i] = Xb + (long)row * 256 + chunk * 8;
+      w_src[i] = p.Wq + (long)row * 256 + chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+      char* xb = smem + buf * 32768;
+      char* wb = xb + 16384;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int grp = (wave * 4 + i) * 1024;
+        glds16(x_src[i] + k0, xb + grp);
+        glds16(w_src[i] + k0, wb + grp);
+      }
+    };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) q[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int sw = fr & 7;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < 4) stage(cur ^ 1, (kt + 1) * 64);
+      const char* xb = smem + cur * 32768;
+      const char* wb = xb + 16384;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + fg) ^ sw) << 4;
+        half8_t xf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const half8_t*)(xb + (wave * 32 + mi * 16 + fr) * 128 + coff);
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          const half8_t wf = *(const half8_t*)(wb + (ni * 16 + fr) * 128 + coff);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            q[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mi], q[mi][ni], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // + (pe Wq^T + bq)[token]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float* pq = p.qpe + (long)(t0 + wave * 32 + mi * 16 + fr) * 128 + fg * 4;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) q[mi][ni] += *(const floatx4*)(pq + ni * 16);
+    }
+  } else {
+    const half_t* Qb = p.Q + (long)b * p.q_bstride;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const half_t* qr = Qb + (long)(t0 + wave * 32 + mi * 16 + fr) * 128 + fg * 4;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const half4_t h = *(const half4_t*)(qr + ni * 16);
+        q[mi][ni] = floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+    }
+    __syncthreads();   // fragment tables visible
+  }
+
+  // ---- phase 2: softmax(q k^T / 4) v over the 7 token keys, per (token, head = ni), on the matrix
+  // cores: S^T = K_h q^T and O^T = V_h^T P^T as 16x16x16 MFMAs whose B operands are the lane's own
+  // accumulator registers (q -> fp16, P -> fp16); row max / sum need 2 shuffles each.
+  half8_t of[2][4];
+  const float sc = 0.25f * 1.4426950408889634f;
+  const bool v0 = fg * 4 + 0 < 7, v1 = fg * 4 + 1 < 7, v2 = fg * 4 + 2 < 7, v3 = fg * 4 + 3 < 7;
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    const half4_t ka = kfr[ni * 64 + lane];
+    const half4_t va = vfr[ni * 64 + lane];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const floatx4 qq = q[mi][ni];
+      const half4_t qb = {(half_t)qq[0], (half_t)qq[1], (half_t)qq[2], (half_t)qq[3]};
+      floatx4 sacc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka, qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const float s0 = v0 ? sacc[0] * sc : -INFINITY, s1 = v1 ? sacc[1] * sc : -INFINITY;
+      const float s2 = v2 ? sacc[2] * sc : -INFINITY, s3 = v3 ? sacc[3] * sc : -INFINITY;
+      float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float p0 = v0 ? exp2f(s0 - mx) : 0.f, p1 = v1 ? exp2f(s1 - mx) : 0.f;
+      const float p2 = v2 ? exp2f(s2 - mx) : 0.f, p3 = v3 ? exp2f(s3 - mx) : 0.f;
+      float sum = (p0 + p1) + (p2 + p3);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const half4_t pb = {(half_t)p0, (half_t)p1, (half_t)p2, (half_t)p3};
+      const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) of[mi][ni >> 1][(ni & 1) * 4 + e] = (half_t)(o[e] * inv);
+    }
+  }
+
+  // ---- phase 3: out-proj  D^T = Wo' O^T  (K = 128, N = 256): stage all of Wo' (64 KB) in LDS
+  __syncthreads();
+  {
+    // 256 rows x 256 B = 4096 16-B chunks: slot = chunk ^ (row & 15) within the row's 16 slots
+    for (int c = tid; c < 4096; c += 256) {
+      const int row = c >> 4, sl = c & 15;
+      // lane-linear LDS image: thread c writes at c*16; it must hold source chunk (sl ^ (row&15))
+      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  floatx4 acc[2][16];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 16; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int ni = 0; ni < 16; ++ni) {
+      if ((ni & 3) == 0) asm volatile("" ::: "memory");   // bound the number of weight fragments in flight
+      const int row = ni * 16 + fr;
+      const half8_t wf = *(const half8_t*)(smem + row * 256 + (((s * 4 + fg) ^ (row & 15)) << 4));
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, of[mi][s], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: + bias + residual, LayerNorm(256), fp16 store
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    asm volatile("" ::: "memory");
+    const int tok = t0 + wave * 32 + mi * 16 + fr;
+    const half_t* xr = p.X + (long)b * p.x_bstride + (long)tok * 256 + fg * 4;
+    float sum = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 16; ++ni) {
+      if ((ni & 3) == 0) asm volatile("" ::: "memory");
+      const floatx4 bb = *(const floatx4*)(p.bo + ni * 16 + fg * 4);
+      const half4_t r = *(const half4_t*)(xr + ni * 16);
+      floatx4 v = acc[mi][ni] + bb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += (float)r[e];
+        sum += v[e];
+      }
+      acc[mi][ni] = v;
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / 256.f);
+    float var = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 16; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = acc[mi][ni][e] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / 256.f) + p.eps);
+    half_t* orow = p.out + ((long)b * p.T + tok) * 256 + fg * 4;
+#pragma unroll
+    for (int ni = 0; ni < 16; ++ni) {
+      if ((ni & 3) == 0) asm volatile("" ::: "memory");
+      const floatx4 g = *(const floatx4*)(p.gamma + ni * 16 + fg * 4);
+      const floatx4 be = *(const floatx4*)(p.beta + ni * 16 + fg * 4);
+      half4_t h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (half_t)((acc[mi][ni][e] - mean) * rstd * g[e] + be[e]);
+      *(half4_t*)(orow + ni * 16) = h;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16,
+                              long q_prompt_stride, const void* Wq_f16, const float* qpe, const void* k_f16,
+                              const void* v_f16, const void* Wo_perm_f16, const float* bo, const float* gamma,
+                              const float* beta, float eps, void* out_f16, int B, int T) {
+  CSAM_REQUIRE(X_f16 && k_f16 && v_f16 && Wo_perm_f16 && bo && gamma && beta && out_f16, "csam_i2t_fused: null pointer");
+  CSAM_REQUIRE((Q_f16 != nullptr) != (Wq_f16 != nullptr), "csam_i2t_fused: give either Q (hoisted) or Wq");
+  CSAM_REQUIRE(!Wq_f16 || qpe, "csam_i2t_fused: qpe required with Wq");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % I2T_TOK == 0, "csam_i2t_fused: T must be a multiple of %d", I2T_TOK);
+  I2tArgs a;
+  a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride;
+  a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
+  a.Wq = (const half_t*)Wq_f16; a.qpe = qpe;
+  a.kv_k = (const half_t*)k_f16; a.kv_v = (const half_t*)v_f16;
+  a.Wo = (const half_t*)Wo_perm_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.out = (half_t*)out_f16; a.T = T;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)i2t_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
+    hipFuncSetAttribute((const void*)i2t_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
+    attr_set = true;
+  }
+  dim3 grid(T / I2T_TOK, B);
+  if (Wq_f16)
+    hipLaunchKernelGGL(i2t_fused_kernel<1>, grid, dim3(256), I2T_SMEM, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(i2t_fused_kernel<0>, grid, dim3(256), I2T_SMEM, (hipStream_t)stream, a);
+  CSAM_LAUNCH_CHECK("csam_i2t_fused");
+  return CSAM_OK;
+}

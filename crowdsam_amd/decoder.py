@@ -52,9 +52,21 @@ def _adjoint_taps(n_in=73, n_out=256):
     return torch.from_numpy(buf.copy())
 
 
+def _kperm(K):
+    """Column permutation that lets fp16 accumulator registers of one MFMA feed the next MFMA's B operand
+    directly: k' = s*32 + g*8 + e  <->  k = (2s + (e>=4))*16 + g*4 + (e&3)   (decoder_fused.hip)."""
+    idx = []
+    for s in range(K // 32):
+        for g in range(4):
+            for e in range(8):
+                idx.append((2 * s + (1 if e >= 4 else 0)) * 16 + g * 4 + (e & 3))
+    return torch.tensor(idx, dtype=torch.long)
+
+
 class DecoderPlan:
-    def __init__(self, sd, device, n_class=1, max_batch=256):
+    def __init__(self, sd, device, n_class=1, max_batch=256, fused=True):
         self.device, self.n_class, self.maxB = device, n_class, max_batch
+        self.fused = fused     # False: round-1 unfused kernel chain (kept as an A/B and debugging reference)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -100,6 +112,8 @@ class DecoderPlan:
             pk = pe_proj(t2i["k_w"])
             d["t2i_kv_pe"] = torch.cat([pk, torch.zeros_like(pk)], 1).contiguous()
             d["i2t_q_pe"] = pe_proj(i2t["q_w"])
+            d["i2t_q_peb"] = (d["i2t_q_pe"] + d["i2t_q_b"]).contiguous()
+            d["i2t_o_w_perm"] = f16(i2t["o_w"][:, _kperm(128)])
             self.layers.append(d)
         fa = attn(T + "final_attn_token_to_image.")
         pk = pe_proj(fa["k_w"])
@@ -249,14 +263,23 @@ class DecoderPlan:
             cast_queries()
             hip.gemm_f16(qpe16, L["i2t_k_w"], out=ws["i2t_k"][:M7], bias=L["i2t_k_b"])
             hip.gemm_f16(q16, L["i2t_v_w"], out=ws["i2t_v"][:M7], bias=L["i2t_v_b"])
-            if li == 0:
-                hip.attn_i2t(st["qi0"], 128, 0, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
-                hip.gemm_f16_resmod(ws["att"][:BT], L["i2t_o_w"], keys_out[:BT], L["i2t_o_b"], st["src16"], T_IMG, M=BT)
+            if self.fused:
+                if li == 0:
+                    hip.i2t_fused(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w_perm"], L["i2t_o_b"],
+                                  L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
+                else:
+                    hip.i2t_fused(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w_perm"], L["i2t_o_b"],
+                                  L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],
+                                  qpe=L["i2t_q_peb"])
             else:
-                hip.gemm_f16_resmod(keys_in, L["i2t_q_w"], ws["qi"][:BT], L["i2t_q_b"], L["i2t_q_pe"], T_IMG, M=BT)
-                hip.attn_i2t(ws["qi"], 128, T_IMG * 128, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
-                hip.gemm_f16(ws["att"][:BT], L["i2t_o_w"], out=keys_out[:BT], bias=L["i2t_o_b"], residual=keys_in[:BT])
-            hip.layernorm(keys_out[:BT], L["norm4_g"], L["norm4_b"], 1e-5, out=keys_out[:BT])
+                if li == 0:
+                    hip.attn_i2t(st["qi0"], 128, 0, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
+                    hip.gemm_f16_resmod(ws["att"][:BT], L["i2t_o_w"], keys_out[:BT], L["i2t_o_b"], st["src16"], T_IMG, M=BT)
+                else:
+                    hip.gemm_f16_resmod(keys_in, L["i2t_q_w"], ws["qi"][:BT], L["i2t_q_b"], L["i2t_q_pe"], T_IMG, M=BT)
+                    hip.attn_i2t(ws["qi"], 128, T_IMG * 128, ws["i2t_k"], ws["i2t_v"], ws["att"], B, T_IMG, nsplit_i2t)
+                    hip.gemm_f16(ws["att"][:BT], L["i2t_o_w"], out=keys_out[:BT], bias=L["i2t_o_b"], residual=keys_in[:BT])
+                hip.layernorm(keys_out[:BT], L["norm4_g"], L["norm4_b"], 1e-5, out=keys_out[:BT])
             keys_in, keys_out = keys_out, ws["keysB"]
         # ---- final token -> image attention (transformer.py:105-112)
         F = self.final

@@ -52,6 +52,7 @@ SIGNATURES = {
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
+    "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
 }
@@ -406,4 +407,11 @@ def sigmoid_max(x):
     C, N = x.shape
     out = torch.empty(N, dtype=torch.float32, device=x.device)
     call("csam_sigmoid_max", _stream(), _ptr(x), C, N, _ptr(out))
+    return out
+
+
+def i2t_fused(X, x_bstride, k, v, Wo_perm, bo, gamma, beta, eps, out, B, T, Q=None, q_bstride=0, Wq=None, qpe=None):
+    """Fused image->token half-block: [Q-proj] -> 7-key attention -> out-proj -> +residual -> LayerNorm."""
+    call("csam_i2t_fused", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq), _ptr(qpe), _ptr(k), _ptr(v),
+         _ptr(Wo_perm), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T)
     return out
