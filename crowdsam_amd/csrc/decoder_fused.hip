@@ -284,3 +284,230 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
   CSAM_LAUNCH_CHECK("csam_i2t_fused");
   return CSAM_OK;
 }
+
+// =====================================================================================================
+// csam_upscale_fused: mask_decoder.py:172-181 in ONE kernel, one pass over the final key state:
+//   up1 = ConvT(256->64,k2,s2)(keys)  ->  LayerNorm2d(64) -> GELU  ->  ConvT(64->32,k2,s2) -> GELU
+//   masks[b,l,Y,X] = sum_c hyper[b,l,c] * up2[b,c,Y,X]
+// Both transposed convolutions are per-token GEMMs (k=2,s=2: no overlap), so a token's 4x4 output
+// pixels depend on that token only.  Workgroup = 128 consecutive tokens (2 rows of the 64x64 grid) of
+// one prompt, 8 waves: wave = (row half r, first-conv position (di,dj)).
+//   GEMM1 (K=256, glds double-buffered, swizzled)  -> the wave's 64 channels x 64 tokens in registers
+//   -> LN over the 64 channels (in-lane + 2 shuffles) + GELU -> fp16 registers ARE GEMM2's B operand
+//   GEMM2 (K=64, N=128 = 4 sub-positions x 32 ch, weights permuted on the host) -> GELU
+//   -> hyper product as a 16x16x32 MFMA (hyper rows hi+lo fp16, rows 4..15 zero), again fed from
+//      the accumulator registers -> 4 mask logits per (token, position, sub-position)
+//   -> staged in LDS as full 256-pixel output rows -> coalesced fp32 stores.
+// HBM per prompt: read 2 MB keys + write 1 MB logits (unfused chain: 19 MB).
+// =====================================================================================================
+namespace {
+
+constexpr int UP_XS = 0, UP_WS = 32 * 1024, UP_W2S = 96 * 1024, UP_HFR = 112 * 1024;
+constexpr int UP_SMEM = 112 * 1024 + 2 * 64 * 16;
+
+struct UpArgs {
+  const half_t* X;          // keys [B*4096, 256]
+  const half_t* W1;         // [256 = pos*64+co, 256 ci]
+  const float* b1;          // [256]
+  const float* ln_g; const float* ln_b; float eps;   // [64]
+  const half_t* W2;         // [128 = pos2*32+co2, 64 ci2 (k-permuted)]
+  const float* b2;          // [128]
+  const float* hyper;       // [B,4,32]
+  float* masks;             // [B,4,256,256]
+};
+
+__global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * 128;                 // first token of the 2 grid rows
+  const int r = wave >> 2, pos = wave & 3;
+  const half_t* Xb = p.X + ((long)b * 4096 + t0) * 256;
+
+  // ---- one-time staging: W2' (16 KB, swizzled) and the hyper A-fragments (hi/lo)
+  {
+    const int c = tid;                              // 1024 16-B pieces: 2 per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int cc = c + it * 512;
+      const int row = cc >> 3, sl = cc & 7;
+      glds16(p.W2 + (long)row * 64 + ((sl ^ (row & 7)) * 8), smem + UP_W2S + (cc & ~63) * 16);
+    }
+    if (tid < 64) {
+      half8_t hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int i = tid & 15, g = tid >> 4;
+      if (i < 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cch = ((e >= 4) ? 16 : 0) + g * 4 + (e & 3);
+          const float h = p.hyper[((long)b * 4 + i) * 32 + cch];
+          hi[e] = (half_t)h;
+          lo[e] = (half_t)(h - (float)hi[e]);
+        }
+      }
+      *(half8_t*)(smem + UP_HFR + tid * 16) = hi;
+      *(half8_t*)(smem + UP_HFR + 1024 + tid * 16) = lo;
+    }
+  }
+
+  // ---- phase 1: GEMM1, K = 256 in 4 chunks of 64
+  auto stage = [&](int buf, int k0) {
+    // X: 128 rows x 8 slots = 1024 pieces (2/thread); W1: 256 rows x 8 = 2048 pieces (4/thread)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int cc = tid + it * 512;
+      const int row = cc >> 3, sl = cc & 7;
+      glds16(Xb + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + UP_XS + buf * 16384 + (cc & ~63) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int cc = tid + it * 512;
+      const int row = cc >> 3, sl = cc & 7;
+      glds16(p.W1 + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + UP_WS + buf * 32768 + (cc & ~63) * 16);
+    }
+  };
+  floatx4 a1[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) a1[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int sw = fr & 7;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < 4) stage(cur ^ 1, (kt + 1) * 64);
+    const char* xb = smem + UP_XS + cur * 16384;
+    const char* wb = smem + UP_WS + cur * 32768;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + fg) ^ sw) << 4;
+      half8_t xf[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[i] = *(const half8_t*)(xb + (r * 64 + i * 16 + fr) * 128 + coff);
+        wf[i] = *(const half8_t*)(wb + (pos * 64 + i * 16 + fr) * 128 + coff);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          a1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], a1[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- phases 2-4 per 16-token tile mi
+  floatx4 b1v[4], gv[4], bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    b1v[ni] = *(const floatx4*)(p.b1 + pos * 64 + ni * 16 + fg * 4);
+    gv[ni] = *(const floatx4*)(p.ln_g + ni * 16 + fg * 4);
+    bv[ni] = *(const floatx4*)(p.ln_b + ni * 16 + fg * 4);
+  }
+  const half8_t hhi = *(const half8_t*)(smem + UP_HFR + lane * 16);
+  const half8_t hlo = *(const half8_t*)(smem + UP_HFR + 1024 + lane * 16);
+  float* outs = (float*)(smem);                     // [2 r][4 l][4 yy][256 X] fp32 = 32 KB (aliases XS/WS)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    asm volatile("" ::: "memory");
+    // LayerNorm2d over the 64 channels of (token, pos), then GELU
+    float sum = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      a1[mi][ni] += b1v[ni];
+      sum += (a1[mi][ni][0] + a1[mi][ni][1]) + (a1[mi][ni][2] + a1[mi][ni][3]);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / 64.f);
+    float var = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = a1[mi][ni][e] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
+    half8_t xf2[2];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = (a1[mi][ni][e] - mean) * rstd * gv[ni][e] + bv[ni][e];
+        xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)csam_gelu_erf(y);
+      }
+    // GEMM2: [128 n2] x [16 tokens], K = 64 (weights k-permuted): 8 N tiles x 2 k-steps
+    floatx4 a2[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+      a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
+      const int row = n2 * 16 + fr;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const half8_t wf = *(const half8_t*)(smem + UP_W2S + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
+        a2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[s], a2[n2], 0, 0, 0);
+      }
+    }
+    // + bias, GELU, hyper product per sub-position pos2 (N tiles 2*pos2, 2*pos2+1)
+#pragma unroll
+    for (int pos2 = 0; pos2 < 4; ++pos2) {
+      half8_t ub;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const floatx4 bb = *(const floatx4*)(p.b2 + (pos2 * 2 + h2) * 16 + fg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ub[h2 * 4 + e] = (half_t)csam_gelu_erf(a2[pos2 * 2 + h2][e] + bb[e]);
+      }
+      floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
+      if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+        const int yy = (pos >> 1) * 2 + (pos2 >> 1);
+        const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) outs[((r * 4 + l) * 4 + yy) * 256 + X] = m4[l];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- coalesced store of the 2 x 4 x 4 output rows (256 fp32 each)
+  {
+    const int i0 = blockIdx.x * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512;               // float4 index in [0, 2048)
+      const int x4 = idx & 63, rowid = idx >> 6;    // rowid = (r*4 + l)*4 + yy
+      const int yy = rowid & 3, l = (rowid >> 2) & 3, rr = rowid >> 4;
+      const floatx4 v = *(const floatx4*)(outs + rowid * 256 + x4 * 4);
+      float* dst = p.masks + ((((long)b * 4 + l) * 256) + (4 * (i0 + rr) + yy)) * 256 + x4 * 4;
+      *(floatx4*)dst = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
+                                  const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
+                                  const float* b2, const float* hyper, float* masks, int B) {
+  CSAM_REQUIRE(keys_f16 && W1_f16 && b1 && ln_gamma && ln_beta && W2_perm_f16 && b2 && hyper && masks && B > 0,
+               "csam_upscale_fused: bad args");
+  UpArgs a;
+  a.X = (const half_t*)keys_f16; a.W1 = (const half_t*)W1_f16; a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta;
+  a.eps = eps; a.W2 = (const half_t*)W2_perm_f16; a.b2 = b2; a.hyper = hyper; a.masks = masks;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)upscale_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upscale_fused_kernel, dim3(32, B), dim3(512), UP_SMEM, (hipStream_t)stream, a);
+  CSAM_LAUNCH_CHECK("csam_upscale_fused");
+  return CSAM_OK;
+}

@@ -130,6 +130,7 @@ class DecoderPlan:
         w2 = sd[M + "output_upscaling.3.weight"]          # [64, 32, 2, 2]
         self.up2_w = f16(w2.permute(2, 3, 1, 0).reshape(128, 64))
         self.up2_b = f32(sd[M + "output_upscaling.3.bias"].repeat(4))
+        self.up2_w_perm = f16(w2.permute(2, 3, 1, 0).reshape(128, 64)[:, _kperm(64)])
 
         def mlp(prefix, n):
             return [(f32(sd[f"{prefix}.layers.{i}.weight"]), f32(sd[f"{prefix}.layers.{i}.bias"])) for i in range(n)]
@@ -287,10 +288,11 @@ class DecoderPlan:
         hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
         t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])
         # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
-        up1 = ws["kv"]                                   # reuse [BT,256] f16
-        hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
-        hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
-        hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
+        if not self.fused:
+            up1 = ws["kv"]                                   # reuse [BT,256] f16
+            hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
+            hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
+            hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
         hs = queries.view(B, 7, 256)
         hs16 = ws["hs16"][:M7]
         hip.add_cast(queries, out16=hs16)
@@ -304,7 +306,11 @@ class DecoderPlan:
         for i in range(4):
             hip.linear_f32(hh2[i], self.hyper[i][2][0], self.hyper[i][2][1], out=ws["hyper"][:B, i], M=B)
         masks = ws["masks"][:B]
-        hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
+        if self.fused:
+            hip.upscale_fused(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,
+                              self.up2_b, ws["hyper"], masks, B)
+        else:
+            hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
         # ---- IoU head (:184) + parallel residual head (:194-198)
         g1, g2 = ws["g1"], ws["g2"]
         hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)

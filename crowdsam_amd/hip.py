@@ -53,6 +53,7 @@ SIGNATURES = {
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
+    "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
 }
@@ -415,3 +416,10 @@ def i2t_fused(X, x_bstride, k, v, Wo_perm, bo, gamma, beta, eps, out, B, T, Q=No
     call("csam_i2t_fused", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq), _ptr(qpe), _ptr(k), _ptr(v),
          _ptr(Wo_perm), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T)
     return out
+
+
+def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B):
+    """Fused ConvT -> LN2d -> GELU -> ConvT -> GELU -> hyper product: keys f16 [B*4096,256] -> masks f32 [B,4,256,256]."""
+    call("csam_upscale_fused", _stream(), _ptr(keys), _ptr(W1), _ptr(b1), _ptr(ln_g), _ptr(ln_b), float(eps),
+         _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), B)
+    return masks
