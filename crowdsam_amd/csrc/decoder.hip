@@ -510,6 +510,13 @@ extern "C" int csam_attn_t2i(void* stream, const void* q_f16, const void* K_f16,
   return CSAM_OK;
 }
 
+// merge launcher shared with the fused kernel (decoder_fused.hip)
+extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts) {
+  hipLaunchKernelGGL(t2i_merge_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, part, (half_t*)out_f16, nparts);
+  CSAM_LAUNCH_CHECK("csam_t2i_merge");
+  return CSAM_OK;
+}
+
 extern "C" int csam_attn_i2t(void* stream, const void* Qi_f16, long ldq, long q_prompt_stride, const void* k_f16,
                              const void* v_f16, void* out_f16, int B, int T, int nsplit) {
   CSAM_REQUIRE(Qi_f16 && k_f16 && v_f16 && out_f16 && B > 0, "csam_attn_i2t: bad args");

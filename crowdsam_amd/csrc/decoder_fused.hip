@@ -511,3 +511,245 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   CSAM_LAUNCH_CHECK("csam_upscale_fused");
   return CSAM_OK;
 }
+
+// =====================================================================================================
+// csam_t2i_fused: token->image attention (transformer.py:173-177 and :105-112) with the K/V projections
+// of the per-prompt key state fused in -- K and V never touch HBM.  Per workgroup: 256 tokens of one
+// prompt, 8 waves x 32 tokens.
+//   K^T = Wk X^T            swapped MFMA orientation  -> lane (token fr, 4 consecutive dims)
+//   V   = X Wv^T            NON-swapped orientation    -> lane (dim l&15, 4 consecutive tokens)
+// (same LDS fragments, operands passed in the other order), which makes every later product chain
+// through registers with no transpose:
+//   S   = K q^T   16x16x16, A = the K registers, B = per-head q fragment -> lane (query j, 4 tokens)
+//   P   = exp2(S - m_wg)  (m_wg: workgroup-wide max per (query, head) through LDS)
+//   O  += P V     16x16x16, A = the P registers, B = the V registers    -> lane (dim d, queries 4g..)
+// The workgroup writes ONE partial record (m, l, O[16]) per (head, query); csam's merge kernel combines
+// the 16 partials of a prompt.  MODE 0 (layer 0): K / V^T of the shared image embedding are hoisted per
+// image and simply loaded in those two layouts.
+// HBM per prompt: read 2 MB keys (+ 65 KB partials) instead of KV GEMM write/read + attention reads (6 MB).
+// =====================================================================================================
+namespace {
+
+constexpr int T2I_TOK = 256;
+constexpr int T2I_STAGE = 128 * 1024;          // 2 x (X 32 KB + W 32 KB)
+constexpr int T2I_QFR = T2I_STAGE;             // [8 h][64 lanes] half4 = 4 KB
+constexpr int T2I_SMEM = T2I_STAGE + 4096;
+constexpr int T2I_NREC = 18;
+
+struct T2iArgs {
+  const half_t* X;            // MODE 1: keys [B*4096, 256]
+  const half_t* Wkv;          // MODE 1: [256,256]: rows 0..127 Wk, 128..255 Wv
+  const float* kpe;           // MODE 1: pe Wk^T + bk, fp32 [4096,128]
+  const float* bv;            // MODE 1: [128]
+  const half_t* K0;           // MODE 0: hoisted K [4096,128] (bias + pe included)
+  const half_t* V0T;          // MODE 0: hoisted V^T [128, 4096] (bias included)
+  const half_t* q;            // [B,7,128] projected queries
+  float* part;                // [B, 16, 8, 7, 18]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int t0 = tile * T2I_TOK;
+  half4_t* qfr = (half4_t*)(smem + T2I_QFR);
+
+  // per-head q fragments (B operand of S = K q^T): lane (col j = l&15, dims 4g..4g+3); zero for j >= 7
+  {
+    const int h = tid >> 6, l = tid & 63, j = l & 15, g4 = (l >> 4) * 4;
+    half4_t v = {0, 0, 0, 0};
+    if (j < 7) v = *(const half4_t*)(p.q + ((long)b * 7 + j) * 128 + h * 16 + g4);
+    qfr[tid] = v;   // 512 threads == 8 heads x 64 lanes
+  }
+
+  half4_t kf[2][8], vf[2][8];   // fp16 K (A operand of S) and V (B operand of PV) per (mi, head)
+  if (MODE == 1) {
+    const half_t* Xb = p.X + ((long)b * 4096 + t0) * 256;
+    auto stage = [&](int buf, int k0) {
+      // X: 256 rows x 8 slots = 2048 pieces; W: 256 rows x 8 = 2048 pieces -> 4 + 4 per thread
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int cc = tid + it * 512;
+        const int row = cc >> 3, sl = cc & 7;
+        glds16(Xb + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + buf * 65536 + (cc & ~63) * 16);
+        glds16(p.Wkv + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + buf * 65536 + 32768 + (cc & ~63) * 16);
+      }
+    };
+    floatx4 ak[2][8], av[2][8];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        ak[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+        av[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+    const int sw = fr & 7;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < 4) stage(cur ^ 1, (kt + 1) * 64);
+      const char* xb = smem + cur * 65536;
+      const char* wb = xb + 32768;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + fg) ^ sw) << 4;
+        half8_t xf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const half8_t*)(xb + (wave * 32 + mi * 16 + fr) * 128 + coff);
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          const half8_t wk = *(const half8_t*)(wb + (ni * 16 + fr) * 128 + coff);
+          const half8_t wv = *(const half8_t*)(wb + (128 + ni * 16 + fr) * 128 + coff);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            ak[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk, xf[mi], ak[mi][ni], 0, 0, 0);   // [n][t]
+            av[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mi], wv, av[mi][ni], 0, 0, 0);   // [t][n]
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float* pk = p.kpe + (long)(t0 + wave * 32 + mi * 16 + fr) * 128 + fg * 4;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const floatx4 kb = *(const floatx4*)(pk + ni * 16);
+        const float vb = p.bv[ni * 16 + fr];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kf[mi][ni][e] = (half_t)(ak[mi][ni][e] + kb[e]);
+          vf[mi][ni][e] = (half_t)(av[mi][ni][e] + vb);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int tb = t0 + wave * 32 + mi * 16;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        kf[mi][ni] = *(const half4_t*)(p.K0 + (long)(tb + fr) * 128 + ni * 16 + fg * 4);
+        vf[mi][ni] = *(const half4_t*)(p.V0T + (long)(ni * 16 + fr) * 4096 + tb + fg * 4);
+      }
+    }
+    __syncthreads();   // qfr visible
+  }
+
+  // ---- S = K q^T per (mi, head): lane (query j = l&15, tokens 4g+r); workgroup max per (j, head)
+  float* wmax = (float*)smem;                    // [8 waves][8 h][16 j]   (aliases the staging region)
+  float* wred = (float*)(smem + 8192);           // [8 waves][8 h][7 j][17]: l, O[16]
+  const float sc = 0.25f * 1.4426950408889634f;
+  floatx4 s[2][8];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    const half4_t qb = qfr[ni * 64 + lane];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      floatx4 a = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[mi][ni], qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      a *= sc;
+      s[mi][ni] = a;
+      mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (fg == 0) wmax[(wave * 8 + ni) * 16 + fr] = mx;
+  }
+  __syncthreads();
+  floatx4 o[8];
+  float lsum[8], mwg[8];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    float m = wmax[ni * 16 + fr];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[(w * 8 + ni) * 16 + fr]);
+    mwg[ni] = m;
+    o[ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float ls = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      half4_t pb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = exp2f(s[mi][ni][e] - m);
+        ls += pe;
+        pb[e] = (half_t)pe;
+      }
+      o[ni] = __builtin_amdgcn_mfma_f32_16x16x16f16(pb, vf[mi][ni], o[ni], 0, 0, 0);   // [j][d]
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    lsum[ni] = ls;
+  }
+  __syncthreads();   // wmax fully consumed before wred (disjoint, but keep phases clean)
+  // per-wave partials -> LDS: O lane = (d = l&15, queries j = 4g+r); l lane = (j = l&15)
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = fg * 4 + r;
+      if (j < 7) wred[((wave * 8 + ni) * 7 + j) * 17 + 1 + fr] = o[ni][r];
+    }
+    if (fg == 0 && fr < 7) wred[((wave * 8 + ni) * 7 + fr) * 17] = lsum[ni];
+  }
+  // stash the workgroup max per (head, j) for the record writer
+  float* mrec = (float*)(smem + 8192 + 8 * 8 * 7 * 17 * 4);
+  if (wave == 0 && fg == 0 && fr < 7) {
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) mrec[ni * 7 + fr] = mwg[ni];
+  }
+  __syncthreads();
+  // reduce the 8 waves (fixed order: deterministic) and write the record
+  for (int i = tid; i < 8 * 7 * 17; i += 512) {
+    const int e = i % 17, hj = i / 17;            // hj = h*7 + j
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) acc += wred[(w * 56 + hj) * 17 + e];
+    float* rec = p.part + (((long)b * 16 + tile) * 56 + hj) * T2I_NREC;
+    rec[1 + e] = acc;                              // e == 0 -> l, e >= 1 -> O[e-1]
+    if (e == 0) rec[0] = mrec[hj];
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
+
+extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * 16 * 56 * T2I_NREC * sizeof(float); }
+
+extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
+                              const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
+                              void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(q_f16 && out_f16 && workspace && B > 0, "csam_t2i_fused: bad args");
+  CSAM_REQUIRE((X_f16 != nullptr) != (K0_f16 != nullptr), "csam_t2i_fused: give either keys+weights or hoisted K0/V0T");
+  CSAM_REQUIRE(!X_f16 || (Wkv_f16 && kpe && bv), "csam_t2i_fused: Wkv/kpe/bv required with keys");
+  CSAM_REQUIRE(!K0_f16 || V0T_f16, "csam_t2i_fused: V0T required with K0");
+  if (workspace_bytes < csam_t2i_fused_workspace_bytes(B)) {
+    csam_set_error("csam_t2i_fused: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  T2iArgs a;
+  a.X = (const half_t*)X_f16; a.Wkv = (const half_t*)Wkv_f16; a.kpe = kpe; a.bv = bv;
+  a.K0 = (const half_t*)K0_f16; a.V0T = (const half_t*)V0T_f16; a.q = (const half_t*)q_f16;
+  a.part = (float*)workspace;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)t2i_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_SMEM);
+    hipFuncSetAttribute((const void*)t2i_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_SMEM);
+    attr_set = true;
+  }
+  dim3 grid(16, B);
+  if (X_f16)
+    hipLaunchKernelGGL(t2i_fused_kernel<1>, grid, dim3(512), T2I_SMEM, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(t2i_fused_kernel<0>, grid, dim3(512), T2I_SMEM, (hipStream_t)stream, a);
+  CSAM_LAUNCH_CHECK("csam_t2i_fused");
+  return csam_t2i_merge_launch(stream, (const float*)workspace, out_f16, B, 16);
+}

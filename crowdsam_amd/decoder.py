@@ -113,6 +113,9 @@ class DecoderPlan:
             d["t2i_kv_pe"] = torch.cat([pk, torch.zeros_like(pk)], 1).contiguous()
             d["i2t_q_pe"] = pe_proj(i2t["q_w"])
             d["i2t_q_peb"] = (d["i2t_q_pe"] + d["i2t_q_b"]).contiguous()
+            d["t2i_kpe"] = (pk + d["t2i_kv_b"][:128]).contiguous()        # pe Wk^T + bk, fp32 [4096,128]
+            d["t2i_bv"] = d["t2i_kv_b"][128:].contiguous()
+            d["t2i_v_bias_mat"] = d["t2i_bv"].view(128, 1).expand(128, T_IMG).contiguous()
             d["i2t_o_w_perm"] = f16(i2t["o_w"][:, _kperm(128)])
             self.layers.append(d)
         fa = attn(T + "final_attn_token_to_image.")
@@ -120,6 +123,7 @@ class DecoderPlan:
         self.final = dict(q_w=f16(fa["q_w"]), q_b=f32(fa["q_b"]),
                           kv_w=f16(torch.cat([fa["k_w"], fa["v_w"]], 0)), kv_b=f32(torch.cat([fa["k_b"], fa["v_b"]], 0)),
                           kv_pe=torch.cat([pk, torch.zeros_like(pk)], 1).contiguous(),
+                          kpe=(pk + f32(fa["k_b"])).contiguous(), bv=f32(fa["v_b"]),
                           o_w=f16(fa["o_w"]), o_b=f32(fa["o_b"]),
                           norm_g=f32(sd[T + "norm_final_attn.weight"]), norm_b=f32(sd[T + "norm_final_attn.bias"]))
         # upscaler: ConvTranspose2d(k=2,s=2) as GEMMs; weight [ci, co, di, dj] -> rows n = (di*2+dj)*co_n + co
@@ -193,6 +197,9 @@ class DecoderPlan:
         hip.gemm_f16(srcpe16, L0["t2i_kv_w"][:128], out=st["kv0"][:, :128], bias=L0["t2i_kv_b"][:128])
         hip.gemm_f16(src16, L0["t2i_kv_w"][128:], out=st["kv0"][:, 128:], bias=L0["t2i_kv_b"][128:])
         st["qi0"] = hip.gemm_f16(srcpe16, L0["i2t_q_w"], bias=L0["i2t_q_b"])
+        # the same hoisted K / V in the two register layouts of the fused kernel: K [4096,128], V^T [128,4096]
+        st["k0"] = hip.gemm_f16(srcpe16, L0["t2i_kv_w"][:128], bias=L0["t2i_kv_b"][:128])
+        st["v0t"] = hip.gemm_f16(L0["t2i_kv_w"][128:], src16, residual=L0["t2i_v_bias_mat"], M=128)
         # dino_proj, both orientations: G f32 [5329,256] (+bias) for the FG prior and
         # G^T f16 [256, 5376] (no bias; added after pooling) as the K-contiguous pooling operand.
         st["G"] = hip.gemm_f16(dino_tok16, self.dino_proj_w, bias=self.dino_proj_b, out_dtype=torch.float32, M=N_DINO)
@@ -229,9 +236,12 @@ class DecoderPlan:
             hip.add_cast(queries, out16=q16)
             hip.add_cast(queries, tokens0, 256, out16=qpe16)
 
-        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b):
+        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None):
             hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
-            hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
+            if fused_args is not None:
+                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **fused_args)
+            else:
+                hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
             hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
             hip.layernorm(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, out=queries)
 
@@ -251,7 +261,11 @@ class DecoderPlan:
             # ---- token -> image cross attention (:173-177)
             cast_queries()
             if li == 0:
-                t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
+                t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                    dict(K0=st["k0"], V0T=st["v0t"]) if self.fused else None)
+            elif self.fused:
+                t2i(L["t2i_q_w"], L["t2i_q_b"], None, 0, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                    dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]))
             else:
                 hip.gemm_f16_resmod(keys_in, L["t2i_kv_w"], ws["kv"][:BT], L["t2i_kv_b"], L["t2i_kv_pe"], T_IMG, M=BT)
                 t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
@@ -285,8 +299,12 @@ class DecoderPlan:
         # ---- final token -> image attention (transformer.py:105-112)
         F = self.final
         cast_queries()
-        hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
-        t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])
+        if self.fused:
+            t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
+                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"]))
+        else:
+            hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
+            t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])
         # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
         if not self.fused:
             up1 = ws["kv"]                                   # reuse [BT,256] f16

@@ -54,12 +54,15 @@ SIGNATURES = {
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I],
+    "csam_t2i_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L],
+    "csam_t2i_merge_launch": [_P, _P, _P, _I, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
 }
 LONG_RETURNS = {
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
+    "csam_t2i_fused_workspace_bytes": [_I],
 }
 
 _lib = None
@@ -423,3 +426,10 @@ def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B):
     call("csam_upscale_fused", _stream(), _ptr(keys), _ptr(W1), _ptr(b1), _ptr(ln_g), _ptr(ln_b), float(eps),
          _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), B)
     return masks
+
+
+def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None, V0T=None):
+    """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
+    call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
+         B, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out

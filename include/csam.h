@@ -119,6 +119,24 @@ int csam_pool_adjoint(void* stream, const float* masks, const float* stats, cons
 int csam_rowscale_bias(void* stream, const float* P, const float* stats, const float* bias, float* out, int rows,
                        int N);
 
+/* ---- fused decoder kernels: one pass over the per-prompt key state each (SURVEY.md 8d's R1..R4) */
+/* whole image->token half-block (transformer.py:186-190): [Q-proj] -> 7-key attention -> out-proj ->
+ * +residual -> LayerNorm4.  Give either Q (hoisted layer-0 projection) or Wq+qpe. Wo columns k-permuted. */
+int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                   const void* Wq_f16, const float* qpe, const void* k_f16, const void* v_f16,
+                   const void* Wo_perm_f16, const float* bo, const float* gamma, const float* beta, float eps,
+                   void* out_f16, int B, int T);
+/* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
+int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
+                       const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
+                       const float* b2, const float* hyper, float* masks, int B);
+/* token->image attention with the K/V projections fused in (transformer.py:173-177,105-112) */
+long csam_t2i_fused_workspace_bytes(int B);
+int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
+                   const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
+                   void* workspace, long workspace_bytes);
+int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
+
 /* ---- PWD-Net selection, fused mask post-processing, EPS occupancy */
 /* crowdsam/model.py:351,325,354: s = clamp(iou,0)*sigmoid(cls[...,0]); sel = first argmax over 4 */
 int csam_select_masks(void* stream, const float* iou, const float* cls, int n_class, int* sel, float* score,
