@@ -156,6 +156,8 @@ class DecoderPlan:
         self.dino_proj_w = f16(sd[M + "dino_proj.weight"])
         self.dino_proj_b = f32(sd[M + "dino_proj.bias"])
         self.taps = _adjoint_taps().to(device)
+        self.state = None
+        self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------------------------------
@@ -179,49 +181,66 @@ class DecoderPlan:
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
             t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev))
         self.allocB = B
+        self.batch_graphs.clear()
 
     # ------------------------------------------------------------------------------------------
-    def set_image(self, feat_tok, dino_tok16):
-        """feat_tok f32 [4096,256] (encoder output, token-major); dino_tok16 f16 [>=5329 rows,1024]
-        inside a buffer with N_DINO_PAD rows.  Builds the per-image constants."""
+    def _alloc_state(self):
         dev = self.device
+        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=dev)
+        f = torch.float32
+        self.state = dict(src16=e(T_IMG, 256), srcpe16=e(T_IMG, 256), src32=e(T_IMG, 256, dt=f), kv0=e(T_IMG, 256),
+                          qi0=e(T_IMG, 128), k0=e(T_IMG, 128), v0t=e(128, T_IMG), G=e(N_DINO, 256, dt=f),
+                          GT=e(256, N_DINO_PAD), g16=e(N_DINO, 256), fgh=e(N_DINO, 256, dt=f),
+                          fg=e(N_DINO, self.n_class, dt=f), feat=None, dtok=None)
+        self.state_graph = hip.GraphCache()
+
+    def set_image(self, feat_tok, dino_tok16):
+        """feat_tok f32 [4096,256] (encoder output, token-major); dino_tok16 f16 [5376,1024] (rows >= 5329 zero).
+        Builds the per-image constants into STATIC buffers (graph-replayable; valid until the next image)."""
+        if self.state is None:
+            self._alloc_state()
+        st = self.state
         L0 = self.layers[0]
-        st = {}
-        src16 = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
-        srcpe16 = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
-        src32 = torch.empty(T_IMG, 256, dtype=torch.float32, device=dev)
-        hip.add_cast(feat_tok, self.no_mask, 0, out16=src16, out32=src32)
-        hip.add_cast(src32, self.pe, 256, out16=srcpe16)
-        st["src16"] = src16
-        st["kv0"] = torch.empty(T_IMG, 256, dtype=torch.float16, device=dev)
-        hip.gemm_f16(srcpe16, L0["t2i_kv_w"][:128], out=st["kv0"][:, :128], bias=L0["t2i_kv_b"][:128])
-        hip.gemm_f16(src16, L0["t2i_kv_w"][128:], out=st["kv0"][:, 128:], bias=L0["t2i_kv_b"][128:])
-        st["qi0"] = hip.gemm_f16(srcpe16, L0["i2t_q_w"], bias=L0["i2t_q_b"])
-        # the same hoisted K / V in the two register layouts of the fused kernel: K [4096,128], V^T [128,4096]
-        st["k0"] = hip.gemm_f16(srcpe16, L0["t2i_kv_w"][:128], bias=L0["t2i_kv_b"][:128])
-        st["v0t"] = hip.gemm_f16(L0["t2i_kv_w"][128:], src16, residual=L0["t2i_v_bias_mat"], M=128)
-        # dino_proj, both orientations: G f32 [5329,256] (+bias) for the FG prior and
-        # G^T f16 [256, 5376] (no bias; added after pooling) as the K-contiguous pooling operand.
-        st["G"] = hip.gemm_f16(dino_tok16, self.dino_proj_w, bias=self.dino_proj_b, out_dtype=torch.float32, M=N_DINO)
-        st["GT"] = hip.gemm_f16(self.dino_proj_w, dino_tok16, out_dtype=torch.float16, M=256)
-        self.state = st
-        return st
+
+        def launch():
+            hip.add_cast(feat_tok, self.no_mask, 0, out16=st["src16"], out32=st["src32"])
+            hip.add_cast(st["src32"], self.pe, 256, out16=st["srcpe16"])
+            hip.gemm_f16(st["srcpe16"], L0["t2i_kv_w"][:128], out=st["kv0"][:, :128], bias=L0["t2i_kv_b"][:128])
+            hip.gemm_f16(st["src16"], L0["t2i_kv_w"][128:], out=st["kv0"][:, 128:], bias=L0["t2i_kv_b"][128:])
+            hip.gemm_f16(st["srcpe16"], L0["i2t_q_w"], out=st["qi0"], bias=L0["i2t_q_b"])
+            # the same hoisted K / V in the two register layouts of the fused kernel: K [4096,128], V^T [128,4096]
+            hip.gemm_f16(st["srcpe16"], L0["t2i_kv_w"][:128], out=st["k0"], bias=L0["t2i_kv_b"][:128])
+            hip.gemm_f16(L0["t2i_kv_w"][128:], st["src16"], out=st["v0t"], residual=L0["t2i_v_bias_mat"], M=128)
+            # dino_proj, both orientations: G f32 [5329,256] (+bias) for the FG prior and
+            # G^T f16 [256, 5376] (no bias; added after pooling) as the K-contiguous pooling operand.
+            hip.gemm_f16(dino_tok16, self.dino_proj_w, out=st["G"], bias=self.dino_proj_b, M=N_DINO)
+            hip.gemm_f16(self.dino_proj_w, dino_tok16, out=st["GT"], M=256)
+            # FG prior logits on the 73x73 grid (predictor.py:113-121 up to the classifier)
+            (w1, b1), (w2, b2) = self.classifier
+            hip.add_cast(st["G"], out16=st["g16"])
+            hip.gemm_f16(st["g16"], self.cls_w16, out=st["fgh"], bias=b1, act=hip.ACT_RELU)
+            hip.linear_f32(st["fgh"], w2, b2, out=st["fg"])
+            return st
+
+        return self.state_graph.run((feat_tok.data_ptr(), dino_tok16.data_ptr()), launch)
 
     def fg_logits(self):
-        """predictor.py:113-121 up to the classifier: [5329, n_class] fp32 logits on the 73x73 grid."""
-        G = self.state["G"]
-        (w1, b1), (w2, b2) = self.classifier
-        g16 = torch.empty(N_DINO, 256, dtype=torch.float16, device=self.device)
-        hip.add_cast(G, out16=g16)
-        h = hip.gemm_f16(g16, self.cls_w16, bias=b1, act=hip.ACT_RELU, out_dtype=torch.float32)
-        return hip.linear_f32(h, w2, b2)
+        """[5329, n_class] fp32 FG-prior logits on the 73x73 grid (computed by set_image)."""
+        return self.state["fg"]
 
     # ------------------------------------------------------------------------------------------
     def run_batch(self, coords_f32):
-        """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C])."""
+        """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C]).
+        The ~100 launches of a batch are captured once per batch size into a hipGraph and replayed."""
         B = coords_f32.shape[0]
         if B > self.allocB:
             self._alloc(B)
+        c = self.ws["coords"][:B]
+        c.copy_(coords_f32)
+        return self.batch_graphs.run(B, lambda: self._run_batch(c))
+
+    def _run_batch(self, coords_f32):
+        B = coords_f32.shape[0]
         ws, st = self.ws, self.state
         M7 = B * 7
         BT = B * T_IMG

@@ -63,7 +63,15 @@ class DinoPlan:
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
         TP = 5376
         self.ws = dict(col=e(5329, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
-                       attn=e(TP, D), mlp=e(TP, 4 * D))
+                       attn=e(TP, D), mlp=e(TP, 4 * D), img=e(3 * 1024 * 1024, dt=torch.float32))
+        self.graphs = hip.GraphCache()
+
+    def forward_static(self, img_chw_f32, out):
+        """Graph-replayed forward into the caller's static ``out`` buffer (one graph per (h, w, out))."""
+        _, h, w = img_chw_f32.shape
+        buf = self.ws["img"][: 3 * h * w].view(3, h, w)
+        buf.copy_(img_chw_f32)
+        return self.graphs.run((h, w, out.data_ptr()), lambda: self.forward(buf, out=out))
 
     def forward(self, img_chw_f32, out=None, normalized_1022=False):
         """raw f32 [3,h,w] image (0..255) -> x_norm_patchtokens f16 [5329, D]."""
@@ -130,7 +138,7 @@ class DinoV2(torch.nn.Module):
     @torch.no_grad()
     def patch_tokens16(self, raw_chw_f32, out):
         """Fast path: raw image -> x_norm_patchtokens fp16 written into out[:5329]."""
-        return self.plan().forward(raw_chw_f32, out=out[:N_PATCH])
+        return self.plan().forward_static(raw_chw_f32, out[:N_PATCH])
 
     @torch.no_grad()
     def forward_features(self, x):

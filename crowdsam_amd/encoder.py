@@ -49,7 +49,17 @@ class EncoderPlan:
             col=e(4096, 768), x=e(4096, D, dt=torch.float32), h=e(4096, D), qkv=e(4096, 3 * D),
             attn=e(4096, D), mlp=e(4096, 4 * D), th=e(heads, 4096, 64, dt=torch.float32),
             tw=e(heads, 4096, 64, dt=torch.float32), n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
-            col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32))
+            col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32),
+            img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32))
+        self.graphs = hip.GraphCache()
+
+    def forward_static(self, img_chw_f32):
+        """Graph-replayed forward: the raw frame is copied into a static buffer, features land in a static
+        buffer (valid until the next image).  One graph per frame shape (h, w)."""
+        _, h, w = img_chw_f32.shape
+        buf = self.ws["img"][: 3 * h * w].view(3, h, w)
+        buf.copy_(img_chw_f32)
+        return self.graphs.run((h, w), lambda: self.forward(buf, out=self.ws["feat"]))
 
     def forward(self, img_chw_f32, out=None, skip_im2col=False):
         """img f32 [3,h,w] raw 0..255 (long side <= 1024) -> features f32 [4096,256] token-major.

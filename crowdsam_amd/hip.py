@@ -142,6 +142,34 @@ class KernelTimer:
 
 
 _timer = None
+GRAPHS_ENABLED = os.environ.get("CSAM_GRAPHS", "1") != "0"
+
+
+class GraphCache:
+    """hipGraph capture/replay of a launch sequence that only touches static buffers.  The decoder batch is
+    ~100 short kernels: replaying one graph removes the per-launch host cost (Python + ctypes + hipLaunch).
+    Disabled while a KernelTimer is active (events cannot be recorded inside a replayed graph)."""
+
+    def __init__(self):
+        self.graphs = {}
+
+    def clear(self):
+        self.graphs.clear()
+
+    def run(self, key, fn):
+        if not GRAPHS_ENABLED or _timer is not None:
+            return fn()
+        ent = self.graphs.get(key)
+        if ent is None:
+            fn()                                   # eager warm-up (also sets kernel attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            ent = self.graphs[key] = (g, out)
+        ent[0].replay()
+        return ent[1]
+
 
 
 def set_timer(timer):

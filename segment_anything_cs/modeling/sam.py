@@ -81,7 +81,7 @@ class ImageEncoderViT(_Planned):
 
     def forward_tokens(self, raw_chw_f32):
         """Fast path: raw 0..255 image f32 [3,h,w] -> features f32 [4096,256] (token-major)."""
-        return self.plan().forward(raw_chw_f32)
+        return self.plan().forward_static(raw_chw_f32)
 
     @torch.no_grad()
     def forward(self, x):
