@@ -17,6 +17,7 @@
 // feed needs the out-proj weight columns permuted on the host:
 //     k' = s*32 + g*8 + e   <->   k = (2s + (e>=4))*16 + g*4 + (e&3).
 #include "csam_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,7 +30,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 constexpr int I2T_TOK = 128;                 // tokens per workgroup
 constexpr int I2T_STAGE = 64 * 1024;         // operand staging region (bytes)
 constexpr int I2T_KV = 2 * 8 * 64 * 8;       // per-head MFMA A-fragment tables of the prompt's k and v^T
-constexpr int I2T_SMEM = I2T_STAGE + I2T_KV;
+constexpr int I2T_PAR = I2T_STAGE + I2T_KV;    // bo | gamma | beta fp32 [3][256]
+constexpr int I2T_SMEM = I2T_PAR + 3 * 256 * 4;
 
 struct I2tArgs {
   const half_t* X; long x_bstride;           // keys in  [.,256] (per-prompt stride; 0 = shared src)
@@ -42,6 +44,7 @@ struct I2tArgs {
   const float* gamma; const float* beta; float eps;
   half_t* out;                               // keys out [B*4096, 256]
   int T;                                     // 4096
+  int dbg;                                   // developer ablation bits (CSAM_DBG env)
 };
 
 template <int QMODE>
@@ -65,6 +68,12 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
       if (g4 + r < 7) va[r] = p.kv_v[((long)b * 7 + g4 + r) * 128 + h * 16 + r16];
     kfr[i] = ka;
     vfr[i] = va;
+  }
+  float* par = (float*)(smem + I2T_PAR);
+  if (tid < 256) {
+    par[tid] = p.bo[tid];
+    par[256 + tid] = p.gamma[tid];
+    par[512 + tid] = p.beta[tid];
   }
 
   floatx4 q[2][8];
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int cur = kt & 1;
@@ -142,12 +152,29 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     __syncthreads();   // fragment tables visible
   }
 
+  // prefetch Wo' (64 KB) into the now-free staging region; it lands while phase 2 runs
+  {
+    // 256 rows x 256 B = 4096 16-B chunks: slot = chunk ^ (row & 15) within the row's 16 slots
+    for (int c = tid; c < 4096; c += 256) {
+      const int row = c >> 4, sl = c & 15;
+      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
+    }
+  }
+
   // ---- phase 2: softmax(q k^T / 4) v over the 7 token keys, per (token, head = ni), on the matrix
   // cores: S^T = K_h q^T and O^T = V_h^T P^T as 16x16x16 MFMAs whose B operands are the lane's own
   // accumulator registers (q -> fp16, P -> fp16); row max / sum need 2 shuffles each.
   half8_t of[2][4];
   const float sc = 0.25f * 1.4426950408889634f;
   const bool v0 = fg * 4 + 0 < 7, v1 = fg * 4 + 1 < 7, v2 = fg * 4 + 2 < 7, v3 = fg * 4 + 3 < 7;
+  if (p.dbg & 1) {
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) of[mi][ni >> 1][(ni & 1) * 4 + e] = (half_t)q[mi][ni][e];
+  } else
 #pragma unroll
   for (int ni = 0; ni < 8; ++ni) {
     const half4_t ka = kfr[ni * 64 + lane];
@@ -175,18 +202,15 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     }
   }
 
-  // ---- phase 3: out-proj  D^T = Wo' O^T  (K = 128, N = 256): stage all of Wo' (64 KB) in LDS
-  __syncthreads();
-  {
-    // 256 rows x 256 B = 4096 16-B chunks: slot = chunk ^ (row & 15) within the row's 16 slots
-    for (int c = tid; c < 4096; c += 256) {
-      const int row = c >> 4, sl = c & 15;
-      // lane-linear LDS image: thread c writes at c*16; it must hold source chunk (sl ^ (row&15))
-      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  if (p.dbg & 2) {
+    half_t* orow = p.out + ((long)b * p.T + t0 + wave * 32 + fr) * 256 + fg * 4;
+    *(half8_t*)orow = of[0][0];
+    *(half8_t*)(orow + 16 * 256) = of[1][0];
+    return;
   }
+  // ---- phase 3: out-proj  D^T = Wo' O^T  (K = 128, N = 256) from the prefetched LDS image of Wo'
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   floatx4 acc[2][16];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -205,18 +229,31 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     }
   }
 
-  // ---- epilogue: + bias + residual, LayerNorm(256), fp16 store
+  // ---- epilogue: + bias + residual, LayerNorm(256), fp16 store.
+  // Residual rows come in and results go out through an LDS tile [128 tokens][512 B] whose 16-B slots are
+  // XOR-swizzled with (row & 15): global traffic is whole coalesced 512-B rows (the accumulator layout
+  // alone would give 8-byte pieces in 32-B segments -- store-issue bound), LDS accesses conflict-free.
+  __syncthreads();                                  // all waves done reading Wo' from LDS
+  {
+    const half_t* xres = p.X + (long)b * p.x_bstride + (long)t0 * 256;
+    for (int c = tid; c < 4096; c += 256) {         // 128 rows x 32 slots, lane-linear glds
+      const int row = c >> 5, sl = c & 31;
+      glds16(xres + (long)row * 256 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    asm volatile("" ::: "memory");
-    const int tok = t0 + wave * 32 + mi * 16 + fr;
-    const half_t* xr = p.X + (long)b * p.x_bstride + (long)tok * 256 + fg * 4;
+    const int row = wave * 32 + mi * 16 + fr;
+    char* lrow = smem + row * 512;
     float sum = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 16; ++ni) {
       if ((ni & 3) == 0) asm volatile("" ::: "memory");
-      const floatx4 bb = *(const floatx4*)(p.bo + ni * 16 + fg * 4);
-      const half4_t r = *(const half4_t*)(xr + ni * 16);
+      const floatx4 bb = *(const floatx4*)(par + ni * 16 + fg * 4);
+      const int slot = (ni * 2 + (fg >> 1)) ^ (row & 15);
+      const half4_t r = *(const half4_t*)(lrow + slot * 16 + (fg & 1) * 8);
       floatx4 v = acc[mi][ni] + bb;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -239,16 +276,25 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     var += __shfl_xor(var, 16, 64);
     var += __shfl_xor(var, 32, 64);
     const float rstd = rsqrtf(var * (1.f / 256.f) + p.eps);
-    half_t* orow = p.out + ((long)b * p.T + tok) * 256 + fg * 4;
 #pragma unroll
     for (int ni = 0; ni < 16; ++ni) {
       if ((ni & 3) == 0) asm volatile("" ::: "memory");
-      const floatx4 g = *(const floatx4*)(p.gamma + ni * 16 + fg * 4);
-      const floatx4 be = *(const floatx4*)(p.beta + ni * 16 + fg * 4);
+      const floatx4 g = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
+      const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
       half4_t h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) h[e] = (half_t)((acc[mi][ni][e] - mean) * rstd * g[e] + be[e]);
-      *(half4_t*)(orow + ni * 16) = h;
+      const int slot = (ni * 2 + (fg >> 1)) ^ (row & 15);
+      *(half4_t*)(lrow + slot * 16 + (fg & 1) * 8) = h;   // same positions this lane read: no hazard
+    }
+  }
+  __syncthreads();
+  {
+    half_t* obase = p.out + ((long)b * p.T + t0) * 256;
+    for (int c = tid; c < 4096; c += 256) {
+      const int row = c >> 5, sl = c & 31;
+      const half8_t v = *(const half8_t*)(smem + c * 16);
+      *(half8_t*)(obase + (long)row * 256 + ((sl ^ (row & 15)) * 8)) = v;
     }
   }
 }
@@ -270,6 +316,11 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
   a.kv_k = (const half_t*)k_f16; a.kv_v = (const half_t*)v_f16;
   a.Wo = (const half_t*)Wo_perm_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("CSAM_DBG_I2T"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)i2t_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
@@ -314,6 +365,7 @@ struct UpArgs {
   const float* b2;          // [128]
   const float* hyper;       // [B,4,32]
   float* masks;             // [B,4,256,256]
+  int dbg;                  // developer ablation bits (CSAM_DBG env): 1 = skip phases 2-4, 2 = skip GEMM1
 };
 
 __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
@@ -376,6 +428,7 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (!(p.dbg & 2))
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     const int cur = kt & 1;
@@ -412,6 +465,9 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
   const half8_t hhi = *(const half8_t*)(smem + UP_HFR + lane * 16);
   const half8_t hlo = *(const half8_t*)(smem + UP_HFR + 1024 + lane * 16);
   float* outs = (float*)(smem);                     // [2 r][4 l][4 yy][256 X] fp32 = 32 KB (aliases XS/WS)
+  if (p.dbg & 1) {
+    outs[tid] = a1[0][0][0] + a1[1][1][1] + a1[2][2][2] + a1[3][3][3];
+  } else
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     asm volatile("" ::: "memory");
@@ -502,6 +558,9 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   UpArgs a;
   a.X = (const half_t*)keys_f16; a.W1 = (const half_t*)W1_f16; a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta;
   a.eps = eps; a.W2 = (const half_t*)W2_perm_f16; a.b2 = b2; a.hyper = hyper; a.masks = masks;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("CSAM_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)upscale_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
