@@ -25,24 +25,63 @@ constexpr int TILE_HALFS = KT * K_LD;  // 4608 halfs = 9216 B
 constexpr int QPW = 32;                // queries per wave
 constexpr int QPB = 128;               // queries per block
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// V^T per head: vt[h][d][t] = qkv[t][v_off + h*64 + d], t < T (columns T..Tpad-1 stay zero).
+// A 64x64 tile goes through LDS so that both the read (128 B per token) and the write (128 B per dim row)
+// are coalesced.  ~20 MB of traffic per DINOv2 block: a few microseconds.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restrict__ qkv, long ld, int v_off,
+                                                          half_t* __restrict__ vt, int T, int Tpad) {
+  __shared__ half_t tile[64][66];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;           // 512 16-B chunks: token c>>3, dims (c&7)*8..+7
+    const int t = t0 + (c >> 3);
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < T) v = *(const half8_t*)(qkv + (long)t * ld + v_off + h * 64 + (c & 7) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[(c & 7) * 8 + e][c >> 3] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;           // dim row c>>3, tokens (c&7)*8..+7
+    const int d = c >> 3, tt = (c & 7) * 8;
+    half8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[d][tt + e];
+    *(half8_t*)(vt + ((long)h * 64 + d) * Tpad + t0 + tt) = v;
+  }
+}
+
+// K-tile LDS swizzle: fragment reads touch key rows {8a + b (+4)}, a,b in 0..3 (see the key permutation
+// below), so the XOR term must separate rows by bits 1 and 3..4 rather than by (row & 7).
+__device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
 template <bool BIAS>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
-                                                         int q_off, int k_off, int v_off,
+                                                         int q_off, int k_off,
+                                                         const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ th,
                                                          const float* __restrict__ tw,
                                                          half_t* __restrict__ out, long ldo, int T,
                                                          float scale) {
-  __shared__ __attribute__((aligned(16))) half_t Ks[2][TILE_HALFS];
-  __shared__ __attribute__((aligned(16))) half_t Vs[2][TILE_HALFS];
+  // LDS: 2 stages x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 32 KB, filled by global_load_lds
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
   const int head = blockIdx.y;
   const int q0 = blockIdx.x * QPB + wave * QPW;
   const half_t* qp = qkv + q_off + head * 64;
   const half_t* kp = qkv + k_off + head * 64;
-  const half_t* vp = qkv + v_off + head * 64;
+  const half_t* vtp = vt + (long)head * 64 * Tpad;
 
-  // ---- Q fragments (B operand: column = query fr), rows clamped for the ragged tail
   half8_t qf[2][2];
   int qrow[2];
 #pragma unroll
@@ -52,7 +91,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[rt][ks] = *(const half8_t*)(qp + (long)qc * ld + (ks * 4 + fg) * 8);
   }
-  // ---- rel-pos: Tw registers (constant over key tiles)
+  // Key permutation inside a 32-key step s: accumulator row (4g + r) of key tile kt holds key
+  // 32s + 8g + r + 4*(kt&1), so that a lane's 8 P values of a step are 8 CONSECUTIVE keys and the V^T
+  // fragment is one 16-B read.  Row this lane supplies as the A operand of S^T = K Q^T:
+  const int krow_in_step = 8 * (fr >> 2) + (fr & 3);
   floatx4 twr[2][4];
   const float* thp[2] = {nullptr, nullptr};
   if constexpr (BIAS) {
@@ -62,10 +104,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
       const float* twq = tw + ((long)head * T + qc) * 64;
       thp[rt] = th + ((long)head * T + qc) * 64;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) twr[rt][kt] = *(const floatx4*)(twq + kt * 16 + fg * 4);
+      for (int kt = 0; kt < 4; ++kt) twr[rt][kt] = *(const floatx4*)(twq + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1));
     }
   }
-
   floatx4 o[2][4];
   float m[2], l[2];
 #pragma unroll
@@ -76,48 +117,35 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
     for (int dt = 0; dt < 4; ++dt) o[rt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- staging: 512 16-B chunks per operand per tile, 2 per thread
   const int nt = (T + KT - 1) / KT;
-  half8_t kreg[2], vreg[2];
-  auto gload = [&](int t) {
+  auto stage = [&](int buf, int t) {
+    // 512 16-B pieces per tile, 2 per thread: piece c -> row c>>3, LDS slot c&7
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256;
-      int key = t * KT + (c >> 3);
+      const int row = c >> 3, sl = c & 7;
+      int key = t * KT + row;
       key = key < T ? key : T - 1;
-      kreg[i] = *(const half8_t*)(kp + (long)key * ld + (c & 7) * 8);
-      vreg[i] = *(const half8_t*)(vp + (long)key * ld + (c & 7) * 8);
+      glds16(kp + (long)key * ld + ((sl ^ kswz(row)) * 8), smem + buf * 16384 + (c & ~63) * 16);
+      glds16(vtp + (long)row * Tpad + t * KT + ((sl ^ (row & 7)) * 8), smem + buf * 16384 + 8192 + (c & ~63) * 16);
     }
   };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256;
-      const int key = c >> 3, ch = c & 7;
-      *(half8_t*)(&Ks[buf][key * K_LD + ch * 8]) = kreg[i];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Vs[buf][(ch * 8 + e) * V_LD + key] = vreg[i][e];
-    }
-  };
-  gload(0);
-  lstore(0);
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const float sl2 = scale * 1.4426950408889634f;
-  const float inv_scale_bias = 1.0f;  // tables already hold bias/scale
-
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) gload(t + 1);
-    const half_t* Kc = Ks[cur];
-    const half_t* Vc = Vs[cur];
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* Kc = smem + cur * 16384;
+    const char* Vc = Kc + 8192;
 
-    // ---- S^T = K Q^T (+ bias)
     floatx4 s[2][4];
     float thv[2] = {0.f, 0.f};
     if constexpr (BIAS) {
-      thv[0] = thp[0][t] * inv_scale_bias;
-      thv[1] = thp[1][t] * inv_scale_bias;
+      thv[0] = thp[0][t];
+      thv[1] = thp[1][t];
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -133,14 +161,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const half8_t kf = *(const half8_t*)(Kc + (kt * 16 + fr) * K_LD + (ks * 4 + fg) * 8);
+        const int krow = (kt >> 1) * 32 + krow_in_step + 4 * (kt & 1);
+        const half8_t kf = *(const half8_t*)(Kc + krow * 128 + (((ks * 4 + fg) ^ kswz(krow)) << 4));
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
           s[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][ks], s[rt][kt], 0, 0, 0);
       }
     }
-    // ---- online softmax (base 2); lane holds keys kt*16 + fg*4 + j of query fr
-    const int kbase = t * KT + fg * 4;
+    // ---- online softmax (base 2); lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr
     const bool tail = (t + 1) * KT > T;
     half8_t pf[2][2];
 #pragma unroll
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = s[rt][kt][j] * sl2;
-          if (tail && kbase + kt * 16 + j >= T) v = -INFINITY;
+          if (tail && t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) v = -INFINITY;
           s[rt][kt][j] = v;
           mx = fmaxf(mx, v);
         }
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
           s[rt][kt][j] = e;
           ps += e;
         }
-      l[rt] = l[rt] * alpha + ps;   // lane-partial sum (reduced over fg at the end)
+      l[rt] = l[rt] * alpha + ps;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= alpha;
 #pragma unroll
@@ -180,21 +208,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
           pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
         }
     }
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T: V^T fragment = dims row dt*16+fr, keys 32 st + 8 fg .. +7 (one 16-B read)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const half_t* vr = Vc + (dt * 16 + fr) * V_LD + fg * 4;
+      const int vrow = dt * 16 + fr;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const half4_t v0 = *(const half4_t*)(vr + 32 * st);
-        const half4_t v1 = *(const half4_t*)(vr + 32 * st + 16);
-        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const half8_t vf = *(const half8_t*)(Vc + vrow * 128 + (((st * 4 + fg) ^ (vrow & 7)) << 4));
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
           o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rt][st], o[rt][dt], 0, 0, 0);
       }
     }
-    if (t + 1 < nt) lstore(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -254,21 +280,33 @@ extern "C" int csam_relpos_tables(void* stream, const void* qkv_f16, long ld, co
   return CSAM_OK;
 }
 
+extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
+  const long Tpad = (long)((T + 63) / 64) * 64;
+  return (long)nH * 64 * Tpad * 2;
+}
+
 extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
                                const float* th, const float* tw, void* out_f16, long ldo, int T, int nH,
-                               float scale) {
-  CSAM_REQUIRE(qkv_f16 && out_f16 && T > 0 && nH > 0, "csam_flash_attn: bad args");
+                               float scale, void* vt_workspace, long vt_workspace_bytes) {
+  CSAM_REQUIRE(qkv_f16 && out_f16 && vt_workspace && T > 0 && nH > 0, "csam_flash_attn: bad args");
+  if (vt_workspace_bytes < csam_flash_attn_workspace_bytes(T, nH)) {
+    csam_set_error("csam_flash_attn: V^T workspace too small (must also be zero-initialised once)");
+    return CSAM_ERR_WORKSPACE;
+  }
+  const int Tpad = ((T + 63) / 64) * 64;
   CSAM_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0,
                "csam_flash_attn: alignment");
   CSAM_REQUIRE((th == nullptr) == (tw == nullptr), "csam_flash_attn: th/tw must come together");
   CSAM_REQUIRE(!th || T == 4096, "csam_flash_attn: rel-pos bias needs the 64x64 token grid");
+  hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)qkv_f16, ld, v_off, (half_t*)vt_workspace, T, Tpad);
   dim3 grid(csam_cdiv(T, QPB), nH), block(256);
   if (th)
     hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, v_off, th, tw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, th, tw, (half_t*)out_f16, ldo, T, scale);
   else
     hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, v_off, th, tw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, th, tw, (half_t*)out_f16, ldo, T, scale);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
   return CSAM_OK;
 }

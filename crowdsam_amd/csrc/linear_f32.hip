@@ -17,7 +17,11 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ R, long ldr,
                                                          float* __restrict__ C, long ldc, int M, int N,
-                                                         int K, int act) {
+                                                         int K, int act, long sA, long sW, long sB, long sC) {
+  A += (long)blockIdx.z * sA;
+  W += (long)blockIdx.z * sW;
+  if (bias) bias += (long)blockIdx.z * sB;
+  C += (long)blockIdx.z * sC;
   __shared__ float As[LBM][LBK + 1];
   __shared__ float Ws[LBN][LBK + 1];
   const int tid = threadIdx.x;
@@ -72,7 +76,19 @@ extern "C" int csam_linear_f32(void* stream, const float* A, long lda, const flo
   CSAM_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "csam_linear_f32: bad args");
   dim3 grid(csam_cdiv(N, LBN), csam_cdiv(M, LBM));
   hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, bias, residual,
-                     ldr, C, ldc, M, N, K, act);
+                     ldr, C, ldc, M, N, K, act, 0L, 0L, 0L, 0L);
   CSAM_LAUNCH_CHECK("csam_linear_f32");
+  return CSAM_OK;
+}
+
+// `batch` independent problems (grid.z) with element strides; no residual (the 4 hyper-MLP output layers).
+extern "C" int csam_linear_f32_batched(void* stream, const float* A, long lda, long strideA, const float* W, long ldw,
+                                       long strideW, const float* bias, long strideBias, float* C, long ldc,
+                                       long strideC, int M, int N, int K, int act, int batch) {
+  CSAM_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && batch > 0, "csam_linear_f32_batched: bad args");
+  dim3 grid(csam_cdiv(N, LBN), csam_cdiv(M, LBM), batch);
+  hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, bias,
+                     (const float*)nullptr, 0L, C, ldc, M, N, K, act, strideA, strideW, strideBias, strideC);
+  CSAM_LAUNCH_CHECK("csam_linear_f32_batched");
   return CSAM_OK;
 }

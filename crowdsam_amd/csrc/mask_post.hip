@@ -175,6 +175,111 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
   }
 }
 
+// Fast path of csam_mask_post for the common geometry (original_size == input_size, source = the 256x256
+// low-res logits, exact x4 up-sampling): the 16 output rows of a workgroup depend on 6 source rows and each
+// thread's 4 output pixels on 3 source columns, so a thread holds its 18 source values in registers and the
+// kernel is a pure streaming write of the mask bytes.  Arithmetic is IDENTICAL to the generic kernel
+// (same src_index / bilerp expressions), so results are bit-identical to it.
+__global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int x4 = tid * 4;
+  const float* p = a.src + (long)b * a.src_bstride + (long)a.sel[b] * a.plane;
+  const int i = blockIdx.x;                      // 16 output rows: y = 16 i .. 16 i + 15
+  int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+  // source columns t-1, t, t+1 and rows 4i-1 .. 4i+4 (clamped)
+  const int c0 = max(tid - 1, 0), c1 = tid, c2 = min(tid + 1, 255);
+  float v[6][3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int r = min(max(4 * i - 1 + k, 0), 255);
+    v[k][0] = p[r * 256 + c0];
+    v[k][1] = p[r * 256 + c1];
+    v[k][2] = p[r * 256 + c2];
+  }
+  int x0[4], x1[4];
+  float lx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) src_index(0.25f, x4 + e, 256, x0[e], x1[e], lx[e]);
+  if (x4 < a.W) {
+#pragma unroll
+    for (int yy = 0; yy < 16; ++yy) {
+      const int y = i * 16 + yy;
+      if (y >= a.H) break;
+      int y0, y1;
+      float ly;
+      src_index(0.25f, y, 256, y0, y1, ly);
+      // static row slots: y0 = 4i + o, o = floor(0.25*yy - 0.375) in {-1,0,1,2,3}; y1 is the next slot
+      // (clamping only ever selects a row whose weight is exactly 0, or the same clamped row)
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int k0 = (yy < 2) ? 0 : (yy < 6) ? 1 : (yy < 10) ? 2 : (yy < 14) ? 3 : 4;
+      const float* top = v[k0];
+      const float* bot = (y1 == y0) ? v[k0] : v[k0 + 1];
+      uint32_t packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = x4 + e;
+        if (x < a.W) {
+          const float t0 = (x0[e] == c1) ? top[1] : (x0[e] == c0 ? top[0] : top[2]);
+          const float t1 = (x1[e] == c1) ? top[1] : (x1[e] == c0 ? top[0] : top[2]);
+          const float b0 = (x0[e] == c1) ? bot[1] : (x0[e] == c0 ? bot[0] : bot[2]);
+          const float b1 = (x1[e] == c1) ? bot[1] : (x1[e] == c0 ? bot[0] : bot[2]);
+          const float w0x = 1.f - lx[e], w0y = 1.f - ly;
+          const float tt = w0x * t0 + lx[e] * t1;
+          const float bb = w0x * b0 + lx[e] * b1;
+          const float val = w0y * tt + ly * bb;
+          cnt_i += val > (a.thr + a.off);
+          cnt_u += val > (a.thr - a.off);
+          if (val > a.thr) {
+            packed |= 1u << (8 * e);
+            xmin = min(xmin, x);
+            xmax = max(xmax, x);
+            ymin = min(ymin, y);
+            ymax = max(ymax, y);
+          }
+        }
+      }
+      const long o = ((long)b * a.H + y) * a.W + x4;
+      if (x4 + 3 < a.W && (o & 3) == 0) {
+        *(uint32_t*)(a.out_mask + o) = packed;
+      } else {
+        for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_mask[o + e] = (packed >> (8 * e)) & 1;
+      }
+    }
+  }
+  __shared__ int red[4][6];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt_i += __shfl_xor(cnt_i, o, 64);
+    cnt_u += __shfl_xor(cnt_u, o, 64);
+    xmin = min(xmin, __shfl_xor(xmin, o, 64));
+    xmax = max(xmax, __shfl_xor(xmax, o, 64));
+    ymin = min(ymin, __shfl_xor(ymin, o, 64));
+    ymax = max(ymax, __shfl_xor(ymax, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    int* r = red[tid >> 6];
+    r[0] = cnt_i; r[1] = cnt_u; r[2] = xmin; r[3] = ymin; r[4] = xmax; r[5] = ymax;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      cnt_i += red[w][0]; cnt_u += red[w][1];
+      xmin = min(xmin, red[w][2]); ymin = min(ymin, red[w][3]);
+      xmax = max(xmax, red[w][4]); ymax = max(ymax, red[w][5]);
+    }
+    if (cnt_i) atomicAdd(a.inter + b, cnt_i);
+    if (cnt_u) atomicAdd(a.uni + b, cnt_u);
+    if (xmax >= 0) {
+      atomicMin(a.box + b * 4 + 0, xmin);
+      atomicMin(a.box + b * 4 + 1, ymin);
+      atomicMax(a.box + b * 4 + 2, xmax);
+      atomicMax(a.box + b * 4 + 3, ymax);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void post_init_kernel(int* inter, int* uni, int* box, int B) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
@@ -254,7 +359,7 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
     a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
     dim3 grid(csam_cdiv(out_h, POST_ROWS), 1, B);
-    hipLaunchKernelGGL(mask_post_kernel<1>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mask_post_x4_kernel, grid, dim3(256), 0, s, a);
   } else {
     CSAM_REQUIRE(tmp_f32, "csam_mask_post: tmp buffer required when original_size != input_size");
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;

@@ -146,6 +146,8 @@ class DecoderPlan:
         self.hyper_b0 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.0.bias"] for i in range(4)]))
         self.hyper_w1 = f16(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.1.weight"] for i in range(4)]))
         self.hyper_b1 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.1.bias"] for i in range(4)]))
+        self.hyper_w2 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.2.weight"] for i in range(4)]))
+        self.hyper_b2 = f32(torch.stack([sd[f"{M}output_hypernetworks_mlps.{i}.layers.2.bias"] for i in range(4)]))
         h16 = lambda pre, i: f16(sd[f"{pre}.layers.{i}.weight"])
         self.iou_head = mlp(M + "iou_prediction_head", 3)
         self.par_iou_head = mlp(M + "parallel_iou_head", 3)
@@ -340,8 +342,8 @@ class DecoderPlan:
                              B, 256, 256, 4, bias=self.hyper_b0, sbias=256, act=hip.ACT_RELU)
         hip.gemm_f16_batched(hh1, 256, hh1.stride(0), self.hyper_w1, 256, 256 * 256, hh2, 256, hh2.stride(0),
                              B, 256, 256, 4, bias=self.hyper_b1, sbias=256, act=hip.ACT_RELU)
-        for i in range(4):
-            hip.linear_f32(hh2[i], self.hyper[i][2][0], self.hyper[i][2][1], out=ws["hyper"][:B, i], M=B)
+        hip.linear_f32_batched(hh2, 256, hh2.stride(0), self.hyper_w2, 256, 32 * 256, self.hyper_b2, 32, ws["hyper"],
+                               128, 32, B, 32, 256, 4)
         masks = ws["masks"][:B]
         if self.fused:
             hip.upscale_fused(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,

@@ -30,10 +30,11 @@ SIGNATURES = {
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
     "csam_win_attn": [_P, _P, _P, _P, _P, _P, _I, _I, _F],
     "csam_relpos_tables": [_P, _P, _L, _P, _P, _P, _P, _I, _F],
-    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _F],
+    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _F, _P, _L],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
     "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
+    "csam_linear_f32_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _P, _L, _L, _I, _I, _I, _I, _I],
     "csam_point_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
     "csam_pe_points": [_P, _P, _P, _P, _I],
     "csam_token_self_attn": [_P, _P, _P, _P, _I],
@@ -63,6 +64,7 @@ LONG_RETURNS = {
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
     "csam_t2i_fused_workspace_bytes": [_I],
+    "csam_flash_attn_workspace_bytes": [_I, _I],
 }
 
 _lib = None
@@ -280,10 +282,24 @@ def relpos_tables(qkv, rel_h, rel_w, th, tw, nH, scale):
          nH, float(scale))
 
 
-def flash_attn(qkv, out, T, nH, scale, D, th=None, tw=None):
+_vt_ws = {}
+
+
+def flash_vt_workspace(T, nH, device):
+    """Zero-initialised per-head V^T scratch [nH,64,Tpad] f16 (cached per shape/device; static for graphs)."""
+    key = (T, nH, str(device))
+    if key not in _vt_ws:
+        n = lib().csam_flash_attn_workspace_bytes(T, nH)
+        _vt_ws[key] = torch.zeros(n // 2, dtype=torch.float16, device=device)
+    return _vt_ws[key]
+
+
+def flash_attn(qkv, out, T, nH, scale, D, th=None, tw=None, vt=None):
     """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]."""
+    if vt is None:
+        vt = flash_vt_workspace(T, nH, qkv.device)
     call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(th), _ptr(tw), _ptr(out),
-         out.stride(0), T, nH, float(scale))
+         out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2)
     return out
 
 
@@ -460,4 +476,10 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out
+
+
+def linear_f32_batched(a, lda, sa, w, ldw, sw, bias, sbias, out, ldc, sc, M, N, K, batch, act=ACT_NONE):
+    call("csam_linear_f32_batched", _stream(), _ptr(a), lda, sa, _ptr(w), ldw, sw, _ptr(bias), sbias, _ptr(out), ldc, sc,
+         M, N, K, act, batch)
     return out

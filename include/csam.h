@@ -60,6 +60,10 @@ int csam_gemm_f16_batched(void* stream, const void* A_f16, long lda, long stride
 int csam_linear_f32(void* stream, const float* A, long lda, const float* W, long ldw, const float* bias,
                     const float* residual, long ldr, float* C, long ldc, int M, int N, int K, int act);
 
+int csam_linear_f32_batched(void* stream, const float* A, long lda, long strideA, const float* W, long ldw,
+                            long strideW, const float* bias, long strideBias, float* C, long ldc, long strideC,
+                            int M, int N, int K, int act, int batch);
+
 /* ---- encoder-side streaming kernels */
 /* nn.LayerNorm / LayerNorm2d on token-major rows (image_encoder.py:168,180; common.py:38-43;
  * transformer.py norm1-4). One wave per row, D % 4 == 0, D <= 1280. */
@@ -91,8 +95,10 @@ int csam_relpos_tables(void* stream, const void* qkv_f16, long ld, const float* 
                        float* th, float* tw, int nH, float scale);
 /* flash-style global attention, head_dim 64: SAM global blocks (th/tw != NULL, T == 4096) and every
  * DINOv2 block (th == tw == NULL, ragged T). */
+long csam_flash_attn_workspace_bytes(int T, int nH); /* per-head V^T scratch; zero-initialise it once */
 int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off, const float* th,
-                    const float* tw, void* out_f16, long ldo, int T, int nH, float scale);
+                    const float* tw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
+                    long vt_workspace_bytes);
 
 /* ---- prompt encoder + two-way decoder (all prompts of a batch at once) */
 /* prompt_encoder.py:75-93,189-218 + mask_decoder.py:153-155: tokens f32 [B,7,256] =
