@@ -253,14 +253,16 @@ class CrowdSAM:
         tmp = None
         if tuple(p.input_size) != (H, W):
             tmp = torch.empty(B, p.input_size[0], p.input_size[1], dtype=torch.float32, device=dev)
+        # pass 1: statistics of every selected candidate (no mask bytes); filters; pass 2: bytes of the kept ones
         hip.mask_post(low, sel, B, p.input_size, (H, W), p.model.mask_threshold, self.stability_score_offset,
-                      masks, inter, uni, box, tmp)
+                      None, inter, uni, box, tmp)
         stability = torch.empty(B, dtype=torch.float32, device=dev)
         keep = torch.empty(B, dtype=torch.uint8, device=dev)
         occ = torch.empty(B, dtype=torch.uint8, device=dev)
         hip.post_finalize(score, inter, uni, box, self.pred_iou_thresh, self.stability_score_thresh,
                           self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
                           stability, keep, occ, B)
+        hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, masks, tmp)
         return dict(masks_all=masks, score=score, category=category, stability=stability, boxes=box, keep=keep,
                     occ=occ, points=torch.as_tensor(points).to(dev))
 

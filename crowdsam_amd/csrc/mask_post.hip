@@ -81,6 +81,8 @@ struct PostArgs {
   float* out_f32;       // mode 0: [B,H,W] fp32 logits
   uint8_t* out_mask;    // mode 1: [B,H,W] u8
   int* inter; int* uni; int* box;   // mode 1: [B], [B], [B,4] = xmin,ymin,xmax,ymax (pre-initialised)
+  const uint8_t* keep;  // optional [B]: prompts with keep[b]==0 are skipped entirely
+  int stats;            // mode 1: accumulate counts / bbox
 };
 
 constexpr int POST_ROWS = 16;   // output rows per workgroup
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
   // grid: (row chunks of POST_ROWS, 1, B); 256 threads x 4 pixels cover a row of up to 1024 pixels.
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
+  if (a.keep && !a.keep[b]) return;
   const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (a.sel ? (long)a.sel[b] * a.plane : 0);
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
       } else {
         for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_f32[o + e] = vv[e];
       }
-    } else {
+    } else if (a.out_mask) {
       if (x4 + 3 < a.W && (o & 3) == 0) {
         *(uint32_t*)(a.out_mask + o) = packed;
       } else {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
       }
     }
   }
-  if (MODE == 1) {
+  if (MODE == 1 && a.stats) {
     // block reduction -> ONE set of integer atomics per workgroup (order-independent, deterministic)
     __shared__ int red[4][6];
 #pragma unroll
@@ -180,9 +183,11 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
 // thread's 4 output pixels on 3 source columns, so a thread holds its 18 source values in registers and the
 // kernel is a pure streaming write of the mask bytes.  Arithmetic is IDENTICAL to the generic kernel
 // (same src_index / bilerp expressions), so results are bit-identical to it.
+template <int PASS>   // 0: statistics only (counts + bbox), 1: mask bytes of the KEPT prompts only
 __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
+  if (a.keep && !a.keep[b]) return;
   const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (long)a.sel[b] * a.plane;
   const int i = blockIdx.x;                      // 16 output rows: y = 16 i .. 16 i + 15
@@ -229,25 +234,32 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
           const float tt = w0x * t0 + lx[e] * t1;
           const float bb = w0x * b0 + lx[e] * b1;
           const float val = w0y * tt + ly * bb;
-          cnt_i += val > (a.thr + a.off);
-          cnt_u += val > (a.thr - a.off);
+          if (PASS == 0) {
+            cnt_i += val > (a.thr + a.off);
+            cnt_u += val > (a.thr - a.off);
+          }
           if (val > a.thr) {
             packed |= 1u << (8 * e);
-            xmin = min(xmin, x);
-            xmax = max(xmax, x);
-            ymin = min(ymin, y);
-            ymax = max(ymax, y);
+            if (PASS == 0) {
+              xmin = min(xmin, x);
+              xmax = max(xmax, x);
+              ymin = min(ymin, y);
+              ymax = max(ymax, y);
+            }
           }
         }
       }
-      const long o = ((long)b * a.H + y) * a.W + x4;
-      if (x4 + 3 < a.W && (o & 3) == 0) {
-        *(uint32_t*)(a.out_mask + o) = packed;
-      } else {
-        for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_mask[o + e] = (packed >> (8 * e)) & 1;
+      if (PASS == 1) {
+        const long o = ((long)b * a.H + y) * a.W + x4;
+        if (x4 + 3 < a.W && (o & 3) == 0) {
+          *(uint32_t*)(a.out_mask + o) = packed;
+        } else {
+          for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_mask[o + e] = (packed >> (8 * e)) & 1;
+        }
       }
     }
   }
+  if (PASS == 1) return;
   __shared__ int red[4][6];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -342,26 +354,26 @@ extern "C" int csam_select_masks(void* stream, const float* iou, const float* cl
 
 // Fused path of sam.py:153-161 for original_size == input_size (the normal case) and the general
 // two-stage path otherwise (trap 9: 1023-sided frames).  tmp_f32 [B,in_h,in_w] is only needed when
-// (out_h,out_w) != (in_h,in_w).
-extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w,
-                              int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
-                              int* box, float* tmp_f32) {
-  CSAM_REQUIRE(lowres && sel && out_mask_u8 && inter && uni && box && B > 0, "csam_mask_post: bad args");
-  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
-               "csam_mask_post: bad sizes");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
+// (out_h,out_w) != (in_h,in_w).  do_stats: counts + bbox (csam_mask_post); out_mask may be NULL (statistics
+// only: the bytes of the prompts that survive the filters are produced later by csam_mask_write).
+static int post_launch(hipStream_t s, const float* lowres, const int* sel, const uint8_t* keep, int B, int in_h,
+                       int in_w, int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
+                       int* box, float* tmp_f32, int do_stats) {
   PostArgs a;
   a.thr = thr; a.off = off;
-  a.inter = inter; a.uni = uni; a.box = box;
+  a.inter = inter; a.uni = uni; a.box = box; a.keep = keep; a.stats = do_stats;
   if (in_h == out_h && in_w == out_w) {
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
     dim3 grid(csam_cdiv(out_h, POST_ROWS), 1, B);
-    hipLaunchKernelGGL(mask_post_x4_kernel, grid, dim3(256), 0, s, a);
+    if (do_stats) hipLaunchKernelGGL(mask_post_x4_kernel<0>, grid, dim3(256), 0, s, a);
+    if (out_mask_u8) hipLaunchKernelGGL(mask_post_x4_kernel<1>, grid, dim3(256), 0, s, a);
   } else {
-    CSAM_REQUIRE(tmp_f32, "csam_mask_post: tmp buffer required when original_size != input_size");
+    if (!tmp_f32) {
+      csam_set_error("csam_mask_post: tmp buffer required when original_size != input_size");
+      return CSAM_ERR_ARG;
+    }
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 0.25f; a.scale_x = 0.25f;
     a.H = in_h; a.W = in_w; a.out_f32 = tmp_f32; a.out_mask = nullptr;
@@ -373,7 +385,36 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
     dim3 g1(csam_cdiv(out_h, POST_ROWS), 1, B);
     hipLaunchKernelGGL(mask_post_kernel<1>, g1, dim3(256), 0, s, a);
   }
+  return CSAM_OK;
+}
+
+extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w,
+                              int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
+                              int* box, float* tmp_f32) {
+  CSAM_REQUIRE(lowres && sel && inter && uni && box && B > 0, "csam_mask_post: bad args");
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+               "csam_mask_post: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
+  const int rc = post_launch(s, lowres, sel, nullptr, B, in_h, in_w, out_h, out_w, thr, off, out_mask_u8, inter, uni,
+                             box, tmp_f32, 1);
+  if (rc) return rc;
   CSAM_LAUNCH_CHECK("csam_mask_post");
+  return CSAM_OK;
+}
+
+// Second pass of the two-pass mode: mask bytes (x > thr) of the prompts with keep[b] != 0 only
+// (keep == NULL: all).  Rows of skipped prompts in out_mask are left untouched.
+extern "C" int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, int B,
+                               int in_h, int in_w, int out_h, int out_w, float thr, void* out_mask_u8,
+                               float* tmp_f32) {
+  CSAM_REQUIRE(lowres && sel && out_mask_u8 && B > 0, "csam_mask_write: bad args");
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+               "csam_mask_write: bad sizes");
+  const int rc = post_launch((hipStream_t)stream, lowres, sel, (const uint8_t*)keep_u8, B, in_h, in_w, out_h, out_w,
+                             thr, 0.f, out_mask_u8, nullptr, nullptr, nullptr, tmp_f32, 0);
+  if (rc) return rc;
+  CSAM_LAUNCH_CHECK("csam_mask_write");
   return CSAM_OK;
 }
 
@@ -387,6 +428,7 @@ extern "C" int csam_bilinear_f32(void* stream, const float* src, int n, int sh, 
   a.sh = sh; a.sw = sw; a.scale_y = (float)sh / (float)H; a.scale_x = (float)sw / (float)W;
   a.H = H; a.W = W; a.thr = 0.f; a.off = 0.f;
   a.out_f32 = dst; a.out_mask = nullptr; a.inter = nullptr; a.uni = nullptr; a.box = nullptr;
+  a.keep = nullptr; a.stats = 0;
   CSAM_REQUIRE(W <= 1024, "csam_bilinear_f32: W=%d > 1024", W);
   dim3 grid(csam_cdiv(H, POST_ROWS), 1, n);
   hipLaunchKernelGGL(mask_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
+    "csam_mask_write": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
@@ -483,3 +484,9 @@ def linear_f32_batched(a, lda, sa, w, ldw, sw, bias, sbias, out, ldc, sc, M, N, 
     call("csam_linear_f32_batched", _stream(), _ptr(a), lda, sa, _ptr(w), ldw, sw, _ptr(bias), sbias, _ptr(out), ldc, sc,
          M, N, K, act, batch)
     return out
+
+
+def mask_write(lowres, sel, keep, B, in_hw, out_hw, thr, out_mask, tmp=None):
+    """Second pass: mask bytes of the prompts with keep[b] != 0 (rows of skipped prompts stay untouched)."""
+    call("csam_mask_write", _stream(), _ptr(lowres), _ptr(sel), _ptr(keep), B, in_hw[0], in_hw[1], out_hw[0], out_hw[1],
+         float(thr), _ptr(out_mask), _ptr(tmp))

@@ -152,6 +152,10 @@ int csam_select_masks(void* stream, const float* iou, const float* cls, int n_cl
 int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w, int out_h,
                    int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni, int* box,
                    float* tmp_f32);
+/* two-pass mode: csam_mask_post with out_mask_u8 == NULL gives the statistics only; after csam_post_finalize
+ * the bytes of the surviving prompts (keep[b] != 0) are produced by csam_mask_write. */
+int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, int B, int in_h, int in_w,
+                    int out_h, int out_w, float thr, void* out_mask_u8, float* tmp_f32);
 int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W);
 /* crowdsam/model.py:371-389,246: keep / occupancy flags, stability = inter/union, empty box -> 0 */
 int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
