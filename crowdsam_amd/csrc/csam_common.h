@@ -57,7 +57,7 @@ static inline int csam_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ~50 instructions -- the exact-erf GELU (nn.GELU default) was the top VALU cost of the fused upscaler.
 __device__ __forceinline__ float csam_erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the 11-op IEEE divide
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

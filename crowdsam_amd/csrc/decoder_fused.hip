@@ -354,7 +354,8 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
 namespace {
 
 constexpr int UP_XS = 0, UP_WS = 32 * 1024, UP_W2S = 96 * 1024, UP_HFR = 112 * 1024;
-constexpr int UP_SMEM = 112 * 1024 + 2 * 64 * 16;
+constexpr int UP_B2 = 112 * 1024 + 2 * 64 * 16;     // b2 fp32 [128]
+constexpr int UP_SMEM = UP_B2 + 128 * 4;
 
 struct UpArgs {
   const half_t* X;          // keys [B*4096, 256]
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
       *(half8_t*)(smem + UP_HFR + tid * 16) = hi;
       *(half8_t*)(smem + UP_HFR + 1024 + tid * 16) = lo;
     }
+    if (tid >= 64 && tid < 192) ((float*)(smem + UP_B2))[tid - 64] = p.b2[tid - 64];
   }
 
   // ---- phase 1: GEMM1, K = 256 in 4 chunks of 64
@@ -498,16 +500,17 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float y = (a1[mi][ni][e] - mean) * rstd * gv[ni][e] + bv[ni][e];
-        xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)csam_gelu_erf(y);
+        xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)((p.dbg & 16) ? y : csam_gelu_erf(y));
       }
     // GEMM2: [128 n2] x [16 tokens], K = 64 (weights k-permuted): 8 N tiles x 2 k-steps
     floatx4 a2[8];
 #pragma unroll
-    for (int n2 = 0; n2 < 8; ++n2) {
-      a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
-      const int row = n2 * 16 + fr;
+    for (int n2 = 0; n2 < 8; ++n2) a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 2; ++s) {          // k-step outer: 8 independent accumulators back to back
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) {
+        const int row = n2 * 16 + fr;
         const half8_t wf = *(const half8_t*)(smem + UP_W2S + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
         a2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[s], a2[n2], 0, 0, 0);
       }
@@ -518,13 +521,16 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
       half8_t ub;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        const floatx4 bb = *(const floatx4*)(p.b2 + (pos2 * 2 + h2) * 16 + fg * 4);
+        const floatx4 bb = *(const floatx4*)(smem + UP_B2 + ((pos2 * 2 + h2) * 16 + fg * 4) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ub[h2 * 4 + e] = (half_t)csam_gelu_erf(a2[pos2 * 2 + h2][e] + bb[e]);
+        for (int e = 0; e < 4; ++e) {
+          const float z = a2[pos2 * 2 + h2][e] + bb[e];
+          ub[h2 * 4 + e] = (half_t)((p.dbg & 16) ? z : csam_gelu_erf(z));
+        }
       }
       floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
-      if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+      if (fg == 0 && !(p.dbg & 8)) {   // rows 0..3 of the product = the 4 mask logits of this pixel
         const int yy = (pos >> 1) * 2 + (pos2 >> 1);
         const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
 #pragma unroll
