@@ -129,45 +129,74 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = fr][n = fg*4 + j] of each 16x16 tile
+  // ---- epilogue.  Lane holds C[m = fr][n = fg*4 + j] of each 16x16 tile: stored straight from the
+  // accumulators that is 8/16-byte pieces in 32/64-B segments (store-issue bound, measured).  Instead the
+  // tile is staged in the (now free) operand LDS with an XOR-swizzled slot index and written / residual-added
+  // as whole coalesced rows, 16 B per lane.
+  const bool res_late = p.R && p.c_dt == CSAM_DT_F32 && p.r_dt == CSAM_DT_F32;   // residual added at copy-out
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int m = bm0 + wm * 64 + mi * 16 + fr;
-    if (m >= p.M) continue;
+    const int row = wm * 64 + mi * 16 + fr;          // row inside the 128-row tile
+    const int m = bm0 + row;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int n = bn0 + wn * 64 + ni * 16 + fg * 4;
+      const int col = wn * 64 + ni * 16 + fg * 4;    // column inside the 128-col tile
+      const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
-      if (p.bias) {
-        const floatx4 b = *(const floatx4*)(p.bias + n);
-        v += b;
-      }
+      if (p.bias) v += *(const floatx4*)(p.bias + n);
       if (p.act != CSAM_ACT_NONE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = csam_apply_act(v[j], p.act);
       }
-      if (p.colscale) {
-        const floatx4 s = *(const floatx4*)(p.colscale + n);
-        v *= s;
-      }
-      if (p.R) {
+      if (p.colscale) v *= *(const floatx4*)(p.colscale + n);
+      if (p.R && !res_late && m < p.M) {
         const int mr = p.res_mod > 0 ? m % p.res_mod : m;
         if (p.r_dt == CSAM_DT_F32) {
-          const floatx4 r = *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
-          v += r;
+          v += *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
         } else {
           const half4_t r = *(const half4_t*)((const half_t*)p.R + (long)mr * p.ldr + n);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
         }
       }
-      if (p.c_dt == CSAM_DT_F32) {
-        *(floatx4*)((float*)p.C + (long)m * p.ldc + n) = v;
-      } else {
+      if (p.c_dt == CSAM_DT_F32) {                    // [128][512 B], 32 slots of 16 B, slot ^= row & 31
+        const int slot = (col >> 2) ^ (row & 31);
+        *(floatx4*)(smem + row * 512 + slot * 16) = v;
+      } else {                                         // [128][256 B], 16 slots of 16 B, slot ^= row & 15
         half4_t h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
-        *(half4_t*)((half_t*)p.C + (long)m * p.ldc + n) = h;
+        const int slot = (col >> 3) ^ (row & 15);
+        *(half4_t*)(smem + row * 256 + slot * 16 + ((col >> 2) & 1) * 8) = h;
+      }
+    }
+  }
+  __syncthreads();
+  if (p.c_dt == CSAM_DT_F32) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int c = tid + it * 256;                    // 4096 16-B pieces: row c>>5, LDS slot c&31
+      const int row = c >> 5, sl = c & 31;
+      const int m = bm0 + row;
+      if (m < p.M) {
+        const int n = bn0 + ((sl ^ (row & 31)) << 2);
+        floatx4 v = *(const floatx4*)(smem + c * 16);
+        if (res_late) {
+          const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+          v += *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
+        }
+        *(floatx4*)((float*)p.C + (long)m * p.ldc + n) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + it * 256;                    // 2048 16-B pieces: row c>>4, LDS slot c&15
+      const int row = c >> 4, sl = c & 15;
+      const int m = bm0 + row;
+      if (m < p.M) {
+        const int n = bn0 + ((sl ^ (row & 15)) << 3);
+        *(half8_t*)((half_t*)p.C + (long)m * p.ldc + n) = *(const half8_t*)(smem + c * 16);
       }
     }
   }
@@ -183,7 +212,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   CSAM_REQUIRE(M > 0 && N > 0 && K > 0, "csam_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
   CSAM_REQUIRE(N % BN == 0, "csam_gemm_f16: N=%d must be a multiple of %d", N, BN);
   CSAM_REQUIRE(K % BK == 0, "csam_gemm_f16: K=%d must be a multiple of %d", K, BK);
-  CSAM_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "csam_gemm_f16: ld alignment");
+  CSAM_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % (c_dtype == CSAM_DT_F16 ? 8 : 4) == 0, "csam_gemm_f16: ld alignment");
   CSAM_REQUIRE(!residual || ldr % 4 == 0, "csam_gemm_f16: ldr alignment");
   CSAM_REQUIRE(c_dtype == CSAM_DT_F16 || c_dtype == CSAM_DT_F32, "csam_gemm_f16: c_dtype");
   GemmArgs p;
