@@ -17,6 +17,8 @@ re-designed for the GPU:
 """
 import logging
 import math
+import os
+import time
 
 import numpy as np
 import torch
@@ -37,8 +39,18 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     return hip.box_nms(boxes, scores, iou_threshold)
 
 
+_TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
+
+
 class CrowdSAM:
     vis_img_id = 0
+
+    def _tick(self, name, t0):
+        """Per-stage wall time (ms) into self.timings when CSAM_TIMING=1 (adds device syncs: diagnostics only)."""
+        if _TIMING:
+            torch.cuda.synchronize()
+            self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
 
     def __init__(self, config, logger=None, sam_state_dict=None, dino_state_dict=None, dino_depth=24,
                  dino_model=None):
@@ -84,6 +96,7 @@ class CrowdSAM:
         if self.apply_box_offsets or self.fuse_simmap:
             raise NotImplementedError("apply_box_offsets / fuse_simmap are off in the shipped config and not built")
         self.timings = {}
+        self.last_candidates = 0
 
     def load_sam_model(self, sam_model, sam_arch, sam_checkpoint, sam_adapter_checkpoint, dino_model, n_class,
                        sam_state_dict=None):
@@ -155,46 +168,79 @@ class CrowdSAM:
         inv_factor = torch.tensor([feat_size[1] / w, feat_size[0] / h])
         return (coords / inv_factor).numpy()
 
+    def _result_store(self, H, W):
+        """Image-level device store the survivors of every EPS batch are compacted into by the GPU itself
+        (csam_post_finalize_compact + csam_mask_write): MaskData.cat of the reference (crowdsam/model.py:247)
+        without host synchronisation or gather copies.  Static per frame shape, reused across images."""
+        cap = int(self.max_prompts) + int(self.points_per_batch)
+        key = (H, W, cap)
+        if getattr(self, "_store_key", None) != key:
+            dev = self.device
+            e = lambda *s, dt: torch.empty(*s, dtype=dt, device=dev)
+            self._store = dict(masks=e(cap, H, W, dt=torch.uint8), score=e(cap, dt=torch.float32),
+                               stability=e(cap, dt=torch.float32), boxes=e(cap, 4, dt=torch.int32),
+                               category=e(cap, dt=torch.int32), points=e(cap, 2, dt=torch.int32),
+                               counter=torch.zeros(1, dtype=torch.int32, device=dev))
+            self._store_key = key
+        return self._store
+
     def _process_crop(self, image, crop_box):
+        t0 = time.perf_counter()
         self.crop_image(image, crop_box)
         self.predictor.set_image(self.image)
+        t0 = self._tick("set_image", t0)
         H, W = self.image.shape[:2]
         orig_h, orig_w = self.orig_image.shape[:2]
         points_for_image = self.sample_prompts()
+        t0 = self._tick("sample_prompts", t0)
         dev = self.device
         prune = math.isfinite(self.filter_thresh)
-        chunks = []                                  # per batch: dict of device tensors (+ host keep if synced)
-        occupy_bits = None
+        store = self._result_store(*self.predictor.original_size)
+        store["counter"].zero_()
 
         points = points_for_image.astype("int")      # :230 truncation
         np.random.shuffle(points)                    # :231 global RNG (seeded by the harness)
         count = 0
+        n_batches = 0
         batch_size = self.points_per_batch
         while len(points) > 0 and count < self.max_prompts:
             batch_size = min(len(points), batch_size)
             sel_pts, points = points[:batch_size], points[batch_size:]
-            bd = self._process_batch(sel_pts, self.predictor.original_size, crop_box)
+            bd = self._process_batch(sel_pts, self.predictor.original_size, crop_box, store)
             if prune and len(points) > 0:
                 rem = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
                 occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
-                hip.occupancy_lookup(rem, bd["masks_all"], bd["occ"], batch_size, H, W, occupy_bits)
+                hip.occupancy_lookup(rem, store["masks"], bd["occ"], batch_size, H, W, occupy_bits, slot=bd["slot"])
                 points = points[~occupy_bits.cpu().numpy().astype(bool)]      # the per-batch sync
-            chunks.append(bd)
             count += batch_size
+            n_batches += 1
         self.predictor.reset_image()
-        if not chunks:
+        t0 = self._tick("eps_sweep", t0)
+        if n_batches == 0:
             return None
-        data = self._gather_batches(chunks)
-        if data is None or len(data["masks"]) == 0:
+        n = int(store["counter"].item())             # the one sync of a dense sweep
+        self.last_candidates = n
+        if n == 0:
             return None
+        data = MaskData(masks=store["masks"][:n].view(torch.bool), iou_preds=store["score"][:n],
+                        points=store["points"][:n].long(), categories=store["category"][:n].long(),
+                        stability_score=store["stability"][:n], boxes=store["boxes"][:n].long())
+        if self.crop_n_layers > 0:
+            keep = ~utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h], self.downscale)
+            if not torch.all(keep):
+                data.filter(keep)
+        t0 = self._tick("gather", t0)
 
         keep = batched_nms(data["boxes"].float(), data["iou_preds"], None, self.box_nms_thresh)
         data.filter(keep)
+        t0 = self._tick("nms", t0)
         if self.min_mask_region_area > 0:
             data = self.postprocess_small_regions(data, self.min_mask_region_area,
                                                   max(self.box_nms_thresh, self.crop_nms_thresh))
+        t0 = self._tick("small_regions", t0)
         data["scores"] = data["iou_preds"]
         data["rles"] = mask_to_rle_pytorch(data["masks"])
+        t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
         del data["masks"]
         data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, self.downscale)
@@ -203,40 +249,15 @@ class CrowdSAM:
         data["fboxes"] = data["boxes"]
         return data
 
-    def _gather_batches(self, chunks):
-        """Concatenate the kept prompts of every batch (one sync for the keep flags)."""
-        keep = torch.cat([c["keep"] for c in chunks]).bool()
-        if self.crop_n_layers > 0:
-            boxes_all = torch.cat([c["boxes"] for c in chunks])
-            orig_h, orig_w = self.orig_image.shape[:2]
-            keep &= ~utils.is_box_near_crop_edge(boxes_all, self._crop_box, [0, 0, orig_w, orig_h], self.downscale)
-        keep_host = keep.cpu()                       # the one sync of a dense sweep
-        if not bool(keep_host.any()):
-            return None
-        idx = keep_host.nonzero()[:, 0].to(self.device)
-        cat = lambda k: torch.cat([c[k] for c in chunks])[idx]
-        parts, off = [], 0
-        for c in chunks:                             # gather kept masks chunk by chunk (no 4 GB concat)
-            n = c["masks_all"].shape[0]
-            loc = keep_host[off:off + n].nonzero()[:, 0]
-            if loc.numel():
-                parts.append(c["masks_all"][loc.to(self.device)])
-            off += n
-        masks = torch.cat(parts) if len(parts) > 1 else parts[0]
-        return MaskData(masks=masks.bool(), iou_preds=cat("score"), points=cat("points"),
-                        categories=cat("category").long(), stability_score=cat("stability"),
-                        boxes=cat("boxes").long())
-
     def select_mask(self, masks, iou_preds):
         if self.mask_selection != "max_iou":
             raise NotImplementedError
         return torch.arange(len(masks)), iou_preds.max(dim=-1)[1]
 
-    def _process_batch(self, points, im_size, crop_box):
-        """One EPS batch: decode B prompts, PWD-Net selection, fused post-processing.
-        Returns device tensors for ALL B prompts plus keep / occupancy flags (filtering is deferred
-        to ``_gather_batches`` so that no host sync is needed here)."""
-        self._crop_box = crop_box
+    def _process_batch(self, points, im_size, crop_box, store):
+        """One EPS batch, entirely asynchronous: decode B prompts, PWD-Net selection, statistics pass, filters +
+        in-kernel compaction of the survivors into ``store``, mask bytes of the survivors.
+        Returns the per-batch occupancy flags and store slots (device) for the pruning lookup."""
         p = self.predictor
         dev = self.device
         B = len(points)
@@ -248,23 +269,24 @@ class CrowdSAM:
         sel, category = i32(B), i32(B)
         score = torch.empty(B, dtype=torch.float32, device=dev)
         hip.select_masks(iou, cls, cls.shape[-1], sel, score, category, None, B)
-        masks = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
         inter, uni, box = i32(B), i32(B), i32(B, 4)
         tmp = None
         if tuple(p.input_size) != (H, W):
             tmp = torch.empty(B, p.input_size[0], p.input_size[1], dtype=torch.float32, device=dev)
-        # pass 1: statistics of every selected candidate (no mask bytes); filters; pass 2: bytes of the kept ones
+        # pass 1: statistics of every selected candidate (no mask bytes)
         hip.mask_post(low, sel, B, p.input_size, (H, W), p.model.mask_threshold, self.stability_score_offset,
                       None, inter, uni, box, tmp)
-        stability = torch.empty(B, dtype=torch.float32, device=dev)
         keep = torch.empty(B, dtype=torch.uint8, device=dev)
         occ = torch.empty(B, dtype=torch.uint8, device=dev)
-        hip.post_finalize(score, inter, uni, box, self.pred_iou_thresh, self.stability_score_thresh,
-                          self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
-                          stability, keep, occ, B)
-        hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, masks, tmp)
-        return dict(masks_all=masks, score=score, category=category, stability=stability, boxes=box, keep=keep,
-                    occ=occ, points=torch.as_tensor(points).to(dev))
+        slot = i32(B)
+        pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+        hip.post_finalize_compact(score, inter, uni, box, category, pts_dev, self.pred_iou_thresh,
+                                  self.stability_score_thresh,
+                                  self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
+                                  keep, occ, slot, store["counter"], store, B)
+        # pass 2: mask bytes of the survivors, straight into their store slots
+        hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, store["masks"], tmp, slot=slot)
+        return dict(occ=occ, slot=slot)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

@@ -22,6 +22,14 @@ data_meta = {
 }
 
 
+# hot-path knobs with the shipped values (reference configs/crowdhuman.yaml:33-58)
+DEFAULT_TEST_CONFIG = dict(
+    mask_selection="max_iou", apply_box_offsets=False, max_prompts=500, filter_thresh=0.7, max_size=1024,
+    grid_size=192, pred_iou_thresh=0.1, fuse_simmap=False, stability_score_thresh=0.8, stability_score_offset=1,
+    box_nms_thresh=0.65, points_per_batch=32, crop_n_layers=0, crop_nms_thresh=0.7, crop_overlap_ratio=0.341,
+    min_mask_region_area=100, pos_sim_thresh=0.5, output_rles=True)
+
+
 # ---- config (crowdsam/utils.py:31-58): YAML -> nested dict, trailing "a.b.c value" overrides
 def load_config(path):
     with open(path, "r") as f:

@@ -82,6 +82,7 @@ struct PostArgs {
   uint8_t* out_mask;    // mode 1: [B,H,W] u8
   int* inter; int* uni; int* box;   // mode 1: [B], [B], [B,4] = xmin,ymin,xmax,ymax (pre-initialised)
   const uint8_t* keep;  // optional [B]: prompts with keep[b]==0 are skipped entirely
+  const int* slot;      // optional [B]: mask bytes of prompt b go to out_mask[slot[b]] (compacted store)
   int stats;            // mode 1: accumulate counts / bbox
 };
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
         }
       }
     }
-    const long o = ((long)b * a.H + y) * a.W + x4;
+    const long o = ((long)((MODE == 1 && a.slot) ? a.slot[b] : b) * a.H + y) * a.W + x4;
     if (MODE == 0) {
       if (x4 + 3 < a.W && (o & 3) == 0) {
         *(floatx4*)(a.out_f32 + o) = floatx4{vv[0], vv[1], vv[2], vv[3]};
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
         }
       }
       if (PASS == 1) {
-        const long o = ((long)b * a.H + y) * a.W + x4;
+        const long o = ((long)(a.slot ? a.slot[b] : b) * a.H + y) * a.W + x4;
         if (x4 + 3 < a.W && (o & 3) == 0) {
           *(uint32_t*)(a.out_mask + o) = packed;
         } else {
@@ -325,10 +326,82 @@ __global__ __launch_bounds__(256) void post_finalize_kernel(const float* __restr
   occ[b] = k && (score[b] > filter_thresh);
 }
 
+// Compacting variant: the same decisions, plus an in-kernel exclusive scan of the keep flags that assigns
+// every surviving prompt a slot in the IMAGE-level result store (base = running device counter), scatters
+// its small fields there and bumps the counter.  No host round trip, no gather copies afterwards: the second
+// mask pass writes the bytes straight to store[slot].  One workgroup (B <= 4096).
+__global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
+    const float* __restrict__ score, const int* __restrict__ inter, const int* __restrict__ uni,
+    const int* __restrict__ box, const int* __restrict__ category, const int* __restrict__ points,
+    float pred_iou_thresh, float stab_thresh, float filter_thresh, uint8_t* __restrict__ keep,
+    uint8_t* __restrict__ occ, int* __restrict__ slot, int* __restrict__ counter, float* __restrict__ o_score,
+    float* __restrict__ o_stab, int* __restrict__ o_box, int* __restrict__ o_cat, int* __restrict__ o_pts, int B,
+    int cap) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = *counter;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    bool k = false;
+    float st = 0.f;
+    int bx[4] = {0, 0, 0, 0};
+    if (b < B) {
+      st = (float)inter[b] / (float)uni[b];
+      k = true;
+      if (pred_iou_thresh > 0.f) k = k && (score[b] > pred_iou_thresh);
+      if (stab_thresh > 0.f) k = k && (st >= stab_thresh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bx[e] = box[b * 4 + e];
+      if (bx[2] < bx[0] || bx[3] < bx[1]) bx[0] = bx[1] = bx[2] = bx[3] = 0;
+      keep[b] = k;
+      occ[b] = k && (score[b] > filter_thresh);
+    }
+    // exclusive scan of k over the 1024 threads
+    const unsigned long long bal = __ballot(k);
+    const int inwave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) woff += wsum[w];
+      total += wsum[w];
+    }
+    const int base = base_s;
+    if (b < B) {
+      int sl = -1;
+      if (k) {
+        sl = base + woff + inwave;
+        if (sl < cap) {
+          o_score[sl] = score[b];
+          o_stab[sl] = st;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o_box[sl * 4 + e] = bx[e];
+          o_cat[sl] = category[b];
+          o_pts[sl * 2] = points[b * 2];
+          o_pts[sl * 2 + 1] = points[b * 2 + 1];
+        } else {
+          sl = -1;   // store full: dropped (cap is sized for max_prompts, cannot happen in the driver)
+          keep[b] = 0;
+          occ[b] = 0;
+        }
+      }
+      slot[b] = sl;
+    }
+    __syncthreads();
+    if (tid == 0) base_s = min(base + total, cap);
+    __syncthreads();
+  }
+  if (tid == 0) *counter = base_s;
+}
+
 // out[p] = OR_b occ[b] & mask[b, y_p, x_p]   (crowdsam/model.py:238,246)
 __global__ __launch_bounds__(256) void occupancy_kernel(const int* __restrict__ pts, int P,
                                                         const uint8_t* __restrict__ masks,
-                                                        const uint8_t* __restrict__ occ, int B, int H, int W,
+                                                        const uint8_t* __restrict__ occ,
+                                                        const int* __restrict__ slot, int B, int H, int W,
                                                         uint8_t* __restrict__ out) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
@@ -336,7 +409,7 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const int* __restrict__ 
   uint8_t r = 0;
   if (x >= 0 && x < W && y >= 0 && y < H) {
     for (int b = 0; b < B; ++b)
-      if (occ[b]) r |= masks[((long)b * H + y) * W + x];
+      if (occ[b]) r |= masks[((long)(slot ? slot[b] : b) * H + y) * W + x];
   }
   out[p] = r;
 }
@@ -356,12 +429,12 @@ extern "C" int csam_select_masks(void* stream, const float* iou, const float* cl
 // two-stage path otherwise (trap 9: 1023-sided frames).  tmp_f32 [B,in_h,in_w] is only needed when
 // (out_h,out_w) != (in_h,in_w).  do_stats: counts + bbox (csam_mask_post); out_mask may be NULL (statistics
 // only: the bytes of the prompts that survive the filters are produced later by csam_mask_write).
-static int post_launch(hipStream_t s, const float* lowres, const int* sel, const uint8_t* keep, int B, int in_h,
-                       int in_w, int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
-                       int* box, float* tmp_f32, int do_stats) {
+static int post_launch(hipStream_t s, const float* lowres, const int* sel, const uint8_t* keep, const int* slot,
+                       int B, int in_h, int in_w, int out_h, int out_w, float thr, float off, void* out_mask_u8,
+                       int* inter, int* uni, int* box, float* tmp_f32, int do_stats) {
   PostArgs a;
   a.thr = thr; a.off = off;
-  a.inter = inter; a.uni = uni; a.box = box; a.keep = keep; a.stats = do_stats;
+  a.inter = inter; a.uni = uni; a.box = box; a.keep = keep; a.slot = slot; a.stats = do_stats;
   if (in_h == out_h && in_w == out_w) {
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
@@ -396,8 +469,8 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
                "csam_mask_post: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
-  const int rc = post_launch(s, lowres, sel, nullptr, B, in_h, in_w, out_h, out_w, thr, off, out_mask_u8, inter, uni,
-                             box, tmp_f32, 1);
+  const int rc = post_launch(s, lowres, sel, nullptr, nullptr, B, in_h, in_w, out_h, out_w, thr, off, out_mask_u8,
+                             inter, uni, box, tmp_f32, 1);
   if (rc) return rc;
   CSAM_LAUNCH_CHECK("csam_mask_post");
   return CSAM_OK;
@@ -405,14 +478,14 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
 
 // Second pass of the two-pass mode: mask bytes (x > thr) of the prompts with keep[b] != 0 only
 // (keep == NULL: all).  Rows of skipped prompts in out_mask are left untouched.
-extern "C" int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, int B,
-                               int in_h, int in_w, int out_h, int out_w, float thr, void* out_mask_u8,
-                               float* tmp_f32) {
+extern "C" int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8,
+                               const int* slot_or_null, int B, int in_h, int in_w, int out_h, int out_w, float thr,
+                               void* out_mask_u8, float* tmp_f32) {
   CSAM_REQUIRE(lowres && sel && out_mask_u8 && B > 0, "csam_mask_write: bad args");
   CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
                "csam_mask_write: bad sizes");
-  const int rc = post_launch((hipStream_t)stream, lowres, sel, (const uint8_t*)keep_u8, B, in_h, in_w, out_h, out_w,
-                             thr, 0.f, out_mask_u8, nullptr, nullptr, nullptr, tmp_f32, 0);
+  const int rc = post_launch((hipStream_t)stream, lowres, sel, (const uint8_t*)keep_u8, slot_or_null, B, in_h, in_w,
+                             out_h, out_w, thr, 0.f, out_mask_u8, nullptr, nullptr, nullptr, tmp_f32, 0);
   if (rc) return rc;
   CSAM_LAUNCH_CHECK("csam_mask_write");
   return CSAM_OK;
@@ -428,7 +501,7 @@ extern "C" int csam_bilinear_f32(void* stream, const float* src, int n, int sh, 
   a.sh = sh; a.sw = sw; a.scale_y = (float)sh / (float)H; a.scale_x = (float)sw / (float)W;
   a.H = H; a.W = W; a.thr = 0.f; a.off = 0.f;
   a.out_f32 = dst; a.out_mask = nullptr; a.inter = nullptr; a.uni = nullptr; a.box = nullptr;
-  a.keep = nullptr; a.stats = 0;
+  a.keep = nullptr; a.slot = nullptr; a.stats = 0;
   CSAM_REQUIRE(W <= 1024, "csam_bilinear_f32: W=%d > 1024", W);
   dim3 grid(csam_cdiv(H, POST_ROWS), 1, n);
   hipLaunchKernelGGL(mask_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -447,11 +520,30 @@ extern "C" int csam_post_finalize(void* stream, const float* score, const int* i
   return CSAM_OK;
 }
 
+// csam_post_finalize + in-kernel compaction into an image-level store (see the kernel comment).
+extern "C" int csam_post_finalize_compact(void* stream, const float* score, const int* inter, const int* uni,
+                                          const int* box, const int* category, const int* points_xy,
+                                          float pred_iou_thresh, float stability_thresh, float filter_thresh,
+                                          void* keep_u8, void* occ_u8, int* slot, int* counter, float* out_score,
+                                          float* out_stability, int* out_box, int* out_category, int* out_points,
+                                          int B, int capacity) {
+  CSAM_REQUIRE(score && inter && uni && box && category && points_xy && keep_u8 && occ_u8 && slot && counter &&
+                   out_score && out_stability && out_box && out_category && out_points && B > 0 && capacity > 0,
+               "csam_post_finalize_compact: bad args");
+  hipLaunchKernelGGL(post_finalize_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, inter, uni, box,
+                     category, points_xy, pred_iou_thresh, stability_thresh, filter_thresh, (uint8_t*)keep_u8,
+                     (uint8_t*)occ_u8, slot, counter, out_score, out_stability, out_box, out_category, out_points, B,
+                     capacity);
+  CSAM_LAUNCH_CHECK("csam_post_finalize_compact");
+  return CSAM_OK;
+}
+
 extern "C" int csam_occupancy_lookup(void* stream, const int* points_xy, int P, const void* masks_u8,
-                                     const void* occ_u8, int B, int H, int W, void* out_u8) {
+                                     const void* occ_u8, const int* slot_or_null, int B, int H, int W,
+                                     void* out_u8) {
   CSAM_REQUIRE(points_xy && masks_u8 && occ_u8 && out_u8 && P > 0 && B > 0, "csam_occupancy_lookup: bad args");
   hipLaunchKernelGGL(occupancy_kernel, dim3(csam_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, points_xy, P,
-                     (const uint8_t*)masks_u8, (const uint8_t*)occ_u8, B, H, W, (uint8_t*)out_u8);
+                     (const uint8_t*)masks_u8, (const uint8_t*)occ_u8, slot_or_null, B, H, W, (uint8_t*)out_u8);
   CSAM_LAUNCH_CHECK("csam_occupancy_lookup");
   return CSAM_OK;
 }

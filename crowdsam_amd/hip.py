@@ -48,8 +48,9 @@ SIGNATURES = {
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
-    "csam_mask_write": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
-    "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "csam_mask_write": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
+    "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -402,8 +403,18 @@ def post_finalize(score, inter, uni, box, pred_iou_thresh, stab_thresh, filter_t
          float(stab_thresh), float(filter_thresh), _ptr(stability), _ptr(keep), _ptr(occ), B)
 
 
-def occupancy_lookup(points, masks, occ, B, H, W, out):
-    call("csam_occupancy_lookup", _stream(), _ptr(points), points.shape[0], _ptr(masks), _ptr(occ), B, H, W, _ptr(out))
+def occupancy_lookup(points, masks, occ, B, H, W, out, slot=None):
+    call("csam_occupancy_lookup", _stream(), _ptr(points), points.shape[0], _ptr(masks), _ptr(occ), _ptr(slot), B, H, W,
+         _ptr(out))
+
+
+def post_finalize_compact(score, inter, uni, box, category, points, pred_iou_thresh, stab_thresh, filter_thresh, keep, occ,
+                          slot, counter, store, B):
+    """Filters + in-kernel compaction of the survivors into ``store`` (dict of image-level device arrays)."""
+    call("csam_post_finalize_compact", _stream(), _ptr(score), _ptr(inter), _ptr(uni), _ptr(box), _ptr(category),
+         _ptr(points), float(pred_iou_thresh), float(stab_thresh), float(filter_thresh), _ptr(keep), _ptr(occ),
+         _ptr(slot), _ptr(counter), _ptr(store["score"]), _ptr(store["stability"]), _ptr(store["boxes"]),
+         _ptr(store["category"]), _ptr(store["points"]), B, store["score"].shape[0])
 
 
 def box_nms(boxes, scores, thr):
@@ -486,7 +497,7 @@ def linear_f32_batched(a, lda, sa, w, ldw, sw, bias, sbias, out, ldc, sc, M, N, 
     return out
 
 
-def mask_write(lowres, sel, keep, B, in_hw, out_hw, thr, out_mask, tmp=None):
-    """Second pass: mask bytes of the prompts with keep[b] != 0 (rows of skipped prompts stay untouched)."""
-    call("csam_mask_write", _stream(), _ptr(lowres), _ptr(sel), _ptr(keep), B, in_hw[0], in_hw[1], out_hw[0], out_hw[1],
-         float(thr), _ptr(out_mask), _ptr(tmp))
+def mask_write(lowres, sel, keep, B, in_hw, out_hw, thr, out_mask, tmp=None, slot=None):
+    """Second pass: mask bytes of the prompts with keep[b] != 0, at out_mask[b] or out_mask[slot[b]]."""
+    call("csam_mask_write", _stream(), _ptr(lowres), _ptr(sel), _ptr(keep), _ptr(slot), B, in_hw[0], in_hw[1], out_hw[0],
+         out_hw[1], float(thr), _ptr(out_mask), _ptr(tmp))

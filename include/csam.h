@@ -154,8 +154,15 @@ int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int
                    float* tmp_f32);
 /* two-pass mode: csam_mask_post with out_mask_u8 == NULL gives the statistics only; after csam_post_finalize
  * the bytes of the surviving prompts (keep[b] != 0) are produced by csam_mask_write. */
-int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, int B, int in_h, int in_w,
-                    int out_h, int out_w, float thr, void* out_mask_u8, float* tmp_f32);
+int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, const int* slot_or_null,
+                    int B, int in_h, int in_w, int out_h, int out_w, float thr, void* out_mask_u8, float* tmp_f32);
+/* finalize + in-kernel compaction of the survivors into an image-level store (MaskData.cat of
+ * crowdsam/model.py:247 without host sync or gather copies): slot[b] = store index or -1 */
+int csam_post_finalize_compact(void* stream, const float* score, const int* inter, const int* uni, const int* box,
+                               const int* category, const int* points_xy, float pred_iou_thresh,
+                               float stability_thresh, float filter_thresh, void* keep_u8, void* occ_u8, int* slot,
+                               int* counter, float* out_score, float* out_stability, int* out_box, int* out_category,
+                               int* out_points, int B, int capacity);
 int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W);
 /* crowdsam/model.py:371-389,246: keep / occupancy flags, stability = inter/union, empty box -> 0 */
 int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
@@ -163,7 +170,7 @@ int csam_post_finalize(void* stream, const float* score, const int* inter, const
                        void* keep_u8, void* occ_u8, int B);
 /* crowdsam/model.py:238: occupancy bits of the remaining points (never the mask itself goes D2H) */
 int csam_occupancy_lookup(void* stream, const int* points_xy, int P, const void* masks_u8, const void* occ_u8,
-                          int B, int H, int W, void* out_u8);
+                          const int* slot_or_null, int B, int H, int W, void* out_u8);
 
 /* ---- NMS + RLE */
 long csam_box_nms_workspace_bytes(int N);

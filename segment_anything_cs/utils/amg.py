@@ -198,7 +198,9 @@ def remove_small_regions(mask, area_thresh, mode):
         fill = np.setdiff1d(np.arange(1, n + 1), small)
         if fill.size == 0:
             fill = np.array([int(np.argmax(sizes)) + 1])
-    return np.isin(labels, fill), True
+    lut = np.zeros(n + 1, dtype=bool)        # label -> keep (a table lookup; np.isin is slow for many labels)
+    lut[fill] = True
+    return lut[labels], True
 
 
 def coco_rle_string(counts):
