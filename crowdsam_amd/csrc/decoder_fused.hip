@@ -366,8 +366,15 @@ struct UpArgs {
   const float* b2;          // [128]
   const float* hyper;       // [B,4,32]
   float* masks;             // [B,4,256,256]
+  float* stats;             // optional [B*4][2]: running max of every mask plane (float atomic max), else NULL
   int dbg;                  // developer ablation bits (CSAM_DBG env): 1 = skip phases 2-4, 2 = skip GEMM1
 };
+
+// order-preserving float atomic max (sign-split integer trick); *addr must start at -inf
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
 
 __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
   const half8_t hhi = *(const half8_t*)(smem + UP_HFR + lane * 16);
   const half8_t hlo = *(const half8_t*)(smem + UP_HFR + 1024 + lane * 16);
   float* outs = (float*)(smem);                     // [2 r][4 l][4 yy][256 X] fp32 = 32 KB (aliases XS/WS)
+  floatx4 mmax = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   if (p.dbg & 1) {
     outs[tid] = a1[0][0][0] + a1[1][1][1] + a1[2][2][2] + a1[3][3][3];
   } else
@@ -534,11 +542,29 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
         const int yy = (pos >> 1) * 2 + (pos2 >> 1);
         const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
 #pragma unroll
-        for (int l = 0; l < 4; ++l) outs[((r * 4 + l) * 4 + yy) * 256 + X] = m4[l];
+        for (int l = 0; l < 4; ++l) {
+          outs[((r * 4 + l) * 4 + yy) * 256 + X] = m4[l];
+          mmax[l] = fmaxf(mmax[l], m4[l]);
+        }
       }
     }
   }
+  float* wmx = (float*)(smem + UP_W2S);   // [8 waves][4] (W2' is dead after the last GEMM2 of every wave... barrier below)
   __syncthreads();
+  if (p.stats) {   // per-plane running max for the PWD-Net softmax (saves a full pass over the logits later)
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const float m = csam_wave_max(mmax[l]);
+      if (lane == 0) wmx[wave * 4 + l] = m;
+    }
+  }
+  __syncthreads();
+  if (p.stats && tid < 4) {
+    float m = wmx[tid];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w * 4 + tid]);
+    atomic_max_float(p.stats + ((long)b * 4 + tid) * 2, m);   // one atomic per (workgroup, plane)
+  }
   // ---- coalesced store of the 2 x 4 x 4 output rows (256 fp32 each)
   {
     const int i0 = blockIdx.x * 2;
@@ -556,14 +582,26 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
 
 }  // namespace
 
+__global__ void stats_init_kernel(float* stats, int rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows) {
+    stats[i * 2] = -INFINITY;
+    stats[i * 2 + 1] = 0.f;
+  }
+}
+
 extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                                   const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
-                                  const float* b2, const float* hyper, float* masks, int B) {
+                                  const float* b2, const float* hyper, float* masks, float* stats_or_null, int B) {
   CSAM_REQUIRE(keys_f16 && W1_f16 && b1 && ln_gamma && ln_beta && W2_perm_f16 && b2 && hyper && masks && B > 0,
                "csam_upscale_fused: bad args");
   UpArgs a;
   a.X = (const half_t*)keys_f16; a.W1 = (const half_t*)W1_f16; a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta;
   a.eps = eps; a.W2 = (const half_t*)W2_perm_f16; a.b2 = b2; a.hyper = hyper; a.masks = masks;
+  a.stats = stats_or_null;
+  if (stats_or_null)
+    hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null,
+                       B * 4);
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("CSAM_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;

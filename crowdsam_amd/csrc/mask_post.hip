@@ -203,11 +203,26 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
     v[k][1] = p[r * 256 + c1];
     v[k][2] = p[r * 256 + c2];
   }
-  int x0[4], x1[4];
-  float lx[4];
+  // horizontal interpolation once per (source row, output column): hl[k][e] = w0x*v0 + lx*v1 -- exactly the
+  // inner expression of bilerp(), so the vertical step below reproduces the generic kernel bit for bit
+  float hl[6][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) src_index(0.25f, x4 + e, 256, x0[e], x1[e], lx[e]);
+  for (int e = 0; e < 4; ++e) {
+    int x0, x1;
+    float lx;
+    src_index(0.25f, x4 + e, 256, x0, x1, lx);
+    const float w0x = 1.f - lx;
+    const int i0 = (x0 == c1) ? 1 : (x0 == c0 ? 0 : 2);
+    const int i1 = (x1 == c1) ? 1 : (x1 == c0 ? 0 : 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float t0 = i0 == 1 ? v[k][1] : (i0 == 0 ? v[k][0] : v[k][2]);
+      const float t1 = i1 == 1 ? v[k][1] : (i1 == 0 ? v[k][0] : v[k][2]);
+      hl[k][e] = w0x * t0 + lx * t1;
+    }
+  }
   if (x4 < a.W) {
+    const float hi_t = a.thr + a.off, lo_t = a.thr - a.off;
 #pragma unroll
     for (int yy = 0; yy < 16; ++yy) {
       const int y = i * 16 + yy;
@@ -217,27 +232,20 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
       src_index(0.25f, y, 256, y0, y1, ly);
       // static row slots: y0 = 4i + o, o = floor(0.25*yy - 0.375) in {-1,0,1,2,3}; y1 is the next slot
       // (clamping only ever selects a row whose weight is exactly 0, or the same clamped row)
-      constexpr int dummy = 0;
-      (void)dummy;
       const int k0 = (yy < 2) ? 0 : (yy < 6) ? 1 : (yy < 10) ? 2 : (yy < 14) ? 3 : 4;
-      const float* top = v[k0];
-      const float* bot = (y1 == y0) ? v[k0] : v[k0 + 1];
+      const bool same = (y1 == y0);
+      const float w0y = 1.f - ly;
       uint32_t packed = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int x = x4 + e;
         if (x < a.W) {
-          const float t0 = (x0[e] == c1) ? top[1] : (x0[e] == c0 ? top[0] : top[2]);
-          const float t1 = (x1[e] == c1) ? top[1] : (x1[e] == c0 ? top[0] : top[2]);
-          const float b0 = (x0[e] == c1) ? bot[1] : (x0[e] == c0 ? bot[0] : bot[2]);
-          const float b1 = (x1[e] == c1) ? bot[1] : (x1[e] == c0 ? bot[0] : bot[2]);
-          const float w0x = 1.f - lx[e], w0y = 1.f - ly;
-          const float tt = w0x * t0 + lx[e] * t1;
-          const float bb = w0x * b0 + lx[e] * b1;
+          const float tt = hl[k0][e];
+          const float bb = same ? hl[k0][e] : hl[k0 + 1][e];
           const float val = w0y * tt + ly * bb;
           if (PASS == 0) {
-            cnt_i += val > (a.thr + a.off);
-            cnt_u += val > (a.thr - a.off);
+            cnt_i += val > hi_t;
+            cnt_u += val > lo_t;
           }
           if (val > a.thr) {
             packed |= 1u << (8 * e);

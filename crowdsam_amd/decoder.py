@@ -347,7 +347,7 @@ class DecoderPlan:
         masks = ws["masks"][:B]
         if self.fused:
             hip.upscale_fused(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,
-                              self.up2_b, ws["hyper"], masks, B)
+                              self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
         else:
             hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
         # ---- IoU head (:184) + parallel residual head (:194-198)
@@ -365,8 +365,11 @@ class DecoderPlan:
                              residual=iou0.view(B * 4, 1))
         # ---- PWD-Net pooling + classifier (:186-192)
         R = B * 4
-        hip.softmax_stats(masks, ws["stats"], R)
-        hip.pool_adjoint(masks, ws["stats"], self.taps, ws["wadj"], R)
+        if self.fused:      # plane max already in stats[:,0] (upscale kernel atomics); one pass over the logits
+            hip.pool_adjoint_v2(masks, ws["stats"], self.taps, ws["wadj"], R)
+        else:
+            hip.softmax_stats(masks, ws["stats"], R)
+            hip.pool_adjoint(masks, ws["stats"], self.taps, ws["wadj"], R)
         hip.gemm_f16(ws["wadj"][:R], st["GT"], out=ws["pooled_raw"][:R])
         hip.rowscale_bias(ws["pooled_raw"], ws["stats"], self.dino_proj_b, ws["pooled"], R, 256)
         (w1, b1), (w2, b2) = self.classifier

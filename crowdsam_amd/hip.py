@@ -56,7 +56,8 @@ SIGNATURES = {
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
-    "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I],
+    "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
+    "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
     "csam_t2i_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L],
     "csam_t2i_merge_launch": [_P, _P, _P, _I, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
@@ -477,11 +478,16 @@ def i2t_fused(X, x_bstride, k, v, Wo_perm, bo, gamma, beta, eps, out, B, T, Q=No
     return out
 
 
-def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B):
-    """Fused ConvT -> LN2d -> GELU -> ConvT -> GELU -> hyper product: keys f16 [B*4096,256] -> masks f32 [B,4,256,256]."""
+def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B, stats=None):
+    """Fused ConvT -> LN2d -> GELU -> ConvT -> GELU -> hyper product: keys f16 [B*4096,256] -> masks f32 [B,4,256,256].
+    ``stats`` f32 [B*4,2]: column 0 receives the per-plane max of the logits (for the PWD-Net softmax)."""
     call("csam_upscale_fused", _stream(), _ptr(keys), _ptr(W1), _ptr(b1), _ptr(ln_g), _ptr(ln_b), float(eps),
-         _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), B)
+         _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), _ptr(stats), B)
     return masks
+
+
+def pool_adjoint_v2(masks, stats, taps, w, rows):
+    call("csam_pool_adjoint_v2", _stream(), _ptr(masks), _ptr(stats), _ptr(taps), _ptr(w), w.stride(0), rows)
 
 
 def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None, V0T=None):

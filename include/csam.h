@@ -122,6 +122,9 @@ int csam_softmax_stats(void* stream, const float* masks, float* stats, int rows)
 int csam_adj_taps_bytes(void);
 int csam_pool_adjoint(void* stream, const float* masks, const float* stats, const void* taps_dev, void* w_f16,
                       long ldw, int rows);
+/* one-pass variant: stats[r][0] = plane max (from csam_upscale_fused), writes stats[r][1] = sum exp */
+int csam_pool_adjoint_v2(void* stream, const float* masks, float* stats, const void* taps_dev, void* w_f16, long ldw,
+                         int rows);
 int csam_rowscale_bias(void* stream, const float* P, const float* stats, const float* bias, float* out, int rows,
                        int N);
 
@@ -135,7 +138,7 @@ int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const 
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
-                       const float* b2, const float* hyper, float* masks, int B);
+                       const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
 /* token->image attention with the K/V projections fused in (transformer.py:173-177,105-112) */
 long csam_t2i_fused_workspace_bytes(int B);
 int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
