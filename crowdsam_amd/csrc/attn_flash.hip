@@ -68,10 +68,11 @@ template <bool BIAS>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
                                                          int q_off, int k_off,
                                                          const half_t* __restrict__ vt, int Tpad,
-                                                         const float* __restrict__ th,
-                                                         const float* __restrict__ tw,
+                                                         const float* __restrict__ traw,
                                                          half_t* __restrict__ out, long ldo, int T,
                                                          float scale) {
+  // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
+  // batched GEMM;  Th[q][kh] = traw[q][qh - kh + 63],  Tw[q][kw] = traw[q][128 + qw - kw + 63]
   // LDS: 2 stages x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 32 KB, filled by global_load_lds
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -97,14 +98,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
   const int krow_in_step = 8 * (fr >> 2) + (fr & 3);
   floatx4 twr[2][4];
   const float* thp[2] = {nullptr, nullptr};
+  const float inv_scale = 1.0f / scale;
   if constexpr (BIAS) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int qc = qrow[rt] < T ? qrow[rt] : T - 1;
-      const float* twq = tw + ((long)head * T + qc) * 64;
-      thp[rt] = th + ((long)head * T + qc) * 64;
+      const float* tq = traw + ((long)head * T + qc) * 256;
+      thp[rt] = tq + (qc >> 6) + 63;                 // Th[q][t] = thp[-t]
+      const float* twq = tq + 128 + (qc & 63) + 63;  // Tw[q][kw] = twq[-kw]
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) twr[rt][kt] = *(const floatx4*)(twq + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1));
+      for (int kt = 0; kt < 4; ++kt) {
+        const int kw0 = (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) twr[rt][kt][j] = twq[-(kw0 + j)] * inv_scale;
+      }
     }
   }
   floatx4 o[2][4];
@@ -144,8 +151,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
     floatx4 s[2][4];
     float thv[2] = {0.f, 0.f};
     if constexpr (BIAS) {
-      thv[0] = thp[0][t];
-      thv[1] = thp[1][t];
+      thv[0] = thp[0][-t] * inv_scale;
+      thv[1] = thp[1][-t] * inv_scale;
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -242,43 +249,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
   }
 }
 
-// Th[h][q][kh] = (q . rel_pos_h[qh - kh + G-1]) / scale ; Tw likewise with (qw, kw).   G == 64.
-// image_encoder.py:292-322 (get_rel_pos, table length == 2G-1 so no interpolation), :349-350.
-__global__ __launch_bounds__(256) void relpos_tables_kernel(const half_t* __restrict__ qkv, long ld,
-                                                            const float* __restrict__ rel_h,
-                                                            const float* __restrict__ rel_w,
-                                                            float* __restrict__ th, float* __restrict__ tw,
-                                                            int nH, float inv_scale) {
-  // block = (query q, head h) pair x 128 outputs (64 kh + 64 kw); 2 pairs per 256-thread block
-  const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
-  const int j = threadIdx.x & 127;
-  const int q = pair / nH, h = pair % nH;
-  if (q >= 4096) return;
-  const int qh = q >> 6, qw = q & 63;
-  const half_t* qv = qkv + (long)q * ld + h * 64;
-  const float* R = (j < 64) ? rel_h + (qh - j + 63) * 64 : rel_w + (qw - (j - 64) + 63) * 64;
-  float acc = 0.f;
-#pragma unroll
-  for (int c8 = 0; c8 < 8; ++c8) {
-    const half8_t qq = *(const half8_t*)(qv + c8 * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc += (float)qq[e] * R[c8 * 8 + e];
-  }
-  acc *= inv_scale;
-  float* dst = (j < 64) ? th + ((long)h * 4096 + q) * 64 + j : tw + ((long)h * 4096 + q) * 64 + (j - 64);
-  *dst = acc;
-}
-
 }  // namespace
-
-extern "C" int csam_relpos_tables(void* stream, const void* qkv_f16, long ld, const float* rel_pos_h,
-                                  const float* rel_pos_w, float* th, float* tw, int nH, float scale) {
-  CSAM_REQUIRE(qkv_f16 && rel_pos_h && rel_pos_w && th && tw && nH > 0, "csam_relpos_tables: bad args");
-  hipLaunchKernelGGL(relpos_tables_kernel, dim3(4096 * nH / 2), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)qkv_f16, ld, rel_pos_h, rel_pos_w, th, tw, nH, 1.0f / scale);
-  CSAM_LAUNCH_CHECK("csam_relpos_tables");
-  return CSAM_OK;
-}
 
 extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
   const long Tpad = (long)((T + 63) / 64) * 64;
@@ -286,8 +257,8 @@ extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
 }
 
 extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
-                               const float* th, const float* tw, void* out_f16, long ldo, int T, int nH,
-                               float scale, void* vt_workspace, long vt_workspace_bytes) {
+                               const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
+                               void* vt_workspace, long vt_workspace_bytes) {
   CSAM_REQUIRE(qkv_f16 && out_f16 && vt_workspace && T > 0 && nH > 0, "csam_flash_attn: bad args");
   if (vt_workspace_bytes < csam_flash_attn_workspace_bytes(T, nH)) {
     csam_set_error("csam_flash_attn: V^T workspace too small (must also be zero-initialised once)");
@@ -296,17 +267,16 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   const int Tpad = ((T + 63) / 64) * 64;
   CSAM_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0,
                "csam_flash_attn: alignment");
-  CSAM_REQUIRE((th == nullptr) == (tw == nullptr), "csam_flash_attn: th/tw must come together");
-  CSAM_REQUIRE(!th || T == 4096, "csam_flash_attn: rel-pos bias needs the 64x64 token grid");
+  CSAM_REQUIRE(!relpos_raw || T == 4096, "csam_flash_attn: rel-pos bias needs the 64x64 token grid");
   hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)qkv_f16, ld, v_off, (half_t*)vt_workspace, T, Tpad);
   dim3 grid(csam_cdiv(T, QPB), nH), block(256);
-  if (th)
+  if (relpos_raw)
     hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, th, tw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale);
   else
     hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, th, tw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
   return CSAM_OK;
 }

@@ -33,8 +33,7 @@ constexpr int SMEM_BYTES = QE_BYTES + KE_BYTES + VT_BYTES;
 
 __global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict__ qkv,
                                                        const float* __restrict__ qkv_bias,
-                                                       const float* __restrict__ rel_h,
-                                                       const float* __restrict__ rel_w,
+                                                       const half_t* __restrict__ relcat,
                                                        half_t* __restrict__ out, int D, int nH,
                                                        float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,27 +75,53 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict_
 
   // ---- rel-pos extension columns of Qe: [64..77] Th hi, [78..91] Tw hi, [92..105] Th lo,
   //      [106..119] Tw lo, [120..127] zero.  Values are T/scale so that S = scale * acc.
+  // T[q][j] = q . relcat[j] (rows 0..26 rel_pos_h, 27..53 rel_pos_w, fp16 like every other weight) is one
+  // small MFMA product per query tile: D[j][q] = relcat[j][:] . q[:], and each lane scatters its 16 values
+  // to the (kh | kw) slot they belong to:  kh = qh + 13 - j,  kw = qw + 13 - (j - 27).
+  const int fr = lane & 15, fg = lane >> 4;
   const float inv_scale = 1.0f / scale;
-  for (int it = tid; it < NPAD * 28; it += 256) {
-    const int i = it / 28, j = it % 28;
-    float t = 0.f;
-    if (i < NTOK) {
-      const int qh = i / WS, qw = i % WS;
-      const float* R = (j < WS) ? rel_h + (qh - j + WS - 1) * 64 : rel_w + (qw - (j - WS) + WS - 1) * 64;
-      const half_t* q = Qe + i * QE_LD;
-#pragma unroll 8
-      for (int c = 0; c < 64; ++c) t += (float)q[c] * R[c];
-      t *= inv_scale;
-    }
-    const half_t hi = (half_t)t;
-    const half_t lo = (half_t)(t - (float)hi);
-    Qe[i * QE_LD + 64 + j] = hi;
-    Qe[i * QE_LD + 92 + j] = lo;
+  for (int it = tid; it < NPAD * 8; it += 256) {           // zero all extension columns first
+    *(half8_t*)(Qe + (it >> 3) * QE_LD + 64 + (it & 7) * 8) = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
   }
-  for (int it = tid; it < NPAD * 8; it += 256) Qe[(it >> 3) * QE_LD + 120 + (it & 7)] = (half_t)0.f;
+  __syncthreads();
+  for (int rt = wave; rt < 13; rt += 4) {
+    half8_t qf0[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf0[ks] = *(const half8_t*)(Qe + (rt * 16 + fr) * QE_LD + (ks * 4 + fg) * 8);
+    const int qi = rt * 16 + fr;
+    const int qh = qi / WS, qw = qi % WS;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      floatx4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8_t rf = *(const half8_t*)(relcat + (nt * 16 + fr) * 64 + (ks * 4 + fg) * 8);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf, qf0[ks], t, 0, 0, 0);
+      }
+      if (qi < NTOK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nt * 16 + fg * 4 + r;
+          int col = -1;
+          if (j < 27) {
+            const int kh = qh + 13 - j;
+            if (kh >= 0 && kh < WS) col = kh;
+          } else if (j < 54) {
+            const int kw = qw + 13 - (j - 27);
+            if (kw >= 0 && kw < WS) col = WS + kw;
+          }
+          if (col >= 0) {
+            const float tv = t[r] * inv_scale;
+            const half_t hi = (half_t)tv;
+            Qe[qi * QE_LD + 64 + col] = hi;
+            Qe[qi * QE_LD + 92 + col] = (half_t)(tv - (float)hi);
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
 
-  const int fr = lane & 15, fg = lane >> 4;
   const float sl2 = scale * 1.4426950408889634f;  // work in base 2
 
   for (int rt = wave; rt < 13; rt += 4) {
@@ -192,9 +217,8 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict_
 }  // namespace
 
 extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias,
-                             const float* rel_pos_h, const float* rel_pos_w, void* out_f16, int D,
-                             int nH, float scale) {
-  CSAM_REQUIRE(qkv_f16 && qkv_bias && rel_pos_h && rel_pos_w && out_f16, "csam_win_attn: null pointer");
+                             const void* relcat_f16, void* out_f16, int D, int nH, float scale) {
+  CSAM_REQUIRE(qkv_f16 && qkv_bias && relcat_f16 && out_f16, "csam_win_attn: null pointer");
   CSAM_REQUIRE(nH > 0 && D == nH * 64, "csam_win_attn: head_dim must be 64 (D=%d nH=%d)", D, nH);
   static bool attr_set = false;
   if (!attr_set) {
@@ -202,7 +226,7 @@ extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv
     attr_set = true;
   }
   hipLaunchKernelGGL(win_attn_kernel, dim3(25 * nH), dim3(256), SMEM_BYTES, (hipStream_t)stream,
-                     (const half_t*)qkv_f16, qkv_bias, rel_pos_h, rel_pos_w, (half_t*)out_f16, D, nH, scale);
+                     (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
   CSAM_LAUNCH_CHECK("csam_win_attn");
   return CSAM_OK;
 }

@@ -37,6 +37,8 @@ class EncoderPlan:
                 lin1_w=f16(sd[B + "mlp.lin1.weight"]), lin1_b=f32(sd[B + "mlp.lin1.bias"]),
                 lin2_w=f16(sd[B + "mlp.lin2.weight"]), lin2_b=f32(sd[B + "mlp.lin2.bias"]),
                 is_global=i in self.global_idx))
+            bl = self.blocks[-1]
+            bl["relcat"] = (hip.relcat_global if bl["is_global"] else hip.relcat_window)(bl["rel_h"], bl["rel_w"])
             L = 127 if i in self.global_idx else 27
             assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, 64), "rel-pos table must be (2S-1, 64) at 1024^2"
         self.neck0_w = f16(sd[P + "neck.0.weight"].reshape(256, D))
@@ -47,8 +49,8 @@ class EncoderPlan:
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
         self.ws = dict(
             col=e(4096, 768), x=e(4096, D, dt=torch.float32), h=e(4096, D), qkv=e(4096, 3 * D),
-            attn=e(4096, D), mlp=e(4096, 4 * D), th=e(heads, 4096, 64, dt=torch.float32),
-            tw=e(heads, 4096, 64, dt=torch.float32), n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
+            attn=e(4096, D), mlp=e(4096, 4 * D), traw=e(heads, 4096, 256, dt=torch.float32),
+            n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
             col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32),
             img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32))
         self.graphs = hip.GraphCache()
@@ -74,10 +76,10 @@ class EncoderPlan:
             hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
             hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
             if b["is_global"]:
-                hip.relpos_tables(ws["qkv"], b["rel_h"], b["rel_w"], ws["th"], ws["tw"], nH, scale)
-                hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, th=ws["th"], tw=ws["tw"])
+                hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)
+                hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"])
             else:
-                hip.win_attn(ws["qkv"], b["qkv_b"], b["rel_h"], b["rel_w"], ws["attn"], D, nH, scale)
+                hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
             hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)
             hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"])
             hip.gemm_f16(ws["h"], b["lin1_w"], out=ws["mlp"], bias=b["lin1_b"], act=hip.ACT_GELU)

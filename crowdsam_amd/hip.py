@@ -28,9 +28,8 @@ SIGNATURES = {
     "csam_dino_im2col": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_im2col3x3": [_P, _P, _P, _I],
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
-    "csam_win_attn": [_P, _P, _P, _P, _P, _P, _I, _I, _F],
-    "csam_relpos_tables": [_P, _P, _L, _P, _P, _P, _P, _I, _F],
-    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _I, _I, _F, _P, _L],
+    "csam_win_attn": [_P, _P, _P, _P, _P, _I, _I, _F],
+    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
     "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
@@ -274,15 +273,31 @@ def add_cast(a, b=None, b_row_stride=0, out16=None, out32=None):
     call("csam_add_cast", _stream(), _ptr(a), _ptr(b), b_row_stride, _ptr(out16), _ptr(out32), M, N)
 
 
-def win_attn(qkv, qkv_bias, rel_h, rel_w, out, D, nH, scale):
-    call("csam_win_attn", _stream(), _ptr(qkv), _ptr(qkv_bias), _ptr(rel_h), _ptr(rel_w), _ptr(out), D, nH,
-         float(scale))
+def relcat_window(rel_h, rel_w):
+    """[64,64] fp16 operand of the windowed kernel: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero."""
+    r = torch.zeros(64, 64, dtype=torch.float16, device=rel_h.device)
+    r[:27] = rel_h.half()
+    r[27:54] = rel_w.half()
+    return r
+
+
+def relcat_global(rel_h, rel_w):
+    """[256,64] fp16 GEMM operand of the global blocks: rows 0..126 rel_pos_h, 128..254 rel_pos_w."""
+    r = torch.zeros(256, 64, dtype=torch.float16, device=rel_h.device)
+    r[:127] = rel_h.half()
+    r[128:255] = rel_w.half()
+    return r
+
+
+def win_attn(qkv, qkv_bias, relcat, out, D, nH, scale):
+    call("csam_win_attn", _stream(), _ptr(qkv), _ptr(qkv_bias), _ptr(relcat), _ptr(out), D, nH, float(scale))
     return out
 
 
-def relpos_tables(qkv, rel_h, rel_w, th, tw, nH, scale):
-    call("csam_relpos_tables", _stream(), _ptr(qkv), qkv.stride(0), _ptr(rel_h), _ptr(rel_w), _ptr(th), _ptr(tw),
-         nH, float(scale))
+def relpos_raw(qkv, relcat_g, out, nH):
+    """out f32 [nH,4096,256] = q_h @ relcat_g^T for every head (one batched MFMA GEMM, K = 64)."""
+    gemm_f16_batched(qkv, qkv.stride(0), 64, relcat_g, 64, 0, out, 256, 4096 * 256, 4096, 256, 64, nH)
+    return out
 
 
 _vt_ws = {}
@@ -297,11 +312,11 @@ def flash_vt_workspace(T, nH, device):
     return _vt_ws[key]
 
 
-def flash_attn(qkv, out, T, nH, scale, D, th=None, tw=None, vt=None):
-    """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]."""
+def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None):
+    """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]; relpos = relpos_raw(...) or None."""
     if vt is None:
         vt = flash_vt_workspace(T, nH, qkv.device)
-    call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(th), _ptr(tw), _ptr(out),
+    call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out),
          out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2)
     return out
 

@@ -88,16 +88,15 @@ int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out); /*
 /* 14x14 windowed attention + decomposed rel-pos; window partition/unpartition folded into the
  * addressing; pad tokens are REAL keys whose q/k/v equal the qkv bias (image_encoder.py:224-289,
  * 325-361; SURVEY.md trap 4). qkv f16 [4096,3D] laid out [3][nH][64]; out f16 [4096,D]. */
-int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const float* rel_pos_h,
-                  const float* rel_pos_w, void* out_f16, int D, int nH, float scale);
-/* Th/Tw tables of the 4 global blocks: T[h][q][k] = (q . rel_pos[q-k+63]) / scale (image_encoder.py:349-350) */
-int csam_relpos_tables(void* stream, const void* qkv_f16, long ld, const float* rel_pos_h, const float* rel_pos_w,
-                       float* th, float* tw, int nH, float scale);
-/* flash-style global attention, head_dim 64: SAM global blocks (th/tw != NULL, T == 4096) and every
- * DINOv2 block (th == tw == NULL, ragged T). */
+/* relcat_f16 [64,64]: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero (fp16 like the other weights) */
+int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const void* relcat_f16, void* out_f16,
+                  int D, int nH, float scale);
+/* flash-style global attention, head_dim 64: every DINOv2 block (relpos_raw == NULL, ragged T) and SAM's
+ * global blocks: relpos_raw fp32 [nH][4096][256] = q . [rel_pos_h(127) | 0 | rel_pos_w(127) | 0]^T, produced by
+ * one csam_gemm_f16_batched over the heads (image_encoder.py:349-350). */
 long csam_flash_attn_workspace_bytes(int T, int nH); /* per-head V^T scratch; zero-initialise it once */
-int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off, const float* th,
-                    const float* tw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
+int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                    const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
                     long vt_workspace_bytes);
 
 /* ---- prompt encoder + two-way decoder (all prompts of a batch at once) */

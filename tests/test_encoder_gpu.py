@@ -47,7 +47,8 @@ def test_win_attn(cuda):
     rel_h = (torch.randn(27, 64, generator=g) * 0.25).to(cuda)
     rel_w = (torch.randn(27, 64, generator=g) * 0.25).to(cuda)
     out = torch.zeros(4096, D, device=cuda, dtype=torch.float16)
-    hip.win_attn(qkv, bias, rel_h, rel_w, out, D, nH, 0.125)
+    hip.win_attn(qkv, bias, hip.relcat_window(rel_h, rel_w), out, D, nH, 0.125)
+    rel_h, rel_w = rel_h.half().float(), rel_w.half().float()      # the kernel holds the tables in fp16
     # reference: pad with the bias (== qkv of a zero token), partition, attend, unpartition
     grid = bias.half().float().expand(70, 70, 3 * D).clone()
     grid[:64, :64] = qkv.float().view(64, 64, 3 * D)
@@ -76,11 +77,10 @@ def test_flash_attn(cuda, T, bias):
     if bias:
         rel_h = (torch.randn(127, 64, generator=g) * 0.25).to(cuda)
         rel_w = (torch.randn(127, 64, generator=g) * 0.25).to(cuda)
-        th = torch.empty(nH, 4096, 64, device=cuda)
-        tw = torch.empty(nH, 4096, 64, device=cuda)
-        hip.relpos_tables(qkv, rel_h, rel_w, th, tw, nH, 0.125)
-        hip.flash_attn(qkv, out, T, nH, 0.125, D, th=th, tw=tw)
-        s = s + _rel_bias(q, rel_h, rel_w, 64)
+        traw = torch.empty(nH, 4096, 256, device=cuda)
+        hip.relpos_raw(qkv, hip.relcat_global(rel_h, rel_w), traw, nH)
+        hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=traw)
+        s = s + _rel_bias(q, rel_h.half().float(), rel_w.half().float(), 64)
     else:
         hip.flash_attn(qkv, out, T, nH, 0.125, D)
     ref = (s.softmax(-1) @ v).transpose(0, 1).reshape(T, D)
