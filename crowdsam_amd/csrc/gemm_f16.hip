@@ -45,7 +45,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
+// MI = M tiles of 16 rows per wave: 4 -> 128-row workgroup tile, 2 -> 64-row tile (twice the workgroups:
+// used when the 128-row grid would leave CUs idle, e.g. N = 1024 projections at M = 4096)
+template <int MI>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
+  constexpr int TBM = MI * 32;   // rows of the workgroup tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   p.A += (long)blockIdx.z * p.sA;
   p.W += (long)blockIdx.z * p.sW;
@@ -57,47 +61,49 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int bn0 = blockIdx.x * BN;
-  const int bm0 = blockIdx.y * BM;
+  const int bm0 = blockIdx.y * TBM;
 
   // ---- staging addresses: wave w, instr i covers tile rows (w*4+i)*8 .. +7
   const int srow = lane >> 3;            // row within the 8-row group
   const int sslot = lane & 7;            // 16-B slot in the 128-B LDS row
-  const half_t* a_src[4];
+  const half_t* a_src[MI];
   const half_t* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + srow;
     const int chunk = sslot ^ (row & 7);
+    w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = (wave * MI + i) * 8 + srow;
+    const int chunk = sslot ^ (row & 7);
     int gm = bm0 + row;
     gm = gm < p.M ? gm : p.M - 1;        // clamp: rows past M are loaded but never stored
     a_src[i] = p.A + (long)gm * p.lda + chunk * 8;
-    w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
     char* abase = smem + buf * 2 * TILE_BYTES;
     char* wbase = abase + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int grp = (wave * 4 + i) * 1024;   // wave-uniform LDS base of this 1-KiB piece
-      glds16(a_src[i] + k0, abase + grp);
-      glds16(w_src[i] + k0, wbase + grp);
-    }
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + k0, wbase + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) glds16(a_src[i] + k0, abase + (wave * MI + i) * 1024);
   };
 
-  floatx4 acc[4][4];
+  floatx4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragment read offsets (bytes within a tile), swizzled
   const int fr = lane & 15, fg = lane >> 4;
-  int a_off[4], w_off[4];
+  int a_off[MI], w_off[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_off[i] = (wm * 64 + i * 16 + fr) * 128;
-    w_off[i] = (wn * 64 + i * 16 + fr) * 128;
-  }
+  for (int i = 0; i < 4; ++i) w_off[i] = (wn * 64 + i * 16 + fr) * 128;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_off[i] = (wm * MI * 16 + i * 16 + fr) * 128;
   const int sw = fr & 7;  // row&7 (tile-row offsets are multiples of 16)
 
   const int nk = p.K / BK;
@@ -113,14 +119,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((kk * 4 + fg) ^ sw) << 4;
-      half8_t af[4], wf[4];
+      half8_t af[MI], wf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const half8_t*)(abase + a_off[i] + coff);
-        wf[i] = *(const half8_t*)(wbase + w_off[i] + coff);
-      }
+      for (int i = 0; i < 4; ++i) wf[i] = *(const half8_t*)(wbase + w_off[i] + coff);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(abase + a_off[i] + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   // as whole coalesced rows, 16 B per lane.
   const bool res_late = p.R && p.c_dt == CSAM_DT_F32 && p.r_dt == CSAM_DT_F32;   // residual added at copy-out
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = wm * 64 + mi * 16 + fr;          // row inside the 128-row tile
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * MI * 16 + mi * 16 + fr;     // row inside the workgroup tile
     const int m = bm0 + row;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   __syncthreads();
   if (p.c_dt == CSAM_DT_F32) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int c = tid + it * 256;                    // 4096 16-B pieces: row c>>5, LDS slot c&31
+    for (int it = 0; it < 4 * MI; ++it) {
+      const int c = tid + it * 256;                    // TBM*32 16-B pieces: row c>>5, LDS slot c&31
       const int row = c >> 5, sl = c & 31;
       const int m = bm0 + row;
       if (m < p.M) {
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     }
   } else {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int c = tid + it * 256;                    // 2048 16-B pieces: row c>>4, LDS slot c&15
+    for (int it = 0; it < 2 * MI; ++it) {
+      const int c = tid + it * 256;                    // TBM*16 16-B pieces: row c>>4, LDS slot c&15
       const int row = c >> 4, sl = c & 15;
       const int m = bm0 + row;
       if (m < p.M) {
@@ -225,14 +230,20 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   p.act = act; p.M = M; p.N = N; p.K = K;
   p.sA = sA; p.sW = sW; p.sC = sC; p.sB = sB;
   CSAM_REQUIRE(batch >= 1 && (batch == 1 || !residual), "csam_gemm_f16: batched call takes no residual");
-  dim3 grid(N / BN, csam_cdiv(M, BM), batch);
+  // 64-row tiles when 128-row tiles would leave CUs without a workgroup (measured: pays at <= 256 tiles,
+  // loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU)
+  const bool small = (long)(N / BN) * csam_cdiv(M, BM) * batch <= 256;
+  dim3 grid(N / BN, csam_cdiv(M, small ? 64 : BM), batch);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        4 * TILE_BYTES);
+    hipFuncSetAttribute((const void*)gemm_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    hipFuncSetAttribute((const void*)gemm_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_f16_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
+  if (small)
+    hipLaunchKernelGGL(gemm_f16_kernel<2>, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_f16_kernel<4>, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
   CSAM_LAUNCH_CHECK("csam_gemm_f16");
   return CSAM_OK;
 }
