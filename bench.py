@@ -35,7 +35,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="vit_l")
     ap.add_argument("--grid", type=int, default=64)
-    ap.add_argument("--points-per-batch", type=int, default=256)
+    ap.add_argument("--points-per-batch", type=int, default=1024,
+                    help="prompts per decoder batch (the dense sweep has no pruning, so results do not depend on it; "
+                         "the reference's EPS default of 32 is used by the parity tests)")
     ap.add_argument("--mode", default="dense", choices=["dense", "eps"])
     ap.add_argument("--stability-thresh", type=float, default=0.25,
                     help="stability_score_thresh of the run.  The shipped 0.8 keeps NO mask with random weights "

@@ -27,7 +27,7 @@ import crowdsam.utils as utils
 from crowdsam_amd import hip
 from crowdsam_amd.dino import DinoV2
 from segment_anything_cs.utils.amg import (MaskData, batched_mask_to_box, coco_encode_rle, generate_crop_boxes,
-                                           mask_to_rle_pytorch, remove_small_regions)
+                                           mask_to_rle_arrays, mask_to_rle_pytorch, remove_small_regions)
 
 
 def box_area(b):
@@ -239,7 +239,7 @@ class CrowdSAM:
                                                   max(self.box_nms_thresh, self.crop_nms_thresh))
         t0 = self._tick("small_regions", t0)
         data["scores"] = data["iou_preds"]
-        data["rles"] = mask_to_rle_pytorch(data["masks"])
+        data["rles"] = mask_to_rle_arrays(data["masks"])    # run lengths as ndarrays -> C string packer
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
         del data["masks"]

@@ -63,6 +63,7 @@ SIGNATURES = {
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
 }
 LONG_RETURNS = {
+    "csam_coco_rle_string": [_P, _L, _P, _L],
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
     "csam_t2i_fused_workspace_bytes": [_I],
@@ -522,3 +523,16 @@ def mask_write(lowres, sel, keep, B, in_hw, out_hw, thr, out_mask, tmp=None, slo
     """Second pass: mask bytes of the prompts with keep[b] != 0, at out_mask[b] or out_mask[slot[b]]."""
     call("csam_mask_write", _stream(), _ptr(lowres), _ptr(sel), _ptr(keep), _ptr(slot), B, in_hw[0], in_hw[1], out_hw[0],
          out_hw[1], float(thr), _ptr(out_mask), _ptr(tmp))
+
+
+def coco_rle_string(counts):
+    """Host helper: COCO compressed-RLE string for a list / array of run lengths."""
+    import numpy as np
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    if c.size == 0:
+        return ""
+    buf = ctypes.create_string_buffer(int(c.size) * 13 + 1)
+    n = lib().csam_coco_rle_string(c.ctypes.data_as(_P), int(c.size), buf, len(buf))
+    if n < 0:
+        raise RuntimeError("csam_coco_rle_string: buffer too small")
+    return buf.raw[:n].decode("ascii")

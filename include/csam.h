@@ -185,6 +185,10 @@ int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int*
 int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
                    const long* mask_offsets, uint32_t* out_positions);
 
+/* host helper (HOST pointers): COCO compressed-RLE string of run lengths (amg.py:294-300 / pycocotools
+ * rleToString); returns the length or -1 when cap is too small (13 chars per run always suffice) */
+long csam_coco_rle_string(const long long* counts, long n, char* out, long cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,20 +136,20 @@ def batched_mask_to_box(masks):
 
 
 def _runs_from_positions(pos, first_set, hw):
-    idx = np.concatenate([[0], pos, [hw]])
-    counts = [0] if first_set else []
-    counts.extend(np.diff(idx).tolist())
-    return counts
+    """Run lengths (int64 array) from the sorted change positions of a column-major flattening."""
+    idx = np.concatenate([[0], pos, [hw]]).astype(np.int64)
+    runs = np.diff(idx)
+    return np.concatenate([[0], runs]) if first_set else runs
 
 
-def mask_to_rle_pytorch(tensor):
-    """Uncompressed column-major RLE per mask (amg.py:107-135).  CUDA input: HIP csam_rle_* kernels
-    with one D2H of the change positions (the reference syncs once per mask)."""
+def mask_to_rle_arrays(tensor):
+    """mask_to_rle_pytorch with the run lengths kept as int64 ndarrays (what the driver feeds straight into
+    the C string packer: a crowded frame has 1e5+ runs per mask, Python lists would dominate the tail)."""
     b, h, w = tensor.shape
     if b == 0:
         return []
     if tensor.is_cuda:
-        m8 = tensor.to(torch.uint8).contiguous()
+        m8 = (tensor.view(torch.uint8) if tensor.dtype == torch.bool else tensor.to(torch.uint8)).contiguous()
         pos, offs = hip.rle_encode(m8)
         pos = pos.cpu().numpy().astype(np.int64)
         first = m8[:, 0, 0].cpu().numpy()
@@ -162,6 +162,12 @@ def mask_to_rle_pytorch(tensor):
         pos = np.flatnonzero(flat[1:] != flat[:-1]) + 1
         out.append({"size": [h, w], "counts": _runs_from_positions(pos, bool(flat[0]), h * w)})
     return out
+
+
+def mask_to_rle_pytorch(tensor):
+    """Uncompressed column-major RLE per mask (amg.py:107-135), counts as Python lists like the reference.
+    CUDA input: HIP csam_rle_* kernels with one D2H of the change positions (the reference syncs per mask)."""
+    return [{"size": r["size"], "counts": r["counts"].tolist()} for r in mask_to_rle_arrays(tensor)]
 
 
 def rle_to_mask(rle):
@@ -204,19 +210,10 @@ def remove_small_regions(mask, area_thresh, mode):
 
 
 def coco_rle_string(counts):
-    """COCO compressed-RLE string of run lengths (pycocotools rleToString: 5 data bits + continuation
-    per char offset by 48, runs after the third delta-coded against counts[i-2])."""
-    chars = []
-    for i, c in enumerate(counts):
-        x = int(c) - (int(counts[i - 2]) if i > 2 else 0)
-        while True:
-            low = x & 0x1F
-            x >>= 5
-            more = (x != -1) if (low & 0x10) else (x != 0)
-            chars.append(chr((low | (0x20 if more else 0)) + 48))
-            if not more:
-                break
-    return "".join(chars)
+    """COCO compressed-RLE string of run lengths (pycocotools rleToString: 5 data bits + continuation per char
+    offset by 48, runs after the third delta-coded against counts[i-2]).  A crowded frame carries 1e5+ runs, so
+    the byte loop is the C host helper csam_coco_rle_string (pycocotools is C in the reference as well)."""
+    return hip.coco_rle_string(counts)
 
 
 def coco_encode_rle(uncompressed_rle):

@@ -14,7 +14,7 @@ import segment_anything_cs.utils.amg as amg
 np.random.seed(0)
 # avoid RLE of 4096 masks: monkeypatch
 import crowdsam.model as cm
-cm.mask_to_rle_pytorch = lambda masks: [ {"size": list(masks.shape[1:]), "counts": [int(masks.shape[1]*masks.shape[2])]} for _ in range(masks.shape[0]) ]
+cm.mask_to_rle_arrays = lambda masks: [ {"size": list(masks.shape[1:]), "counts": [int(masks.shape[1]*masks.shape[2])]} for _ in range(masks.shape[0]) ]
 out = m.generate(synth.synthetic_crowd_frame(0))
 s, st, b = out["scores"], out["stability_score"], out["boxes"]
 print("n", len(s), "score pct", np.percentile(s, [1, 10, 50, 90, 99]))
