@@ -26,8 +26,7 @@ import torch
 import crowdsam.utils as utils
 from crowdsam_amd import hip
 from crowdsam_amd.dino import DinoV2
-from segment_anything_cs.utils.amg import (MaskData, batched_mask_to_box, coco_encode_rle, generate_crop_boxes,
-                                           mask_to_rle_arrays, mask_to_rle_pytorch, remove_small_regions)
+from segment_anything_cs.utils.amg import MaskData, coco_encode_rle, generate_crop_boxes, mask_to_rle_arrays
 
 
 def box_area(b):
@@ -291,26 +290,19 @@ class CrowdSAM:
     # ------------------------------------------------------------------------------------------
     @staticmethod
     def postprocess_small_regions(mask_data, min_area, nms_thresh):
-        """Hole filling / island removal on the host (as the reference: crowdsam/model.py:394-443) and
-        a second NMS that prefers untouched masks."""
+        """Hole filling / island removal and a second NMS that prefers untouched masks
+        (crowdsam/model.py:394-443).  The reference labels components on the host one mask at a time; here
+        csam_small_regions does all masks of the frame on device and also returns the post-edit boxes."""
         if len(mask_data["masks"]) == 0:
             return mask_data
-        dev = mask_data["masks"].device
-        new_masks, scores = [], []
-        for mask in mask_data["masks"].cpu().numpy():
-            mask, changed = remove_small_regions(mask, min_area, mode="holes")
-            unchanged = not changed
-            mask, changed = remove_small_regions(mask, min_area, mode="islands")
-            unchanged = unchanged and not changed
-            new_masks.append(torch.as_tensor(mask).unsqueeze(0))
-            scores.append(float(unchanged))
-        masks = torch.cat(new_masks, dim=0)
-        boxes = batched_mask_to_box(masks)
-        keep = batched_nms(boxes.float().to(dev), torch.as_tensor(scores, device=dev), None, nms_thresh)
-        for i in keep.tolist():
-            if scores[i] == 0.0:
-                mask_data["boxes"][i] = boxes[i].to(dev)
-                mask_data["masks"][i] = masks[i].to(dev)
+        masks = mask_data["masks"]
+        new_masks, changed, boxes = hip.small_regions(masks, min_area)
+        scores = (changed == 0).float()
+        keep = batched_nms(boxes, scores, None, nms_thresh)
+        edited = keep[scores[keep] == 0]
+        if edited.numel():
+            mask_data["boxes"][edited] = boxes[edited].to(mask_data["boxes"].dtype)
+            mask_data["masks"][edited] = new_masks[edited].to(masks.dtype)
         mask_data.filter(keep)
         return mask_data
 

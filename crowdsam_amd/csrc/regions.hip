@@ -1,0 +1,367 @@
+// csam_small_regions: hole filling + island removal on device (8-connected component labelling).
+//
+// Reference: segment_anything_cs/utils/amg.py:267-291 remove_small_regions (cv2.connectedComponentsWithStats,
+// connectivity 8) as driven by crowdsam/model.py:394-443 postprocess_small_regions: per mask, first
+// mode="holes" (components of the complement smaller than area_thresh are filled), then mode="islands"
+// (foreground components smaller than area_thresh are dropped; when every component is small the largest
+// one — first in raster order on ties — is kept).  `changed` is set when either pass modified the mask.
+// The reference runs this on the host one mask at a time; here all masks of the frame go through five
+// kernels per pass with no host round trip, and the post-edit XYXY boxes (amg.py:293-324 batched_mask_to_box)
+// come out of the last kernel.
+//
+// Labelling is union-find over pixel indices (labels only ever decrease, roots are the raster-first pixel
+// of a component, so "first label on ties" == smallest root):
+//   init     one wave per 64-pixel row segment; a pixel's initial parent is the start of its horizontal
+//            run inside the segment (ballot + bit scan), so horizontal links inside a segment cost nothing;
+//   merge    the remaining links: segment-boundary west link, and north links pruned with the usual
+//            decision tree (a pixel whose west neighbour is set only needs NE when N is clear);
+//   count    path compression + per-root area with wave-aggregated atomics (16 rows per wave);
+//   flags    per-root: any small / any big / arg-max area (64-bit atomicMax of area:~root);
+//   apply    rewrites the mask;  extent: box extents of the final masks (block reduction, 4 atomics per block).
+#include "csam_common.h"
+#include <algorithm>
+
+namespace {
+
+struct RegionMeta {        // one per mask per pass
+  int any_small;
+  int any_big;
+  unsigned long long best;   // (area << 32) | (0xffffffff - root)
+};
+
+__device__ __forceinline__ int uf_load(const int* L, int i) { return __atomic_load_n(L + i, __ATOMIC_RELAXED); }
+
+__device__ __forceinline__ int uf_find(const int* L, int i) {
+  int p;
+  while ((p = uf_load(L, i)) != i) i = p;
+  return i;
+}
+
+// find with path halving.  The shortcut store may race with other shortcuts / stale atomicMins, but any value it
+// writes is an ancestor of i at some earlier time (same component, smaller index), which keeps the forest valid;
+// root-time links (the only ones that define components) are never written by it because it never touches a root.
+__device__ __forceinline__ int uf_find_halve(int* L, int i) {
+  int p = uf_load(L, i);
+  while (p != i) {
+    const int g = uf_load(L, p);
+    if (g == p) return p;
+    __atomic_store_n(L + i, g, __ATOMIC_RELAXED);
+    i = g;
+    p = uf_load(L, i);
+  }
+  return i;
+}
+
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+  bool done;
+  do {
+    a = uf_find_halve(L, a);
+    b = uf_find_halve(L, b);
+    if (a < b) {
+      const int old = atomicMin(L + b, a);
+      done = (old == b);
+      b = old;
+    } else if (b < a) {
+      const int old = atomicMin(L + a, b);
+      done = (old == a);
+      a = old;
+    } else {
+      done = true;
+    }
+  } while (!done);
+}
+
+// Row-segment coordinates shared by all kernels: wave -> (y, x0), lane -> x.
+struct Seg {
+  int y, x, lane;
+  bool in;
+};
+__device__ __forceinline__ Seg seg_coords(int H, int W) {
+  const int sw = (W + 63) >> 6;
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  Seg s;
+  s.lane = threadIdx.x & 63;
+  s.y = seg / sw;
+  s.x = (seg - s.y * sw) * 64 + s.lane;
+  s.in = (s.y < H) && (s.x < W);
+  return s;
+}
+
+template <int HOLES>
+__device__ __forceinline__ bool work_at(const uint8_t* m, int W, int y, int x) {
+  return HOLES ? (m[(long)y * W + x] == 0) : (m[(long)y * W + x] != 0);
+}
+
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t* __restrict__ masks, int* __restrict__ L,
+                                                      int* __restrict__ S, int H, int W) {
+  const long base = (long)blockIdx.y * H * W;
+  const Seg s = seg_coords(H, W);
+  const bool wk = s.in && work_at<HOLES>(masks + base, W, s.y, s.x);
+  const unsigned long long bits = __ballot(wk);
+  if (!s.in) return;
+  const int p = s.y * W + s.x;
+  int lab = -1;
+  if (wk) {
+    const unsigned long long below = (s.lane == 0) ? 0ull : (~bits & ((1ull << s.lane) - 1ull));
+    const int start = below ? (64 - __clzll(below)) : 0;
+    lab = p - s.lane + start;
+  }
+  L[base + p] = lab;
+  S[base + p] = 0;
+}
+
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict__ masks, int* __restrict__ L,
+                                                       int H, int W) {
+  const long base = (long)blockIdx.y * H * W;
+  const Seg s = seg_coords(H, W);
+  if (!s.in) return;
+  const uint8_t* m = masks + base;
+  if (!work_at<HOLES>(m, W, s.y, s.x)) return;
+  int* Lm = L + base;
+  const int p = s.y * W + s.x;
+  const bool w = s.x > 0 && work_at<HOLES>(m, W, s.y, s.x - 1);
+  if (w && s.lane == 0) uf_union(Lm, p, p - 1);
+  if (s.y == 0) return;
+  const bool b = work_at<HOLES>(m, W, s.y - 1, s.x);
+  const bool c = s.x + 1 < W && work_at<HOLES>(m, W, s.y - 1, s.x + 1);
+  if (w) {
+    if (c && !b) uf_union(Lm, p, p - W + 1);
+    return;
+  }
+  if (b) {
+    uf_union(Lm, p, p - W);
+    return;
+  }
+  const bool a = s.x > 0 && work_at<HOLES>(m, W, s.y - 1, s.x - 1);
+  if (a) uf_union(Lm, p, p - W - 1);
+  if (c) uf_union(Lm, p, p - W + 1);
+}
+
+// Path compression + per-root area.  A wave walks CC_ROWS vertically consecutive row segments and keeps a running
+// (root, count) pair, so a solid region costs one atomic per 64 x CC_ROWS pixels instead of one per segment.
+constexpr int CC_ROWS = 16;
+__global__ __launch_bounds__(256) void cc_count_kernel(int* __restrict__ L, int* __restrict__ S, int H, int W) {
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);     // (row band, x segment)
+  const int lane = threadIdx.x & 63;
+  const int band = col / sw;
+  const int x = (col - band * sw) * 64 + lane;
+  int cur = -1, cnt = 0;
+  for (int i = 0; i < CC_ROWS; ++i) {
+    const int y = band * CC_ROWS + i;
+    int r = -1;
+    if (y < H && x < W) {
+      const int p = y * W + x;
+      if (uf_load(L + base, p) >= 0) {
+        r = uf_find(L + base, p);
+        L[base + p] = r;
+      }
+    }
+    unsigned long long active = __ballot(r >= 0);
+    while (active) {
+      const int leader = __ffsll((long long)active) - 1;
+      const int rl = __shfl(r, leader);
+      const unsigned long long same = __ballot(r == rl);
+      const int k = (int)__popcll(same);
+      if (rl == cur) {
+        cnt += k;
+      } else {
+        if (cur >= 0 && lane == 0) atomicAdd(S + base + cur, cnt);
+        cur = rl;
+        cnt = k;
+      }
+      active &= ~same;
+    }
+  }
+  if (cur >= 0 && lane == 0) atomicAdd(S + base + cur, cnt);
+}
+
+// Per-mask summary of the roots: any small / any big / arg-max area.  Same-address atomics from every wave that
+// holds a root serialise in L2 (masks with ragged borders have 1e4+ roots), so this is a chunked reduction:
+// grid (chunks, n), registers -> wave -> block, then at most three atomics per block.
+__global__ __launch_bounds__(256) void cc_flags_kernel(const int* __restrict__ L, const int* __restrict__ S,
+                                                       RegionMeta* __restrict__ meta, int H, int W, int thresh) {
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int segs = H * sw;
+  const int per = (segs + gridDim.x - 1) / gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * per, s1 = min(segs, s0 + per);
+  unsigned long long key = 0ull;
+  int flags = 0;                       // bit 0: small root seen, bit 1: big root seen
+  for (int sg = s0 + wave; sg < s1; sg += 4) {
+    const int y = sg / sw;
+    const int x = (sg - y * sw) * 64 + lane;
+    if (x >= W) continue;
+    const int p = y * W + x;
+    if (L[base + p] != p) continue;
+    const int area = S[base + p];
+    flags |= area < thresh ? 1 : 2;
+    const unsigned long long k = ((unsigned long long)(unsigned)area << 32) | (0xffffffffu - (unsigned)p);
+    key = k > key ? k : key;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off);
+    key = o > key ? o : key;
+    flags |= __shfl_xor(flags, off);
+  }
+  __shared__ unsigned long long rkey[4];
+  __shared__ int rflags[4];
+  if (lane == 0) { rkey[wave] = key; rflags[wave] = flags; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; ++w) {
+    key = rkey[w] > key ? rkey[w] : key;
+    flags |= rflags[w];
+  }
+  RegionMeta* mm = meta + blockIdx.y;
+  if (flags & 1) atomicOr(&mm->any_small, 1);
+  if (flags & 2) atomicOr(&mm->any_big, 1);
+  if (key) atomicMax(&mm->best, key);
+}
+
+// HOLES: out = mask | (complement component smaller than thresh).
+// ISLANDS: out = mask & (component not small), or only the arg-max component when all are small.
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc_apply_kernel(const uint8_t* in, uint8_t* out,
+                                                       const int* __restrict__ L, const int* __restrict__ S,
+                                                       const RegionMeta* __restrict__ meta, int H, int W,
+                                                       int thresh) {
+  const long base = (long)blockIdx.y * H * W;
+  const Seg s = seg_coords(H, W);
+  const RegionMeta mm = meta[blockIdx.y];
+  bool v = false;
+  if (s.in) {
+    const int p = s.y * W + s.x;
+    v = in[base + p] != 0;
+    if (mm.any_small) {
+      const int r = L[base + p];
+      if (HOLES) {
+        if (r >= 0 && S[base + r] < thresh) v = true;
+      } else if (r >= 0) {
+        if (mm.any_big) v = S[base + r] >= thresh;
+        else v = (unsigned)r == 0xffffffffu - (unsigned)(mm.best & 0xffffffffull);
+      }
+    }
+    out[base + p] = v ? 1 : 0;
+  }
+}
+
+// Box extents of the final masks: grid (chunks, n); a block reduces its share of the row segments in
+// registers and issues at most four atomics.
+__global__ __launch_bounds__(256) void cc_extent_kernel(const uint8_t* __restrict__ masks, int* __restrict__ ext,
+                                                        int H, int W) {
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int segs = H * sw;
+  const int per = (segs + gridDim.x - 1) / gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * per, s1 = min(segs, s0 + per);
+  int x0 = W, y0 = H, x1 = -1, y1 = -1;
+  for (int sg = s0 + wave; sg < s1; sg += 4) {
+    const int y = sg / sw;
+    const int x = (sg - y * sw) * 64 + lane;
+    if (x < W && masks[base + (long)y * W + x]) {
+      x0 = min(x0, x); x1 = max(x1, x);
+      y0 = min(y0, y); y1 = max(y1, y);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+  }
+  __shared__ int red[4][4];
+  if (lane == 0) { red[wave][0] = x0; red[wave][1] = y0; red[wave][2] = x1; red[wave][3] = y1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      x0 = min(x0, red[w][0]); y0 = min(y0, red[w][1]);
+      x1 = max(x1, red[w][2]); y1 = max(y1, red[w][3]);
+    }
+    if (x1 >= 0) {
+      int* e = ext + (long)blockIdx.y * 4;
+      atomicMin(e + 0, x0); atomicMin(e + 1, y0);
+      atomicMax(e + 2, x1); atomicMax(e + 3, y1);
+    }
+  }
+}
+
+__global__ void cc_prepare_kernel(RegionMeta* meta, int* ext, int n, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n) {
+    meta[i].any_small = 0;
+    meta[i].any_big = 0;
+    meta[i].best = 0ull;
+  }
+  if (i < n) {
+    ext[i * 4 + 0] = W;
+    ext[i * 4 + 1] = H;
+    ext[i * 4 + 2] = -1;
+    ext[i * 4 + 3] = -1;
+  }
+}
+
+__global__ void cc_finish_kernel(const RegionMeta* meta, const int* ext, int n, int* changed, float* boxes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  changed[i] = (meta[i].any_small | meta[n + i].any_small) ? 1 : 0;
+  const int* e = ext + i * 4;
+  const bool empty = e[2] < e[0] || e[3] < e[1];
+  for (int k = 0; k < 4; ++k) boxes[i * 4 + k] = empty ? 0.f : (float)e[k];
+}
+
+inline long align256(long v) { return (v + 255) & ~255L; }
+
+}  // namespace
+
+extern "C" long csam_small_regions_workspace_bytes(int n, int H, int W) {
+  if (n <= 0 || H <= 0 || W <= 0) return 0;
+  const long px = (long)n * H * W;
+  return 2 * align256(px * 4) + align256((long)2 * n * sizeof(RegionMeta)) + align256((long)n * 16);
+}
+
+extern "C" int csam_small_regions(void* stream_, const uint8_t* masks, uint8_t* out, int* changed, float* boxes,
+                                  int n, int H, int W, int min_area, void* ws, long ws_bytes) {
+  CSAM_REQUIRE(masks && out && changed && boxes && ws, "csam_small_regions: null pointer");
+  CSAM_REQUIRE(n > 0 && H > 0 && W > 0 && (long)H * W < (1L << 31), "csam_small_regions: bad shape");
+  CSAM_REQUIRE(n <= 65535, "csam_small_regions: at most 65535 masks per call");
+  CSAM_REQUIRE(ws_bytes >= csam_small_regions_workspace_bytes(n, H, W), "csam_small_regions: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const long px = (long)n * H * W;
+  char* w = (char*)ws;
+  int* L = (int*)w;
+  w += align256(px * 4);
+  int* S = (int*)w;
+  w += align256(px * 4);
+  RegionMeta* meta = (RegionMeta*)w;
+  w += align256((long)2 * n * sizeof(RegionMeta));
+  int* ext = (int*)w;
+
+  const int segs = H * ((W + 63) >> 6);
+  const dim3 grid(csam_cdiv(segs, 4), n), block(256);
+  // chunked reductions (flags, extents): enough blocks to fill the chip whatever n is
+  const dim3 rgrid(std::min(std::min(std::max(1024 / n, 16), 256), std::max(1, segs / 8)), n);
+  const dim3 cgrid(csam_cdiv(csam_cdiv(H, CC_ROWS) * ((W + 63) >> 6), 4), n);
+  hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);
+  // pass 1: holes (components of the complement)
+  hipLaunchKernelGGL(cc_init_kernel<1>, grid, block, 0, stream, masks, L, S, H, W);
+  hipLaunchKernelGGL(cc_merge_kernel<1>, grid, block, 0, stream, masks, L, H, W);
+  hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  hipLaunchKernelGGL(cc_flags_kernel, rgrid, block, 0, stream, L, S, meta, H, W, min_area);
+  hipLaunchKernelGGL(cc_apply_kernel<1>, grid, block, 0, stream, masks, out, L, S, meta, H, W, min_area);
+  // pass 2: islands (components of the hole-filled mask)
+  hipLaunchKernelGGL(cc_init_kernel<0>, grid, block, 0, stream, out, L, S, H, W);
+  hipLaunchKernelGGL(cc_merge_kernel<0>, grid, block, 0, stream, out, L, H, W);
+  hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  hipLaunchKernelGGL(cc_flags_kernel, rgrid, block, 0, stream, L, S, meta + n, H, W, min_area);
+  hipLaunchKernelGGL(cc_apply_kernel<0>, grid, block, 0, stream, out, out, L, S, meta + n, H, W, min_area);
+  hipLaunchKernelGGL(cc_extent_kernel, rgrid, block, 0, stream, out, ext, H, W);
+  hipLaunchKernelGGL(cc_finish_kernel, dim3(csam_cdiv(n, 256)), dim3(256), 0, stream, meta, ext, n, changed, boxes);
+  CSAM_LAUNCH_CHECK("csam_small_regions");
+  return CSAM_OK;
+}

@@ -53,6 +53,7 @@ SIGNATURES = {
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
@@ -66,6 +67,7 @@ LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
+    "csam_small_regions_workspace_bytes": [_I, _I, _I],
     "csam_t2i_fused_workspace_bytes": [_I],
     "csam_flash_attn_workspace_bytes": [_I, _I],
 }
@@ -447,6 +449,23 @@ def box_nms(boxes, scores, thr):
     count = torch.zeros(1, dtype=torch.int32, device=boxes.device)
     call("csam_box_nms", _stream(), _ptr(boxes), _ptr(scores), N, float(thr), _ptr(keep), _ptr(count), _ptr(ws), nbytes)
     return keep[: int(count.item())]
+
+
+def small_regions(masks, min_area):
+    """Hole filling then island removal (8-connected) of u8/bool masks [n,H,W] on device.
+    -> (edited masks u8, changed int32 [n], boxes f32 [n,4])."""
+    n, H, W = masks.shape
+    m8 = (masks.view(torch.uint8) if masks.dtype == torch.bool else masks).contiguous()
+    out = torch.empty_like(m8)
+    changed = torch.empty((n,), dtype=torch.int32, device=m8.device)
+    boxes = torch.empty((n, 4), dtype=torch.float32, device=m8.device)
+    if n == 0:
+        return out, changed, boxes
+    nbytes = lib().csam_small_regions_workspace_bytes(n, H, W)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=m8.device)
+    call("csam_small_regions", _stream(), _ptr(m8), _ptr(out), _ptr(changed), _ptr(boxes), n, H, W, int(min_area),
+         _ptr(ws), nbytes)
+    return out, changed, boxes
 
 
 def rle_encode(masks):

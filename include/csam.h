@@ -185,6 +185,13 @@ int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int*
 int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
                    const long* mask_offsets, uint32_t* out_positions);
 
+/* ---- small-region clean-up (amg.py:267-291 remove_small_regions mode "holes" then "islands", 8-connected,
+ * as driven by crowdsam/model.py:394-443): masks u8 [n,H,W] -> out u8 (may alias masks), changed int32 [n]
+ * (either pass modified the mask), boxes f32 [n,4] XYXY of the edited masks (amg.py:293-324) */
+long csam_small_regions_workspace_bytes(int n, int H, int W);
+int csam_small_regions(void* stream, const uint8_t* masks, uint8_t* out, int* changed, float* boxes, int n, int H,
+                       int W, int min_area, void* workspace, long workspace_bytes);
+
 /* host helper (HOST pointers): COCO compressed-RLE string of run lengths (amg.py:294-300 / pycocotools
  * rleToString); returns the length or -1 when cap is too small (13 chars per run always suffice) */
 long csam_coco_rle_string(const long long* counts, long n, char* out, long cap);

@@ -1,0 +1,78 @@
+"""GPU parity (bit-exact) of csam_small_regions -- device connected components for hole filling and island
+removal -- against the oracle restatement of amg.py:267-291 / crowdsam/model.py:394-443."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobs(n, H, W, seed, k=21, thr=0.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 1, H, W, generator=g)
+    x = torch.nn.functional.avg_pool2d(x, k, 1, k // 2)
+    return (x[:, 0] > thr * x.std()).numpy()
+
+
+def _oracle(masks, min_area):
+    from oracle import pipeline_oracle as po
+    outs, changed = [], []
+    for m in masks:
+        m1, c1 = po.remove_small_regions(m, min_area, "holes")
+        m2, c2 = po.remove_small_regions(m1, min_area, "islands")
+        outs.append(np.asarray(m2, dtype=bool))
+        changed.append(int(c1 or c2))
+    outs = np.stack(outs)
+    boxes = po.batched_mask_to_box(torch.as_tensor(outs)).float().numpy()
+    return outs, np.array(changed), boxes
+
+
+def _check(cuda, masks, min_area):
+    from crowdsam_amd import hip
+    out, changed, boxes = hip.small_regions(torch.as_tensor(masks).to(cuda), min_area)
+    ro, rc, rb = _oracle(masks, min_area)
+    assert np.array_equal(changed.cpu().numpy(), rc)
+    assert np.array_equal(out.cpu().numpy().astype(bool), ro)
+    assert np.array_equal(boxes.cpu().numpy(), rb)
+
+
+@pytest.mark.parametrize("hw", [(683, 1024), (1024, 683), (97, 130), (64, 64), (5, 200)])
+def test_blobs(cuda, hw):
+    H, W = hw
+    masks = np.concatenate([_blobs(3, H, W, 1, 21), _blobs(3, H, W, 2, 7, 0.5), _blobs(2, H, W, 3, 3, 1.0)])
+    _check(cuda, masks, 100)
+
+
+def test_noise_and_degenerate(cuda):
+    H, W = 333, 517
+    rng = np.random.RandomState(0)
+    noise = rng.rand(4, H, W) > np.array([0.5, 0.3, 0.7, 0.95])[:, None, None]
+    empty = np.zeros((1, H, W), bool)
+    full = np.ones((1, H, W), bool)
+    one = np.zeros((1, H, W), bool)
+    one[0, 100, 200] = True                       # single small island: kept as the arg-max fallback
+    ties = np.zeros((1, H, W), bool)              # all-small islands with equal areas: first in raster order
+    ties[0, 10:13, 300:303] = True
+    ties[0, 10:13, 20:23] = True
+    ties[0, 200:203, 5:8] = True
+    spiral = np.zeros((1, H, W), bool)            # long serpentine component (deep union-find chains)
+    for y in range(0, H - 2, 4):
+        spiral[0, y, :] = True
+        spiral[0, y:y + 4, (W - 1) if (y // 4) % 2 == 0 else 0] = True
+    diag = np.zeros((1, H, W), bool)              # 8-connectivity only links
+    idx = np.arange(min(H, W))
+    diag[0, idx, idx] = True
+    diag[0, idx[:-1], idx[:-1] + 2] = True
+    masks = np.concatenate([noise, empty, full, one, ties, spiral, diag])
+    for min_area in (100, 1, 5000):
+        _check(cuda, masks, min_area)
+
+
+def test_in_place_and_many(cuda):
+    from crowdsam_amd import hip
+    masks = _blobs(70, 200, 300, 5, 9, 0.3)
+    ro, rc, rb = _oracle(masks, 60)
+    out, changed, boxes = hip.small_regions(torch.as_tensor(masks).to(cuda), 60)
+    assert np.array_equal(out.cpu().numpy().astype(bool), ro)
+    assert np.array_equal(changed.cpu().numpy(), rc)
+    assert np.array_equal(boxes.cpu().numpy(), rb)
