@@ -19,6 +19,7 @@
 //   * epilogue fused: +bias[n], GELU(erf)/ReLU, *colscale[n] (DINOv2 LayerScale),
 //     +residual[m,n] (f16 or f32), cast to f16 or f32.
 #include "csam_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct GemmArgs {
   const float* colscale;
   const void* R; long ldr; int r_dt;
   int res_mod;          // >0: residual row = m % res_mod (per-image constant broadcast over prompts)
+  int xcd;              // XCD-aware tile order on/off
   int act;
   int M, N, K;
   long sA, sW, sC, sB;  // batch strides in elements (grid.z); sB: bias stride
@@ -45,94 +47,142 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-// MI = M tiles of 16 rows per wave: 4 -> 128-row workgroup tile, 2 -> 64-row tile (twice the workgroups:
-// used when the 128-row grid would leave CUs idle, e.g. N = 1024 projections at M = 4096)
-template <int MI>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
-  constexpr int TBM = MI * 32;   // rows of the workgroup tile
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `ahead` stages (L loads each) issued after the wanted one are still in flight
+template <int L, int MAXA>
+__device__ __forceinline__ void wait_stage(int ahead) {
+  if constexpr (MAXA == 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (ahead >= MAXA) wait_vmcnt<MAXA * L>();
+    else wait_stage<L, MAXA - 1>(ahead);
+  }
+}
+
+// Tile configuration: WM x WN waves, each owning MI x NI MFMA 16x16 tiles; the workgroup tile is
+// (WM*MI*16) x 128 (WN*NI == 8).  NS = depth of the operand ring in LDS.  Stage kt+NS-1 is issued while stage
+// kt is consumed and the wait before each K step is a COUNTED vmcnt -- the prefetches stay in flight across the
+// (raw) barrier.  Shipped configurations:
+//   <4,4,2,2,2>  128-row tile, 4 waves, 2 x 32 KB: two workgroups per CU
+//   <2,4,2,2,3>   64-row tile, 4 waves, 3 x 24 KB: two workgroups per CU; for grids that would leave CUs idle
+//   <4,2,2,4,4>  128-row tile, 8 waves, 4 x 32 KB: one workgroup per CU, two waves per SIMD, 3 stages in flight
+template <int MI, int NI, int WM, int WN, int NS, int KB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TBM = WM * MI * 16;              // rows of the workgroup tile
+  static_assert(WN * NI * 16 == BN, "tile is 128 columns wide");
+  static_assert(KB == 64 || KB == 32, "K step");
+  constexpr int PITCH = KB * 2;                  // bytes per LDS row
+  constexpr int RPI = 1024 / PITCH;              // rows covered by one wave-wide global_load_lds (8 / 16)
+  constexpr int SPR = PITCH / 16;                // 16-B slots per row (8 / 4)
+  constexpr int A_BYTES = TBM * PITCH;
+  constexpr int STAGE = A_BYTES + BN * PITCH;    // [A: TBM rows][W: 128 rows]
+  constexpr int LA = TBM / RPI / NW, LW = BN / RPI / NW;   // global_load_lds per lane per stage
+  static_assert(LA >= 1 && LW >= 1 && LA * NW * RPI == TBM && LW * NW * RPI == BN, "staging split");
+  constexpr int L = LA + LW;
+  // bank-conflict swizzle of the 16-B slot index, applied to the global SOURCE chunk and to the fragment reads:
+  // 128-B rows: slot ^= row & 7;  64-B rows: slot ^= 3 * ((row >> 2) & 1)  (both conflict-free for the 16-lane
+  // groups ds_read_b128 is serviced in, MI355X_MICROARCH.md LDS table)
+  auto swz = [](int row) { return KB == 64 ? (row & 7) : 3 * ((row >> 2) & 1); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   p.A += (long)blockIdx.z * p.sA;
   p.W += (long)blockIdx.z * p.sW;
   if (p.bias) p.bias += (long)blockIdx.z * p.sB;
   p.C = (p.c_dt == CSAM_DT_F32) ? (void*)((float*)p.C + (long)blockIdx.z * p.sC)
                                 : (void*)((half_t*)p.C + (long)blockIdx.z * p.sC);
-  // layout: [stage][A|W][128 rows][128 B]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int bn0 = blockIdx.x * BN;
-  const int bm0 = blockIdx.y * TBM;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of row-major
+  // tiles (N fastest): an XCD's L2 then sees few A row-tiles and A crosses the fabric about once instead of
+  // 8 times.  Bijective for any tile count.
+  const int gx = p.N / BN;
+  const int ntiles = gridDim.x;
+  int t = blockIdx.x;
+  if (p.xcd) {
+    const int b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int bn0 = (t % gx) * BN;
+  const int bm0 = (t / gx) * TBM;
 
-  // ---- staging addresses: wave w, instr i covers tile rows (w*4+i)*8 .. +7
-  const int srow = lane >> 3;            // row within the 8-row group
-  const int sslot = lane & 7;            // 16-B slot in the 128-B LDS row
-  const half_t* a_src[MI];
-  const half_t* w_src[4];
+  // ---- staging addresses: wave w, instr i covers tile rows (w*LX+i)*RPI .. +RPI-1
+  const int srow = lane / SPR;           // row within the group
+  const int sslot = lane % SPR;          // 16-B slot in the LDS row
+  const half_t* a_src[LA];
+  const half_t* w_src[LW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + srow;
-    const int chunk = sslot ^ (row & 7);
+  for (int i = 0; i < LW; ++i) {
+    const int row = (wave * LW + i) * RPI + srow;
+    const int chunk = sslot ^ swz(row);
     w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
   }
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int row = (wave * MI + i) * 8 + srow;
-    const int chunk = sslot ^ (row & 7);
+  for (int i = 0; i < LA; ++i) {
+    const int row = (wave * LA + i) * RPI + srow;
+    const int chunk = sslot ^ swz(row);
     int gm = bm0 + row;
     gm = gm < p.M ? gm : p.M - 1;        // clamp: rows past M are loaded but never stored
     a_src[i] = p.A + (long)gm * p.lda + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
-    char* abase = smem + buf * 2 * TILE_BYTES;
-    char* wbase = abase + TILE_BYTES;
+    char* abase = smem + buf * STAGE;
+    char* wbase = abase + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(w_src[i] + k0, wbase + (wave * 4 + i) * 1024);
+    for (int i = 0; i < LW; ++i) glds16(w_src[i] + k0, wbase + (wave * LW + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) glds16(a_src[i] + k0, abase + (wave * MI + i) * 1024);
+    for (int i = 0; i < LA; ++i) glds16(a_src[i] + k0, abase + (wave * LA + i) * 1024);
   };
 
-  floatx4 acc[MI][4];
+  floatx4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragment read offsets (bytes within a tile), swizzled
+  // ---- fragment read offsets (bytes within a stage), swizzled
   const int fr = lane & 15, fg = lane >> 4;
-  int a_off[MI], w_off[4];
+  int a_off[MI], w_off[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w_off[i] = (wn * 64 + i * 16 + fr) * 128;
+  for (int i = 0; i < NI; ++i) w_off[i] = A_BYTES + (wn * NI * 16 + i * 16 + fr) * PITCH;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) a_off[i] = (wm * MI * 16 + i * 16 + fr) * 128;
-  const int sw = fr & 7;  // row&7 (tile-row offsets are multiples of 16)
+  for (int i = 0; i < MI; ++i) a_off[i] = (wm * MI * 16 + i * 16 + fr) * PITCH;
+  const int sw = swz(fr);  // tile-row offsets are multiples of 16, which the swizzle ignores
 
-  const int nk = p.K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  const int nk = p.K / KB;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s, s * KB);
 
+  int cur = 0;                                         // kt % NS
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const char* abase = smem + cur * 2 * TILE_BYTES;
-    const char* wbase = abase + TILE_BYTES;
+    // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
+    // done reading the buffer of stage kt-1, which the next prefetch overwrites
+    wait_stage<L, NS - 2>(min(NS - 2, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
+    const char* base = smem + cur * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KB / 32; ++kk) {
       const int coff = ((kk * 4 + fg) ^ sw) << 4;
-      half8_t af[MI], wf[4];
+      half8_t af[MI], wf[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *(const half8_t*)(wbase + w_off[i] + coff);
+      for (int i = 0; i < NI; ++i) wf[i] = *(const half8_t*)(base + w_off[i] + coff);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(abase + a_off[i] + coff);
+      for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(base + a_off[i] + coff);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
+  __syncthreads();                                     // operand ring is free: reuse it for the output tile
 
   // ---- epilogue.  Lane holds C[m = fr][n = fg*4 + j] of each 16x16 tile: stored straight from the
   // accumulators that is 8/16-byte pieces in 32/64-B segments (store-issue bound, measured).  Instead the
@@ -144,8 +194,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     const int row = wm * MI * 16 + mi * 16 + fr;     // row inside the workgroup tile
     const int m = bm0 + row;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = wn * 64 + ni * 16 + fg * 4;    // column inside the 128-col tile
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = wn * NI * 16 + ni * 16 + fg * 4;    // column inside the 128-col tile
       const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
       if (p.bias) v += *(const floatx4*)(p.bias + n);
@@ -164,10 +214,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
           for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
         }
       }
-      if (p.c_dt == CSAM_DT_F32) {                    // [128][512 B], 32 slots of 16 B, slot ^= row & 31
+      if (p.c_dt == CSAM_DT_F32) {                    // [TBM][512 B], 32 slots of 16 B, slot ^= row & 31
         const int slot = (col >> 2) ^ (row & 31);
         *(floatx4*)(smem + row * 512 + slot * 16) = v;
-      } else {                                         // [128][256 B], 16 slots of 16 B, slot ^= row & 15
+      } else {                                         // [TBM][256 B], 16 slots of 16 B, slot ^= row & 15
         half4_t h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
@@ -179,8 +229,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   __syncthreads();
   if (p.c_dt == CSAM_DT_F32) {
 #pragma unroll
-    for (int it = 0; it < 4 * MI; ++it) {
-      const int c = tid + it * 256;                    // TBM*32 16-B pieces: row c>>5, LDS slot c&31
+    for (int it = 0; it < TBM * 32 / NT; ++it) {
+      const int c = tid + it * NT;                     // TBM*32 16-B pieces: row c>>5, LDS slot c&31
       const int row = c >> 5, sl = c & 31;
       const int m = bm0 + row;
       if (m < p.M) {
@@ -195,8 +245,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     }
   } else {
 #pragma unroll
-    for (int it = 0; it < 2 * MI; ++it) {
-      const int c = tid + it * 256;                    // TBM*16 16-B pieces: row c>>4, LDS slot c&15
+    for (int it = 0; it < TBM * 16 / NT; ++it) {
+      const int c = tid + it * NT;                     // TBM*16 16-B pieces: row c>>4, LDS slot c&15
       const int row = c >> 4, sl = c & 15;
       const int m = bm0 + row;
       if (m < p.M) {
@@ -233,17 +283,37 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   // 64-row tiles when 128-row tiles would leave CUs without a workgroup (measured: pays at <= 256 tiles,
   // loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU)
   const bool small = (long)(N / BN) * csam_cdiv(M, BM) * batch <= 256;
-  dim3 grid(N / BN, csam_cdiv(M, small ? 64 : BM), batch);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    hipFuncSetAttribute((const void*)gemm_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    attr_set = true;
+  static int variant = -1, xcd = 1;
+  if (variant < 0) {
+    const char* e = getenv("CSAM_GEMM_VARIANT");
+    variant = e ? atoi(e) : 0;
+    const char* x = getenv("CSAM_GEMM_XCD");
+    xcd = x ? atoi(x) : 1;
   }
-  if (small)
-    hipLaunchKernelGGL(gemm_f16_kernel<2>, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(gemm_f16_kernel<4>, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
+  p.xcd = xcd;
+  dim3 grid((N / BN) * csam_cdiv(M, small ? 64 : BM), 1, batch);
+#define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
+  {                                                                                                            \
+    constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
+    constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
+    constexpr int SM = SM_RING > SM_OUT ? SM_RING : SM_OUT;                                                    \
+    static bool set = false;                                                                                   \
+    auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
+    if (!set) {                                                                                                \
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
+      set = true;                                                                                              \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
+  }
+  if (small) {
+    if (variant == 0) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
+    else if (variant == 1) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 4, 32)
+    else CSAM_GEMM_LAUNCH(2, 4, 2, 2, 6, 32)
+  } else {
+    if (variant == 0) CSAM_GEMM_LAUNCH(4, 4, 2, 2, 2, 64)
+    else if (variant == 1) CSAM_GEMM_LAUNCH(4, 4, 2, 2, 4, 32)
+    else CSAM_GEMM_LAUNCH(4, 4, 2, 2, 3, 32)
+  }
   CSAM_LAUNCH_CHECK("csam_gemm_f16");
   return CSAM_OK;
 }
