@@ -28,6 +28,25 @@ sys.path.insert(0, ROOT)
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
+    needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        rows = [v for k, v in d["kernels"].items() if k.startswith(kernel_prefix)]
+        launches = sum(r["launches"] for r in rows)
+        total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+        if launches == 0:
+            return None, "no PMC rows for " + kernel_prefix
+        return total / launches, ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same bench "
+                                  "command (profiles/r01_pmc_traffic.json); all kernels: %.1f GB/image"
+                                  % (d["hbm_bytes_per_image_total"] / 1e9))
+    except (OSError, KeyError, ValueError):
+        return None, "profiles/r01_pmc_traffic.json not found"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,9 +157,11 @@ def main():
             work = sum(v["work"] for v in summ.values())
             calls = sum(v["calls"] for v in summ.values())
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_note = pmc_traffic("gemm_f16_kernel")
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (csam_gemm_f16*)", "achieved": achieved,
                                "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                               "traffic": None, "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
+                               "traffic": traffic, "traffic_note": traffic_note,
+                               "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
                                "gemm_ms_per_step": ms / args.steps,
                                "note": ("algorithmic 2*M*N*K of every GEMM launch / HIP-event time on the launch stream, measured on an "
                                         "instrumented repeat of the K timed steps (graph replay disabled)")}

@@ -341,9 +341,9 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
 //   up1 = ConvT(256->64,k2,s2)(keys)  ->  LayerNorm2d(64) -> GELU  ->  ConvT(64->32,k2,s2) -> GELU
 //   masks[b,l,Y,X] = sum_c hyper[b,l,c] * up2[b,c,Y,X]
 // Both transposed convolutions are per-token GEMMs (k=2,s=2: no overlap), so a token's 4x4 output
-// pixels depend on that token only.  Workgroup = 128 consecutive tokens (2 rows of the 64x64 grid) of
-// one prompt, 8 waves: wave = (row half r, first-conv position (di,dj)).
-//   GEMM1 (K=256, glds double-buffered, swizzled)  -> the wave's 64 channels x 64 tokens in registers
+// pixels depend on that token only.  Workgroup = 64 consecutive tokens (one row of the 64x64 grid) of
+// one prompt, 4 waves: wave = first-conv position (di,dj).
+//   GEMM1 (K=256, 3-deep glds ring, swizzled)  -> the wave's 64 channels x 64 tokens in registers
 //   -> LN over the 64 channels (in-lane + 2 shuffles) + GELU -> fp16 registers ARE GEMM2's B operand
 //   GEMM2 (K=64, N=128 = 4 sub-positions x 32 ch, weights permuted on the host) -> GELU
 //   -> hyper product as a 16x16x32 MFMA (hyper rows hi+lo fp16, rows 4..15 zero), again fed from
@@ -353,8 +353,13 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
 // =====================================================================================================
 namespace {
 
-constexpr int UP_XS = 0, UP_WS = 32 * 1024, UP_W2S = 96 * 1024, UP_HFR = 112 * 1024;
-constexpr int UP_B2 = 112 * 1024 + 2 * 64 * 16;     // b2 fp32 [128]
+// LDS map (78.5 KB -> two workgroups per CU): operand ring 3 x (X 64x64 B + W1 256x64 B) | W2' | hyper frags | b2
+constexpr int UP_NS = 3;                              // ring depth (K step = 32)
+constexpr int UP_XB = 64 * 64, UP_WB = 256 * 64;      // bytes per stage
+constexpr int UP_STAGE = UP_XB + UP_WB;               // 20 KB
+constexpr int UP_W2S = UP_NS * UP_STAGE;              // 60 KB
+constexpr int UP_HFR = UP_W2S + 16 * 1024;
+constexpr int UP_B2 = UP_HFR + 2 * 64 * 16;           // b2 fp32 [128]
 constexpr int UP_SMEM = UP_B2 + 128 * 4;
 
 struct UpArgs {
@@ -367,7 +372,6 @@ struct UpArgs {
   const float* hyper;       // [B,4,32]
   float* masks;             // [B,4,256,256]
   float* stats;             // optional [B*4][2]: running max of every mask plane (float atomic max), else NULL
-  int dbg;                  // developer ablation bits (CSAM_DBG env): 1 = skip phases 2-4, 2 = skip GEMM1
 };
 
 // order-preserving float atomic max (sign-split integer trick); *addr must start at -inf
@@ -376,21 +380,26 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else atomicMin((unsigned int*)addr, __float_as_uint(v));
 }
 
-__global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
+// Workgroup = the 64 tokens of one row of the 64x64 grid, 4 waves: wave = first-conv position (di,dj), each
+// wave owns 64 channels x 64 tokens.  Two workgroups are co-resident per CU (LDS 78.5 KB, 2 waves/SIMD), so
+// one's GEMM1 load latency and store tail hide behind the other's LN/GELU/GEMM2 phases (the single 8-wave
+// workgroup per CU this replaces idled there: measured 3.35 -> ms per 1024 prompts).
+// ABL: developer ablation (compile-time, CSAM_DBG env picks the instantiation): 1 = no phases 2-4, 2 = no GEMM1
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.y;
-  const int t0 = blockIdx.x * 128;                 // first token of the 2 grid rows
-  const int r = wave >> 2, pos = wave & 3;
+  const int t0 = blockIdx.x * 64;                  // first token of the grid row
+  const int pos = wave;
   const half_t* Xb = p.X + ((long)b * 4096 + t0) * 256;
 
-  // ---- one-time staging: W2' (16 KB, swizzled) and the hyper A-fragments (hi/lo)
+  // ---- one-time staging: W2' (16 KB, 128-B rows, swizzled) and the hyper A-fragments (hi/lo)
   {
-    const int c = tid;                              // 1024 16-B pieces: 2 per thread
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int cc = c + it * 512;
+    for (int it = 0; it < 4; ++it) {
+      const int cc = tid + it * 256;                // 1024 16-B pieces
       const int row = cc >> 3, sl = cc & 7;
       glds16(p.W2 + (long)row * 64 + ((sl ^ (row & 7)) * 8), smem + UP_W2S + (cc & ~63) * 16);
     }
@@ -412,56 +421,62 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
     if (tid >= 64 && tid < 192) ((float*)(smem + UP_B2))[tid - 64] = p.b2[tid - 64];
   }
 
-  // ---- phase 1: GEMM1, K = 256 in 4 chunks of 64
+  // ---- phase 1: GEMM1, K = 256 in 8 steps of 32 through a 3-deep ring with counted vmcnt (64-B LDS rows:
+  // slot ^= 3 * ((row >> 2) & 1) on the global source and on the fragment reads, conflict-free for ds_read_b128)
+  const half_t* x_src;
+  const half_t* w_src[4];
+  {
+    const int row = tid >> 2, sl = tid & 3;          // X: 64 rows x 4 slots = 256 pieces, 1 per thread
+    x_src = Xb + (long)row * 256 + ((sl ^ (3 * ((row >> 2) & 1))) * 8);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                 // W1: 256 rows x 4 slots = 1024 pieces, 4 per thread
+      const int cc = tid + it * 256;
+      const int wrow = cc >> 2, wsl = cc & 3;
+      w_src[it] = p.W1 + (long)wrow * 256 + ((wsl ^ (3 * ((wrow >> 2) & 1))) * 8);
+    }
+  }
   auto stage = [&](int buf, int k0) {
-    // X: 128 rows x 8 slots = 1024 pieces (2/thread); W1: 256 rows x 8 = 2048 pieces (4/thread)
+    char* xb = smem + buf * UP_STAGE;
+    glds16(x_src + k0, xb + (tid & ~63) * 16);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int cc = tid + it * 512;
-      const int row = cc >> 3, sl = cc & 7;
-      glds16(Xb + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + UP_XS + buf * 16384 + (cc & ~63) * 16);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int cc = tid + it * 512;
-      const int row = cc >> 3, sl = cc & 7;
-      glds16(p.W1 + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + UP_WS + buf * 32768 + (cc & ~63) * 16);
-    }
+    for (int it = 0; it < 4; ++it) glds16(w_src[it] + k0, xb + UP_XB + ((tid + it * 256) & ~63) * 16);
   };
   floatx4 a1[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) a1[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-  const int sw = fr & 7;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (!(p.dbg & 2))
+  const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
+  if (ABL != 2) {
+    stage(0, 0);
+    stage(1, 32);
+  }
+  if (ABL != 2) {
+    int cur = 0;
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < 4) stage(cur ^ 1, (kt + 1) * 64);
-    const char* xb = smem + UP_XS + cur * 16384;
-    const char* wb = smem + UP_WS + cur * 32768;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((kk * 4 + fg) ^ sw) << 4;
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt < 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // one later stage (5 loads) may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < 8) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * 32);
+      const char* xb = smem + cur * UP_STAGE;
+      const char* wb = xb + UP_XB;
       half8_t xf[4], wf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xf[i] = *(const half8_t*)(xb + (r * 64 + i * 16 + fr) * 128 + coff);
-        wf[i] = *(const half8_t*)(wb + (pos * 64 + i * 16 + fr) * 128 + coff);
+        xf[i] = *(const half8_t*)(xb + (i * 16 + fr) * 64 + coff);
+        wf[i] = *(const half8_t*)(wb + (pos * 64 + i * 16 + fr) * 64 + coff);
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           a1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], a1[mi][ni], 0, 0, 0);
+      cur = cur == 2 ? 0 : cur + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  __syncthreads();                                   // ring is free (the output rows alias it)
 
   // ---- phases 2-4 per 16-token tile mi
   floatx4 b1v[4], gv[4], bv[4];
@@ -473,15 +488,11 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
   }
   const half8_t hhi = *(const half8_t*)(smem + UP_HFR + lane * 16);
   const half8_t hlo = *(const half8_t*)(smem + UP_HFR + 1024 + lane * 16);
-  float* outs = (float*)(smem);                     // [2 r][4 l][4 yy][256 X] fp32 = 32 KB (aliases XS/WS)
-  floatx4 mmax = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  if (p.dbg & 1) {
-    outs[tid] = a1[0][0][0] + a1[1][1][1] + a1[2][2][2] + a1[3][3][3];
-  } else
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    asm volatile("" ::: "memory");
-    // LayerNorm2d over the 64 channels of (token, pos), then GELU
+  float* outs = (float*)(smem);                     // [4 l][4 yy][256 X] fp32 = 16 KB (aliases the ring)
+  // Per 16-token tile mi: LayerNorm2d(64) + GELU -> GEMM2 (MFMA) -> +bias, GELU -> hyper product (MFMA) -> LDS rows.
+  // Software-pipelined by one tile: GEMM2 of tile mi+1 is issued before the GELU/hyper stage of tile mi, so the
+  // matrix pipe works under the (dominant) VALU stream instead of in front of it.
+  auto ln_gelu = [&](int mi, half8_t (&xf2)[2]) {
     float sum = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -502,16 +513,22 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
     var += __shfl_xor(var, 16, 64);
     var += __shfl_xor(var, 32, 64);
     const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
-    half8_t xf2[2];
+    const float nmr = -mean * rstd;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float y = (a1[mi][ni][e] - mean) * rstd * gv[ni][e] + bv[ni][e];
-        xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)((p.dbg & 16) ? y : csam_gelu_erf(y));
+      for (int e = 0; e < 4; e += 2) {
+        // y = (a - mean) * rstd * g + b, two channels per packed op
+        const float2_t av = {a1[mi][ni][e], a1[mi][ni][e + 1]};
+        const float2_t g2 = {gv[ni][e], gv[ni][e + 1]}, b2 = {bv[ni][e], bv[ni][e + 1]};
+        const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
+        const float2_t ge = csam_gelu_poly2(__builtin_elementwise_fma(nrm, g2, b2));
+        xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)ge[0];
+        xf2[ni >> 1][(ni & 1) * 4 + e + 1] = (half_t)ge[1];
       }
-    // GEMM2: [128 n2] x [16 tokens], K = 64 (weights k-permuted): 8 N tiles x 2 k-steps
-    floatx4 a2[8];
+  };
+  // GEMM2: [128 n2] x [16 tokens], K = 64 (weights k-permuted): 8 N tiles x 2 k-steps
+  auto gemm2 = [&](const half8_t (&xf2)[2], floatx4 (&a2)[8]) {
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -523,7 +540,9 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
         a2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[s], a2[n2], 0, 0, 0);
       }
     }
-    // + bias, GELU, hyper product per sub-position pos2 (N tiles 2*pos2, 2*pos2+1)
+  };
+  // + bias, GELU, hyper product per sub-position pos2 (N tiles 2*pos2, 2*pos2+1)
+  auto gelu_hyper = [&](int mi, const floatx4 (&a2)[8]) {
 #pragma unroll
     for (int pos2 = 0; pos2 < 4; ++pos2) {
       half8_t ub;
@@ -531,51 +550,65 @@ __global__ __launch_bounds__(512) void upscale_fused_kernel(UpArgs p) {
       for (int h2 = 0; h2 < 2; ++h2) {
         const floatx4 bb = *(const floatx4*)(smem + UP_B2 + ((pos2 * 2 + h2) * 16 + fg * 4) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = a2[pos2 * 2 + h2][e] + bb[e];
-          ub[h2 * 4 + e] = (half_t)((p.dbg & 16) ? z : csam_gelu_erf(z));
+        for (int e = 0; e < 4; e += 2) {
+          const float2_t z = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]} + (float2_t){bb[e], bb[e + 1]};
+          const float2_t ge = csam_gelu_poly2(z);
+          ub[h2 * 4 + e] = (half_t)ge[0];
+          ub[h2 * 4 + e + 1] = (half_t)ge[1];
         }
       }
       floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
-      if (fg == 0 && !(p.dbg & 8)) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+      if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
         const int yy = (pos >> 1) * 2 + (pos2 >> 1);
         const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          outs[((r * 4 + l) * 4 + yy) * 256 + X] = m4[l];
-          mmax[l] = fmaxf(mmax[l], m4[l]);
-        }
+        for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 256 + X] = m4[l];
+      }
+    }
+  };
+  if (ABL == 1) {
+    outs[tid] = a1[0][0][0] + a1[1][1][1] + a1[2][2][2] + a1[3][3][3];
+  } else {
+    half8_t xfa[2], xfb[2];
+    floatx4 a2a[8], a2b[8];
+    ln_gelu(0, xfa);
+    gemm2(xfa, a2a);
+    ln_gelu(1, xfb);
+    gemm2(xfb, a2b);
+    gelu_hyper(0, a2a);
+    ln_gelu(2, xfa);
+    gemm2(xfa, a2a);
+    gelu_hyper(1, a2b);
+    ln_gelu(3, xfb);
+    gemm2(xfb, a2b);
+    gelu_hyper(2, a2a);
+    gelu_hyper(3, a2b);
+  }
+  float* wmx = (float*)(smem + UP_W2S);   // [4 waves][4] (W2' is dead after the last GEMM2 of every wave: barrier below)
+  __syncthreads();
+  // ---- coalesced store of the 4 x 4 output rows (256 fp32 each); iteration `it` of a thread is plane l = it,
+  // row yy = wave, so the per-plane running max for the PWD-Net softmax (saves a full pass over the logits
+  // later) falls out of the same LDS reads
+  {
+    const int i0 = blockIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int x4 = tid & 63, rowid = it * 4 + wave;   // rowid = l*4 + yy
+      const floatx4 v = *(const floatx4*)(outs + rowid * 256 + x4 * 4);
+      float* dst = p.masks + ((((long)b * 4 + it) * 256) + (4 * i0 + wave)) * 256 + x4 * 4;
+      *(floatx4*)dst = v;
+      if (p.stats) {
+        const float m = csam_wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        if (lane == 0) wmx[wave * 4 + it] = m;
       }
     }
   }
-  float* wmx = (float*)(smem + UP_W2S);   // [8 waves][4] (W2' is dead after the last GEMM2 of every wave... barrier below)
-  __syncthreads();
-  if (p.stats) {   // per-plane running max for the PWD-Net softmax (saves a full pass over the logits later)
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const float m = csam_wave_max(mmax[l]);
-      if (lane == 0) wmx[wave * 4 + l] = m;
-    }
-  }
-  __syncthreads();
-  if (p.stats && tid < 4) {
-    float m = wmx[tid];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w * 4 + tid]);
-    atomic_max_float(p.stats + ((long)b * 4 + tid) * 2, m);   // one atomic per (workgroup, plane)
-  }
-  // ---- coalesced store of the 2 x 4 x 4 output rows (256 fp32 each)
-  {
-    const int i0 = blockIdx.x * 2;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 512;               // float4 index in [0, 2048)
-      const int x4 = idx & 63, rowid = idx >> 6;    // rowid = (r*4 + l)*4 + yy
-      const int yy = rowid & 3, l = (rowid >> 2) & 3, rr = rowid >> 4;
-      const floatx4 v = *(const floatx4*)(outs + rowid * 256 + x4 * 4);
-      float* dst = p.masks + ((((long)b * 4 + l) * 256) + (4 * (i0 + rr) + yy)) * 256 + x4 * 4;
-      *(floatx4*)dst = v;
+  if (p.stats) {
+    __syncthreads();
+    if (tid < 4) {
+      const float m = fmaxf(fmaxf(wmx[tid], wmx[4 + tid]), fmaxf(wmx[8 + tid], wmx[12 + tid]));
+      atomic_max_float(p.stats + ((long)b * 4 + tid) * 2, m);   // one atomic per (workgroup, plane)
     }
   }
 }
@@ -602,15 +635,17 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   if (stats_or_null)
     hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null,
                        B * 4);
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("CSAM_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)upscale_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
-    attr_set = true;
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("CSAM_DBG");
+    abl = e ? atoi(e) : 0;
+    hipFuncSetAttribute((const void*)upscale_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
+    hipFuncSetAttribute((const void*)upscale_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
+    hipFuncSetAttribute((const void*)upscale_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
   }
-  hipLaunchKernelGGL(upscale_fused_kernel, dim3(32, B), dim3(512), UP_SMEM, (hipStream_t)stream, a);
+  if (abl == 1) hipLaunchKernelGGL(upscale_fused_kernel<1>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
+  else if (abl == 2) hipLaunchKernelGGL(upscale_fused_kernel<2>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(upscale_fused_kernel<0>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_upscale_fused");
   return CSAM_OK;
 }
