@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * I2T_TOK;
   const half_t* Xb = p.X + (long)b * p.x_bstride + (long)t0 * 256;
+  if (QMODE == 0) {
+    for (int c = tid; c < 4096; c += 256) {          // see prefetch_wo below
+      const int row = c >> 4, sl = c & 15;
+      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
+    }
+  }
 
   // prompt's token-side k, v -> ready-made 16x16x16 MFMA A fragments (zero rows beyond the 7 keys)
   for (int i = tid; i < 8 * 64; i += 256) {
@@ -69,6 +75,15 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     kfr[i] = ka;
     vfr[i] = va;
   }
+  // Wo' (64 KB) -> staging region: 256 rows x 256 B = 4096 16-B chunks, slot = chunk ^ (row & 15).  QMODE 0 has
+  // no phase 1 in that region, so its prefetch is the first thing the workgroup issues (the whole latency
+  // hides under the table build and the Q loads); QMODE 1 issues it after phase 1.
+  auto prefetch_wo = [&]() {
+    for (int c = tid; c < 4096; c += 256) {
+      const int row = c >> 4, sl = c & 15;
+      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
+    }
+  };
   float* par = (float*)(smem + I2T_PAR);
   if (tid < 256) {
     par[tid] = p.bo[tid];
@@ -153,13 +168,7 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
   }
 
   // prefetch Wo' (64 KB) into the now-free staging region; it lands while phase 2 runs
-  {
-    // 256 rows x 256 B = 4096 16-B chunks: slot = chunk ^ (row & 15) within the row's 16 slots
-    for (int c = tid; c < 4096; c += 256) {
-      const int row = c >> 4, sl = c & 15;
-      glds16(p.Wo + (long)row * 128 + ((sl ^ (row & 15)) * 8), smem + (c & ~63) * 16);
-    }
-  }
+  if (QMODE == 1) prefetch_wo();
 
   // ---- phase 2: softmax(q k^T / 4) v over the 7 token keys, per (token, head = ni), on the matrix
   // cores: S^T = K_h q^T and O^T = V_h^T P^T as 16x16x16 MFMAs whose B operands are the lane's own
