@@ -53,6 +53,7 @@ SIGNATURES = {
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
@@ -449,6 +450,20 @@ def box_nms(boxes, scores, thr):
     count = torch.zeros(1, dtype=torch.int32, device=boxes.device)
     call("csam_box_nms", _stream(), _ptr(boxes), _ptr(scores), N, float(thr), _ptr(keep), _ptr(count), _ptr(ws), nbytes)
     return keep[: int(count.item())]
+
+
+def caltech_match(dt, dt_off, gt, gt_off, gt_npos, thres):
+    """Caltech matching of the CrowdHuman evaluator on device (float64).  dt [Nd,5] / gt [Ng,5] float64 device
+    tensors in the order csam.h documents, CSR offsets int64, gt_npos int32 -> (label int8 [Nd], pos uint8 [Nd])."""
+    n_img = gt_npos.numel()
+    label = torch.empty((dt.shape[0],), dtype=torch.int8, device=dt.device)
+    pos = torch.empty((dt.shape[0],), dtype=torch.uint8, device=dt.device)
+    if n_img == 0 or dt.shape[0] == 0:
+        return label, pos
+    max_pos = int(gt_npos.max().item())
+    call("csam_caltech_match", _stream(), _ptr(dt), _ptr(dt_off), _ptr(gt), _ptr(gt_off), _ptr(gt_npos), n_img, max_pos,
+         float(thres), _ptr(label), _ptr(pos))
+    return label, pos
 
 
 def small_regions(masks, min_area):

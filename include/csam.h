@@ -192,6 +192,14 @@ long csam_small_regions_workspace_bytes(int n, int H, int W);
 int csam_small_regions(void* stream, const uint8_t* masks, uint8_t* out, int* changed, float* boxes, int n, int H,
                        int W, int min_area, void* workspace, long workspace_bytes);
 
+/* ---- CrowdHuman evaluator, Caltech matching (tools/crowdhuman_eval.py:113-143 compare_caltech with :215-236
+ * box_overlap_opr), float64, one wave per image.  dt [Nd,5] = x0,y0,x1,y1,score in descending score per image,
+ * gt [Ng,5] = x0,y0,x1,y1,tag with the gt_npos[i] positive boxes of image i first; offsets are CSR rows.
+ * label[d] = 1 matched, 0 false positive, -1 dropped (ignore region / image without GT); pos[d] as the reference. */
+int csam_caltech_match(void* stream, const double* dt, const long* dt_off, const double* gt, const long* gt_off,
+                       const int* gt_npos, int n_img, int max_pos, double thres, signed char* label,
+                       unsigned char* pos);
+
 /* host helper (HOST pointers): COCO compressed-RLE string of run lengths (amg.py:294-300 / pycocotools
  * rleToString); returns the length or -1 when cap is too small (13 chars per run always suffice) */
 long csam_coco_rle_string(const long long* counts, long n, char* out, long cap);

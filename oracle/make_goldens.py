@@ -240,9 +240,92 @@ def golden_pipeline():
     print("pipeline", {k: v.shape for k, v in res.items()}, out["scores"][:5])
 
 
+def evaluator_dataset(seed=0, n_img=14):
+    """Synthetic CrowdHuman-style GT (.odgt records) and COCO-format detections: crowded boxes, ignore regions,
+    score ties, detections hanging over the image border, one image without detections."""
+    rs = np.random.RandomState(seed)
+    records, images, annots = [], [], []
+    aid = 0
+    for i in range(n_img):
+        w, h = int(rs.randint(400, 1200)), int(rs.randint(300, 900))
+        name = "img%03d,%05x" % (i, rs.randint(0, 1 << 20))
+        n_gt = int(rs.randint(3, 40))
+        gts = []
+        for _ in range(n_gt):
+            bw, bh = int(rs.randint(15, 160)), int(rs.randint(30, 320))
+            x, y = int(rs.randint(-20, w - 10)), int(rs.randint(-20, h - 10))
+            vis = [x + int(rs.randint(0, 6)), y + int(rs.randint(0, 6)), max(4, bw - int(rs.randint(0, 12))),
+                   max(4, bh - int(rs.randint(0, 12)))]
+            tag = "person" if rs.rand() < 0.85 else "mask"
+            rb = {"tag": tag, "fbox": [x, y, bw, bh], "vbox": vis, "hbox": [x, y, bw // 3, bh // 6]}
+            if rs.rand() < 0.12:
+                rb["extra"] = {"ignore": 1}
+            elif rs.rand() < 0.5:
+                rb["extra"] = {"ignore": 0, "box_id": 1}
+            gts.append(rb)
+        if not any(g["tag"] == "person" and g.get("extra", {}).get("ignore", 0) == 0 for g in gts):
+            gts[0]["tag"] = "person"
+            gts[0].pop("extra", None)
+        records.append({"ID": name, "gtboxes": gts})
+        images.append({"id": name, "file_name": name + ".jpg", "width": w, "height": h})
+        if i == 5:
+            continue                                    # an image the detector returned nothing for
+        dets = []
+        for g in gts:                                   # jittered true positives, duplicates, misses
+            if rs.rand() < 0.8:
+                for _ in range(1 + (rs.rand() < 0.3)):
+                    x, y, bw, bh = g["vbox"]
+                    j = rs.normal(0, 0.12, 4)
+                    dets.append([x + j[0] * bw, y + j[1] * bh, bw * (1 + j[2]), bh * (1 + j[3])])
+        for _ in range(int(rs.randint(0, 15))):         # clutter
+            dets.append([rs.uniform(-30, w), rs.uniform(-30, h), rs.uniform(10, 200), rs.uniform(10, 300)])
+        scores = np.round(rs.rand(len(dets)), 2)        # two decimals: plenty of exact ties
+        for d, sc in zip(dets, scores):
+            annots.append({"category_id": 1, "bbox": [float(v) for v in d], "image_id": name, "iscrowd": False,
+                           "area": float(d[2] * d[3]), "id": aid, "score": float(sc)})
+            aid += 1
+    coco = {"images": [im for k, im in enumerate(images) if k != 5], "annotations": annots,
+            "categories": [{"id": 1, "name": "person"}]}
+    return records, coco
+
+
+def golden_evaluator():
+    """Tier O1: tools/crowdhuman_eval.py is pure numpy and imports with zero shims.  Fixture = the synthetic
+    GT/detection files (data) + AP / MR / recall / tp / fp and the curves the reference computes from them."""
+    import importlib.util
+    import json
+    d = os.path.join(OUT, "crowdhuman_eval")
+    os.makedirs(d, exist_ok=True)
+    records, coco = evaluator_dataset()
+    gt_file, dt_file = os.path.join(d, "gt.odgt"), os.path.join(d, "det.json")
+    with open(gt_file, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in records) + "\n")
+    with open(dt_file, "w") as f:
+        json.dump(coco, f)
+    spec = importlib.util.spec_from_file_location("ref_crowdhuman_eval", "/root/reference/tools/crowdhuman_eval.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = {}
+    for rm in (False, True):
+        for vis in (False, True):
+            mod.gt_path = gt_file          # Database.__init__ reads the module-level name (crowdhuman_eval.py:368,372)
+            db = mod.Database(gt_file, dt_file, "boxes", None, 0, rm, visible_flag=vis)
+            db.compare()
+            ap, recall, data = db.eval_AP()
+            mr, _, (tp, fp) = db.eval_MR(fppiX=data[-2], fppiY=data[-1])
+            key = "rm%d_vis%d" % (rm, vis)
+            res[key + "_summary"] = np.array([ap, mr, recall, tp, fp], dtype=np.float64)
+            res[key + "_labels"] = np.array([it[1] for it in db.scorelist], dtype=np.int8)
+            res[key + "_scores"] = np.array([it[0][-1] for it in db.scorelist], dtype=np.float64)
+            res[key + "_recall"] = np.array(data[0], dtype=np.float64)
+            res[key + "_precision"] = np.array(data[1], dtype=np.float64)
+            print("evaluator", key, res[key + "_summary"])
+    np.savez_compressed(os.path.join(OUT, "crowdhuman_eval.npz"), **res)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["amg", "decoder", "encoder", "pipeline"]
+    which = sys.argv[1:] or ["amg", "decoder", "encoder", "pipeline", "evaluator"]
     for w in which:
         globals()["golden_" + w]()

@@ -125,3 +125,24 @@ def test_state_dict_layout_and_adapter_load():
     adapter = {k[len("mask_decoder."):]: v for k, v in sd.items() if k.startswith("mask_decoder.")}
     res = sam.mask_decoder.load_state_dict(adapter, strict=False)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_batch_eval_convert_to_coco_schema():
+    """tools/batch_eval.py:31-58: ids = file_name[:-4], xyxy -> xywh, area from xyxy, running annotation ids."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "own_batch_eval", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "batch_eval.py"))
+    be = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(be)
+    gt = {"images": [{"file_name": "a,1.jpg", "id": 7, "width": 10, "height": 20},
+                     {"file_name": "b,2.jpg", "id": 9, "width": 30, "height": 40}], "categories": [{"id": 1}]}
+    rows = np.array([[1, 2, 3, 12, 23, 0.5], [0, 1, 1, 5, 9, 0.9], [1, 0, 0, 4, 4, 0.25]], np.float32)
+    res = be.rows_to_results(rows, 2)
+    assert res[0]["boxes"] == [[1.0, 1.0, 5.0, 9.0]] and res[1]["scores"] == [0.5, 0.25]
+    coco = be.convert_to_coco(res, gt)
+    assert [im["id"] for im in coco["images"]] == ["a,1", "b,2"]
+    a = coco["annotations"]
+    assert [x["id"] for x in a] == [0, 1, 2] and [x["image_id"] for x in a] == ["a,1", "b,2", "b,2"]
+    assert a[0]["bbox"] == [1.0, 1.0, 4.0, 8.0] and a[0]["area"] == 32.0 and a[1]["bbox"] == [2.0, 3.0, 10.0, 20.0]
+    assert coco["categories"] == [{"id": 1}]

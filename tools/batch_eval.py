@@ -23,13 +23,28 @@ from crowdsam.utils import load_config, load_coco_index, load_img_and_annotation
 from crowdsam_amd.distributed import detections_to_rows, gather_rows, shard_range  # noqa: E402
 
 
-def convert_to_coco(rows, names):
-    """rows [n,6] = (image_index, x0,y0,x1,y1, score) -> COCO detection list (tools/batch_eval.py:31-58)."""
-    out = []
+def convert_to_coco(det_result, gt_js):
+    """Per-image results [{image_id, boxes (xyxy), scores}] + the GT json -> COCO detection dict, as the reference's
+    tools/batch_eval.py:31-58: image ids become file_name[:-4], boxes xywh, running annotation ids."""
+    images = gt_js["images"]
+    for im in images:
+        im["id"] = im["file_name"][:-4]
+    annots = []
+    for k, item in enumerate(det_result):
+        image_id = images[k]["id"] if images else item["image_id"]
+        for score, box in zip(item["scores"], item["boxes"]):
+            x0, y0, x1, y1 = (float(v) for v in box)
+            annots.append({"category_id": 1, "bbox": [x0, y0, x1 - x0, y1 - y0], "image_id": image_id, "iscrowd": False,
+                           "area": (y1 - y0) * (x1 - x0), "id": len(annots), "score": float(score)})
+    return {"images": images, "annotations": annots, "categories": gt_js.get("categories", [])}
+
+
+def rows_to_results(rows, n_images):
+    """Gathered rows [n,6] = (image_index, x0,y0,x1,y1, score) -> the per-image list tools/test.py writes."""
+    out = [{"image_id": i, "boxes": [], "scores": []} for i in range(n_images)]
     for r in rows:
-        x0, y0, x1, y1 = [float(v) for v in r[1:5]]
-        name = names[int(r[0])]
-        out.append({"image_id": name[:-4], "category_id": 1, "bbox": [x0, y0, x1 - x0, y1 - y0], "score": float(r[5])})
+        out[int(r[0])]["boxes"].append([float(v) for v in r[1:5]])
+        out[int(r[0])]["scores"].append(float(r[5]))
     return out
 
 
@@ -71,9 +86,19 @@ def main(argv=None):
         rows.append(detections_to_rows(i, out["boxes"], out["scores"]))
     allrows = gather_rows(np.concatenate(rows))
     if rank == 0:
+        gt_js = {"images": [{"file_name": n, "width": 1024, "height": 1024} for n in names], "categories": []} \
+            if args.synthetic else json.load(open(config["data"]["json_file"]))
+        coco_json = convert_to_coco(rows_to_results(allrows, len(names)), gt_js)
         with open(args.output, "w") as f:
-            json.dump(convert_to_coco(allrows, names), f)
+            json.dump(coco_json, f, ensure_ascii=True)
         logger.info("wrote %d detections over %d images to %s", len(allrows), len(names), args.output)
+        odgt = config.get("data", {}).get("odgt_file") if not args.synthetic else None
+        if odgt and os.path.exists(odgt):
+            # the reference shells out to tools/crowdhuman_eval.py (-d test.json -g odgt --remove_empty_gt
+            # --visible_flag, :100-103); same numbers here straight from the gathered rows, matching on the GPU
+            from crowdsam_amd import evaluate as ev
+            r = ev.evaluate(odgt, coco_json, remove_empty_gt=True, visible_flag=True)
+            logger.info("AP: %.4f, MR: %.4f, Recall: %.4f, tp: %d, fp: %d", r["AP"], r["MR"], r["recall"], r["tp"], r["fp"])
     if world > 1:
         dist.destroy_process_group()
 
