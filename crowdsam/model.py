@@ -90,6 +90,7 @@ class CrowdSAM:
         self.min_mask_region_area = t["min_mask_region_area"]
         self.pos_sim_thresh = t["pos_sim_thresh"]
         self.output_rles = t["output_rles"]
+        self.mask_nms_thresh = float(t.get("mask_nms_thresh", 0.0))     # build's opt-in knob, see _process_crop
         if self.mask_selection != "max_iou":
             raise NotImplementedError("only mask_selection='max_iou' (the shipped config) runs on the fused HIP path")
         if self.apply_box_offsets or self.fuse_simmap:
@@ -232,6 +233,10 @@ class CrowdSAM:
 
         keep = batched_nms(data["boxes"].float(), data["iou_preds"], None, self.box_nms_thresh)
         data.filter(keep)
+        if self.mask_nms_thresh > 0 and len(data["masks"]) > 0:
+            # opt-in (test.mask_nms_thresh, off in the shipped config): the coverage NMS on 150x150 masks the
+            # reference defines but never calls (crowdsam/utils.py:422-467), on device
+            data.filter(hip.mask_nms(data["masks"], data["iou_preds"], self.mask_nms_thresh))
         t0 = self._tick("nms", t0)
         if self.min_mask_region_area > 0:
             data = self.postprocess_small_regions(data, self.min_mask_region_area,

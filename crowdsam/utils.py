@@ -201,5 +201,28 @@ def evaluate_boxes(pred_boxes, pred_scores, gt_boxes, score_thresh=0.5, iou_thre
     return tp, gt_used
 
 
+def coverage(mask1, mask2):
+    """max(inter/|A|, inter/|B|) over the last two dims (reference: crowdsam/utils.py:460-469)."""
+    inter = (mask1 * mask2).sum([-1, -2])
+    return torch.maximum(inter / mask1.sum([-1, -2]), inter / mask2.sum([-1, -2]))
+
+
+def mask_iou(mask1, mask2):
+    """Mask IoU over the last two dims (reference: crowdsam/utils.py:471-478)."""
+    return torch.logical_and(mask1, mask2).sum([-1, -2]) / torch.logical_or(mask1, mask2).sum([-1, -2])
+
+
+def mask_iou_nms(boxes, scores, mask_preds, threshold):
+    """Coverage NMS on 150x150 nearest-resampled masks (reference: crowdsam/utils.py:422-458; `boxes` is unused
+    there as well).  Runs in csam_mask_nms; returns the kept original indices in descending-score order."""
+    if mask_preds.numel() == 0:
+        return []
+    from crowdsam_amd import hip
+    dev = mask_preds.device if mask_preds.is_cuda else torch.device("cuda")
+    keep = hip.mask_nms(mask_preds.to(dev).bool(), torch.as_tensor(np.asarray(scores), dtype=torch.float32, device=dev),
+                        threshold)
+    return keep.cpu().numpy()
+
+
 def visualize_result(*a, **k):
     raise NotImplementedError("visualisation is out of scope of the MI355X hot-path build (SURVEY.md §2 #12)")

@@ -118,6 +118,91 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mask "coverage" NMS (crowdsam/utils.py:422-467 mask_iou_nms + coverage): every mask is nearest-resampled
+// to 150x150 (F.interpolate default mode: src = min(floorf(dst * (float)in / 150), in - 1)), then greedily in
+// descending score a mask is dropped when max(inter/|A|, inter/|B|) > thr against a KEPT mask (fp32 division
+// of the integer counts, NaN from an empty mask never suppresses -- torch.maximum / `>` semantics).
+// Here: 150x150 bits packed into 352 64-bit words per mask (ballot), the N x N intersections are AND+popcount
+// over LDS-staged column tiles, and the sequential part is the same single-wave bitmap scan box NMS uses.
+// ---------------------------------------------------------------------------------------------
+constexpr int MN_SIDE = 150, MN_BITS = MN_SIDE * MN_SIDE, MN_WORDS = (MN_BITS + 63) / 64;   // 352
+constexpr int MN_CHUNK = 32;                                                                 // words per LDS stage
+
+__global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restrict__ masks, int H, int W,
+                                                        uint64_t* __restrict__ packed, int* __restrict__ area) {
+  const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint8_t* m = masks + (long)n * H * W;
+  const float sh = (float)H / (float)MN_SIDE, sw = (float)W / (float)MN_SIDE;
+  int cnt = 0;
+  for (int w = wave; w < MN_WORDS; w += 4) {
+    const int idx = w * 64 + lane;
+    bool bit = false;
+    if (idx < MN_BITS) {
+      const int y = idx / MN_SIDE, x = idx - y * MN_SIDE;
+      const int sy = min((int)floorf((float)y * sh), H - 1), sx = min((int)floorf((float)x * sw), W - 1);
+      bit = m[(long)sy * W + sx] != 0;
+    }
+    const unsigned long long word = __ballot(bit);
+    if (lane == 0) packed[(long)n * MN_WORDS + w] = word;
+    cnt += __popcll(word);
+  }
+  __shared__ int part[4];
+  if (lane == 0) part[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) area[n] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(64) void mask_cov_kernel(const uint64_t* __restrict__ packed, const int* __restrict__ area,
+                                                      const int* __restrict__ order, int N, int nw, float thr,
+                                                      uint64_t* __restrict__ mask) {
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (cb < rb) return;
+  __shared__ uint64_t cols[64][MN_CHUNK];
+  const int t = threadIdx.x;
+  const int i = rb * 64 + t;
+  const uint64_t* myrow = packed + (long)order[min(i, N - 1)] * MN_WORDS;
+  int acc[64];
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) acc[jj] = 0;
+  for (int c0 = 0; c0 < MN_WORDS; c0 += MN_CHUNK) {
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < MN_CHUNK; ++k) {                   // 64 masks x 32 words, 256 contiguous bytes per mask
+      const int e = k * 64 + t, mj = e / MN_CHUNK, w = e % MN_CHUNK;
+      const int j = cb * 64 + mj;
+      cols[mj][w] = j < N ? packed[(long)order[j] * MN_WORDS + c0 + w] : 0ull;
+    }
+    uint64_t r[MN_CHUNK];
+#pragma unroll
+    for (int w = 0; w < MN_CHUNK; ++w) r[w] = myrow[c0 + w];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 64; ++jj) {
+      int a = acc[jj];
+#pragma unroll
+      for (int w = 0; w < MN_CHUNK; ++w) a += __popcll(r[w] & cols[jj][w]);   // LDS broadcast reads
+      acc[jj] = a;
+    }
+  }
+  if (i >= N) return;
+  const int ai = area[order[i]];
+  uint64_t bits = 0;
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) {
+    const int j = cb * 64 + jj;
+    if (j > i && j < N) {
+      const int aj = area[order[j]];
+      if (ai > 0 && aj > 0) {                              // 0/0 = NaN in the reference: never suppresses
+        const float inter = (float)acc[jj];
+        const float c = fmaxf(inter / (float)ai, inter / (float)aj);
+        if (c > thr) bits |= 1ull << jj;
+      }
+    }
+  }
+  mask[(long)i * nw + cb] = bits;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column-major RLE (amg.py:107-135 mask_to_rle_pytorch): positions i in [1, H*W) of the
 // Fortran-order flattening (i = x*H + y) where the value changes.  Thread = column; pass 1 counts
 // per column, pass 2 writes the sorted positions at the exclusive-scan offsets.
@@ -209,6 +294,44 @@ extern "C" int csam_box_nms(void* stream, const float* boxes, const float* score
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s, boxes, order, N, nw, thr, mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 64 * nw * 8, s, mask, order, N, nw, out_keep, out_count);
   CSAM_LAUNCH_CHECK("csam_box_nms");
+  return CSAM_OK;
+}
+
+extern "C" long csam_mask_nms_workspace_bytes(int N) {
+  const long nw = (N + 63) / 64;
+  return (long)N * MN_WORDS * 8 + (long)N * nw * 8 + (long)N * 4 * 2 + 256;
+}
+
+extern "C" int csam_mask_nms(void* stream, const void* masks_u8, const float* scores, int N, int H, int W, float thr,
+                             long* out_keep, int* out_count, void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(masks_u8 && scores && out_keep && out_count && workspace, "csam_mask_nms: null pointer");
+  CSAM_REQUIRE(N > 0 && N <= NMS_MAX && H > 0 && W > 0, "csam_mask_nms: bad shape N=%d H=%d W=%d", N, H, W);
+  if (workspace_bytes < csam_mask_nms_workspace_bytes(N)) {
+    csam_set_error("csam_mask_nms: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nw = (N + 63) / 64;
+  int NP = 1;
+  while (NP < N) NP <<= 1;
+  char* w = (char*)workspace;
+  uint64_t* packed = (uint64_t*)w;
+  w += (long)N * MN_WORDS * 8;
+  uint64_t* mask = (uint64_t*)w;
+  w += (long)N * nw * 8;
+  int* order = (int*)w;
+  int* area = order + N;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX * 8);
+    hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mask_pack_kernel, dim3(N), dim3(256), 0, s, (const uint8_t*)masks_u8, H, W, packed, area);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), NP * 8, s, scores, N, NP, order);
+  hipLaunchKernelGGL(mask_cov_kernel, dim3(nw, nw), dim3(64), 0, s, packed, area, order, N, nw, thr, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 64 * nw * 8, s, mask, order, N, nw, out_keep, out_count);
+  CSAM_LAUNCH_CHECK("csam_mask_nms");
   return CSAM_OK;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_mask_nms": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _L],
     "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
@@ -68,6 +69,7 @@ LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
+    "csam_mask_nms_workspace_bytes": [_I],
     "csam_small_regions_workspace_bytes": [_I, _I, _I],
     "csam_t2i_fused_workspace_bytes": [_I],
     "csam_flash_attn_workspace_bytes": [_I, _I],
@@ -481,6 +483,22 @@ def small_regions(masks, min_area):
     call("csam_small_regions", _stream(), _ptr(m8), _ptr(out), _ptr(changed), _ptr(boxes), n, H, W, int(min_area),
          _ptr(ws), nbytes)
     return out, changed, boxes
+
+
+def mask_nms(masks, scores, thr):
+    """Coverage NMS over 150x150 nearest-resampled masks (crowdsam/utils.py mask_iou_nms).  masks u8/bool [N,H,W],
+    scores f32 [N] -> kept indices int64 (device) in descending-score order."""
+    N, H, W = masks.shape
+    if N == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=masks.device)
+    m8 = (masks.view(torch.uint8) if masks.dtype == torch.bool else masks).contiguous()
+    nbytes = lib().csam_mask_nms_workspace_bytes(N)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=masks.device)
+    keep = torch.empty((N,), dtype=torch.int64, device=masks.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=masks.device)
+    call("csam_mask_nms", _stream(), _ptr(m8), _ptr(scores.float().contiguous()), N, H, W, float(thr), _ptr(keep),
+         _ptr(count), _ptr(ws), nbytes)
+    return keep[: int(count.item())]
 
 
 def rle_encode(masks):

@@ -180,6 +180,11 @@ long csam_box_nms_workspace_bytes(int N);
  * suppress IoU > thr; kept indices (int64) in descending-score order; N <= 16384. */
 int csam_box_nms(void* stream, const float* boxes, const float* scores, int N, float thr, long* out_keep,
                  int* out_count, void* workspace, long workspace_bytes);
+/* crowdsam/utils.py:422-467 mask_iou_nms + coverage (opt-in test.mask_nms_thresh): masks nearest-resampled to
+ * 150x150, greedy in descending score, drop when max(inter/|A|, inter/|B|) > thr against a kept mask; N <= 16384 */
+long csam_mask_nms_workspace_bytes(int N);
+int csam_mask_nms(void* stream, const void* masks_u8, const float* scores, int N, int H, int W, float thr,
+                  long* out_keep, int* out_count, void* workspace, long workspace_bytes);
 /* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes */
 int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals);
 int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,

@@ -289,6 +289,46 @@ def evaluator_dataset(seed=0, n_img=14):
     return records, coco
 
 
+def mask_nms_inputs(seed=11, n=48, hw=(97, 211)):
+    """Overlapping blob masks (several near-duplicates, one empty mask) with distinct scores."""
+    rs = np.random.RandomState(seed)
+    H, W = hw
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((n, H, W), bool)
+    for i in range(n):
+        if i % 3 == 1:                                   # jittered copy of the previous blob
+            cy, cx, ry, rx = prev
+            cy, cx = cy + rs.uniform(-4, 4), cx + rs.uniform(-6, 6)
+            ry, rx = ry * rs.uniform(0.7, 1.2), rx * rs.uniform(0.7, 1.2)
+        else:
+            cy, cx, ry, rx = rs.uniform(0, H), rs.uniform(0, W), rs.uniform(4, 30), rs.uniform(4, 50)
+        prev = (cy, cx, ry, rx)
+        masks[i] = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1
+    masks[17] = False
+    scores = rs.permutation(n).astype(np.float32) / n
+    return masks, scores
+
+
+def golden_mask_nms():
+    """Tier O2 import (crowdsam/utils.py pulls cv2 / loguru / torchvision at module level; none of them is touched
+    by the three functions captured here, which are pure torch/numpy)."""
+    _install_shims()
+    sys.path.insert(0, "/root/reference")
+    import importlib
+    ru = importlib.import_module("crowdsam.utils")
+    assert ru.__file__.startswith("/root/reference")
+    masks, scores = mask_nms_inputs()
+    mt = torch.from_numpy(masks)
+    res = {"masks_packed": np.packbits(masks), "shape": np.array(masks.shape), "scores": scores}
+    for thr in (0.3, 0.5, 0.8):
+        res["keep_%02d" % int(thr * 100)] = np.asarray(ru.mask_iou_nms(torch.zeros(len(masks), 4), scores, mt, thr))
+    a, b = mt[:8].unsqueeze(1), mt[None, 8:20]
+    res["coverage"] = ru.coverage(a, b).numpy()
+    res["mask_iou"] = ru.mask_iou(a, b).numpy()
+    np.savez_compressed(os.path.join(OUT, "mask_nms.npz"), **res)
+    print("mask_nms", {k: (v.shape if hasattr(v, "shape") else v) for k, v in res.items() if k.startswith("keep")})
+
+
 def golden_evaluator():
     """Tier O1: tools/crowdhuman_eval.py is pure numpy and imports with zero shims.  Fixture = the synthetic
     GT/detection files (data) + AP / MR / recall / tp / fp and the curves the reference computes from them."""
@@ -326,6 +366,6 @@ def golden_evaluator():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["amg", "decoder", "encoder", "pipeline", "evaluator"]
+    which = sys.argv[1:] or ["amg", "decoder", "encoder", "pipeline", "evaluator", "mask_nms"]
     for w in which:
         globals()["golden_" + w]()

@@ -111,6 +111,33 @@ def remove_small_regions(mask, area_thresh, mode):
     return np.isin(regions, fill), True
 
 
+def coverage(mask1, mask2):
+    """crowdsam/utils.py:460-469: max(inter/|A|, inter/|B|) over the last two dims (fp32 true division of counts)."""
+    inter = (mask1 * mask2).sum([-1, -2])
+    return torch.maximum(inter / mask1.sum([-1, -2]), inter / mask2.sum([-1, -2]))
+
+
+def mask_iou(mask1, mask2):
+    """crowdsam/utils.py:471-478."""
+    return torch.logical_and(mask1, mask2).sum([-1, -2]) / torch.logical_or(mask1, mask2).sum([-1, -2])
+
+
+def mask_iou_nms(boxes, scores, mask_preds, threshold):
+    """crowdsam/utils.py:422-458: masks nearest-resampled to 150x150, greedy in descending score (stable order here:
+    the reference's np.argsort default leaves tie order unspecified), a mask is dropped when its coverage with any
+    kept mask exceeds the threshold.  -> kept original indices in descending-score order."""
+    if mask_preds.numel() == 0:
+        return []
+    m = torch.nn.functional.interpolate(mask_preds.float().unsqueeze(0), (150, 150))[0].bool()
+    order = np.argsort(-np.asarray(scores), kind="stable").tolist()
+    keep = []
+    for i in order:
+        if keep and torch.any(coverage(m[i].unsqueeze(0), m[keep]) > threshold):
+            continue
+        keep.append(i)
+    return np.array(keep)
+
+
 def generate_crop_boxes(im_size, n_layers, overlap_ratio):
     """amg.py:200-234."""
     crop_boxes, layer_idxs = [], []
