@@ -93,8 +93,8 @@ class CrowdSAM:
         self.mask_nms_thresh = float(t.get("mask_nms_thresh", 0.0))     # build's opt-in knob, see _process_crop
         if self.mask_selection != "max_iou":
             raise NotImplementedError("only mask_selection='max_iou' (the shipped config) runs on the fused HIP path")
-        if self.apply_box_offsets or self.fuse_simmap:
-            raise NotImplementedError("apply_box_offsets / fuse_simmap are off in the shipped config and not built")
+        if self.apply_box_offsets:
+            raise NotImplementedError("apply_box_offsets is off in the shipped config (the decoder has no offset head)")
         self.timings = {}
         self.last_candidates = 0
 
@@ -163,6 +163,7 @@ class CrowdSAM:
         sim = hip.bilinear_f32(sim[0], (g, g))                           # [C,g,g]
         sim = hip.sigmoid_max(sim.view(sim.shape[0], g * g)).view(g, g)
         self.sim_map = sim
+        self.sim_feat_size = (int(feat_size[0]), int(feat_size[1]))
         sim_c = sim[: int(feat_size[0]), : int(feat_size[1])].cpu()      # one small D2H
         coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
         inv_factor = torch.tensor([feat_size[1] / w, feat_size[0] / h])
@@ -242,7 +243,13 @@ class CrowdSAM:
             data = self.postprocess_small_regions(data, self.min_mask_region_area,
                                                   max(self.box_nms_thresh, self.crop_nms_thresh))
         t0 = self._tick("small_regions", t0)
-        data["scores"] = data["iou_preds"]
+        if self.fuse_simmap:
+            # crowdsam/model.py:273-286: score = sqrt(iou) * sqrt(clamp(mean of the resized prior over the mask + 0.5))
+            fh, fw = self.sim_feat_size
+            cls = torch.clamp(hip.mask_mean_bilinear(data["masks"], self.sim_map[:fh, :fw]) + 0.5, 0, 1)
+            data["scores"] = data["iou_preds"] ** 0.5 * cls ** 0.5
+        else:
+            data["scores"] = data["iou_preds"]
         data["rles"] = mask_to_rle_arrays(data["masks"])    # run lengths as ndarrays -> C string packer
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]

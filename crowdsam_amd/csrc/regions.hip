@@ -315,9 +315,71 @@ __global__ void cc_finish_kernel(const RegionMeta* meta, const int* ext, int n, 
   for (int k = 0; k < 4; ++k) boxes[i * 4 + k] = empty ? 0.f : (float)e[k];
 }
 
+// fuse_simmap (crowdsam/model.py:273-286): mean over a mask's pixels of the prompt-prior map bilinearly resized
+// (align_corners = False) from [fh,fw] to the frame.  The resized map is never materialised: each set pixel
+// samples the small map (L1/L2 resident); partial sums in float64, one atomic pair per block.
+__global__ __launch_bounds__(256) void mask_mean_bilinear_kernel(const uint8_t* __restrict__ masks,
+                                                                 const float* __restrict__ sim, int fh, int fw, int lds,
+                                                                 int H, int W, double* __restrict__ sum,
+                                                                 int* __restrict__ cnt) {
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int segs = H * sw;
+  const int per = (segs + gridDim.x - 1) / gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * per, s1 = min(segs, s0 + per);
+  const float sy = (float)fh / (float)H, sx = (float)fw / (float)W;
+  double acc = 0.0;
+  int n = 0;
+  for (int sg = s0 + wave; sg < s1; sg += 4) {
+    const int y = sg / sw;
+    const int x = (sg - y * sw) * 64 + lane;
+    if (x < W && masks[base + (long)y * W + x]) {
+      const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.f);
+      const int y0 = min((int)fy, fh - 1), x0 = min((int)fx, fw - 1);
+      const int y1 = min(y0 + 1, fh - 1), x1 = min(x0 + 1, fw - 1);
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      const float top = sim[y0 * lds + x0] * (1.f - lx) + sim[y0 * lds + x1] * lx;
+      const float bot = sim[y1 * lds + x0] * (1.f - lx) + sim[y1 * lds + x1] * lx;
+      acc += (double)(top * (1.f - ly) + bot * ly);
+      ++n;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_xor(acc, off);
+    n += __shfl_xor(n, off);
+  }
+  __shared__ double racc[4];
+  __shared__ int rn[4];
+  if (lane == 0) { racc[wave] = acc; rn[wave] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tn = rn[0] + rn[1] + rn[2] + rn[3];
+    if (tn) {
+      atomicAdd(sum + blockIdx.y, (racc[0] + racc[1]) + (racc[2] + racc[3]));
+      atomicAdd(cnt + blockIdx.y, tn);
+    }
+  }
+}
+
 inline long align256(long v) { return (v + 255) & ~255L; }
 
 }  // namespace
+
+extern "C" int csam_mask_mean_bilinear(void* stream, const uint8_t* masks, int n, int H, int W, const float* sim, int fh,
+                                       int fw, int ld_sim, double* sum, int* count) {
+  CSAM_REQUIRE(masks && sim && sum && count && n > 0 && n <= 65535 && H > 0 && W > 0 && fh > 0 && fw > 0 && ld_sim >= fw,
+               "csam_mask_mean_bilinear: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(sum, 0, (size_t)n * sizeof(double), s);
+  hipMemsetAsync(count, 0, (size_t)n * sizeof(int), s);
+  const int segs = H * ((W + 63) >> 6);
+  const dim3 grid(std::min(std::min(std::max(1024 / n, 16), 256), std::max(1, segs / 8)), n);
+  hipLaunchKernelGGL(mask_mean_bilinear_kernel, grid, dim3(256), 0, s, masks, sim, fh, fw, ld_sim, H, W, sum, count);
+  CSAM_LAUNCH_CHECK("csam_mask_mean_bilinear");
+  return CSAM_OK;
+}
 
 extern "C" long csam_small_regions_workspace_bytes(int n, int H, int W) {
   if (n <= 0 || H <= 0 || W <= 0) return 0;

@@ -55,6 +55,7 @@ SIGNATURES = {
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_mask_nms": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _L],
     "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
+    "csam_mask_mean_bilinear": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
@@ -466,6 +467,21 @@ def caltech_match(dt, dt_off, gt, gt_off, gt_npos, thres):
     call("csam_caltech_match", _stream(), _ptr(dt), _ptr(dt_off), _ptr(gt), _ptr(gt_off), _ptr(gt_npos), n_img, max_pos,
          float(thres), _ptr(label), _ptr(pos))
     return label, pos
+
+
+def mask_mean_bilinear(masks, sim):
+    """Mean over each mask's pixels of `sim` ([fh,fw] f32, may be a strided view of a wider map) resized bilinearly
+    to the mask frame; 0 for an empty mask.  masks u8/bool [n,H,W] -> f32 [n]."""
+    n, H, W = masks.shape
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.float32, device=masks.device)
+    m8 = (masks.view(torch.uint8) if masks.dtype == torch.bool else masks).contiguous()
+    assert sim.dtype == torch.float32 and sim.stride(1) == 1
+    s = torch.empty((n,), dtype=torch.float64, device=masks.device)
+    c = torch.empty((n,), dtype=torch.int32, device=masks.device)
+    call("csam_mask_mean_bilinear", _stream(), _ptr(m8), n, H, W, _ptr(sim), sim.shape[0], sim.shape[1], sim.stride(0),
+         _ptr(s), _ptr(c))
+    return torch.where(c > 0, s / c.clamp(min=1), torch.zeros_like(s)).float()
 
 
 def small_regions(masks, min_area):

@@ -205,6 +205,11 @@ int csam_caltech_match(void* stream, const double* dt, const long* dt_off, const
                        const int* gt_npos, int n_img, int max_pos, double thres, signed char* label,
                        unsigned char* pos);
 
+/* fuse_simmap (crowdsam/model.py:273-286): sum / count over every mask's pixels of the [fh,fw] prior map resized
+ * bilinearly (align_corners False) to H x W; masks u8 [n,H,W], sim f32 rows of stride ld_sim, sum f64 [n], count i32 [n] */
+int csam_mask_mean_bilinear(void* stream, const uint8_t* masks, int n, int H, int W, const float* sim, int fh, int fw,
+                            int ld_sim, double* sum, int* count);
+
 /* host helper (HOST pointers): COCO compressed-RLE string of run lengths (amg.py:294-300 / pycocotools
  * rleToString); returns the length or -1 when cap is too small (13 chars per run always suffice) */
 long csam_coco_rle_string(const long long* counts, long n, char* out, long cap);

@@ -212,7 +212,7 @@ def pipeline_image():
     return synth.synthetic_crowd_frame(3, size=1024, n_ellipses=60)[:768]   # 768 x 1024 (h x w)
 
 
-def golden_pipeline():
+def golden_pipeline(fuse=False):
     import importlib
     _install_shims()
     ref_import.load_modeling()
@@ -225,6 +225,7 @@ def golden_pipeline():
     cs = object.__new__(model_mod.CrowdSAM)
     cfg = dict(po.DEFAULT_TEST_CFG)
     cfg.update(PIPE_CFG)
+    cfg["fuse_simmap"] = fuse
     cs.device = torch.device("cpu")
     cs.train_free = False
     cs.predictor = predictor
@@ -236,8 +237,15 @@ def golden_pipeline():
         out = cs.generate(img)
     res = {k: out[k] for k in ("boxes", "scores", "categories", "points", "stability_score")}
     rle_counts = np.array([r["counts"] for r in out["rles"]], dtype=object)
-    np.savez_compressed(os.path.join(OUT, "pipeline_test128.npz"), rle_counts=rle_counts, **res)
-    print("pipeline", {k: v.shape for k, v in res.items()}, out["scores"][:5])
+    name = "pipeline_test128_fuse.npz" if fuse else "pipeline_test128.npz"
+    np.savez_compressed(os.path.join(OUT, name), rle_counts=rle_counts, **res)
+    print("pipeline", name, {k: v.shape for k, v in res.items()}, out["scores"][:5])
+
+
+def golden_pipeline_fuse():
+    """Same run with test.fuse_simmap = True (crowdsam/model.py:273-286; its hard-coded .cuda() is the identity
+    under the trap-2 shim)."""
+    golden_pipeline(fuse=True)
 
 
 def evaluator_dataset(seed=0, n_img=14):

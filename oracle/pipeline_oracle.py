@@ -138,6 +138,18 @@ def mask_iou_nms(boxes, scores, mask_preds, threshold):
     return np.array(keep)
 
 
+def fuse_simmap_scores(masks, iou_preds, sim_map, image_hw):
+    """crowdsam/model.py:273-286: per mask the mean of the bilinearly resized prior map over its pixels (0 when
+    empty), clamp(+0.5, 0, 1), score = sqrt(iou) * sqrt(cls)."""
+    hi = F.interpolate(sim_map.unsqueeze(0).unsqueeze(0), tuple(image_hw), mode="bilinear")[0, 0]
+    cls = []
+    for m in masks:
+        c = hi[m].mean() if m.sum() > 0 else torch.tensor(0.)
+        cls.append(torch.clamp(c + 0.5, 0, 1))
+    cls = torch.stack(cls) if cls else torch.zeros(0)
+    return iou_preds ** 0.5 * cls ** 0.5
+
+
 def generate_crop_boxes(im_size, n_layers, overlap_ratio):
     """amg.py:200-234."""
     crop_boxes, layer_idxs = [], []
@@ -295,6 +307,7 @@ class OracleCrowdSAM:
         sim = F.interpolate(sim, (g, g), mode="bilinear")
         sim = sim.sigmoid().max(dim=1)[0]
         sim = sim[0, :feat_size[0], :feat_size[1]]
+        self._sim = sim
         fg = sim > cfg["pos_sim_thresh"]
         coords = fg.nonzero()[:, [1, 0]]
         inv = torch.tensor([feat_size[1] / self.image.shape[1], feat_size[0] / self.image.shape[0]])
@@ -386,7 +399,10 @@ class OracleCrowdSAM:
         if cfg["min_mask_region_area"] > 0:
             data = self.postprocess_small_regions(data, cfg["min_mask_region_area"],
                                                   max(cfg["box_nms_thresh"], cfg["crop_nms_thresh"]))
-        data["scores"] = data["iou_preds"]
+        if cfg["fuse_simmap"]:
+            data["scores"] = fuse_simmap_scores(data["masks"], data["iou_preds"], self._sim, self.image.shape[:2])
+        else:
+            data["scores"] = data["iou_preds"]
         rles = mask_to_rle(data["masks"])
         boxes = data["boxes"] / self.downscale + torch.tensor([[0, 0, 0, 0]])
         points_out = data["points"] / self.downscale + torch.tensor([[0, 0]])

@@ -105,6 +105,22 @@ def test_full_pipeline_matches_reference(sd):
         assert int((a != b).sum()) <= 4
 
 
+def test_full_pipeline_fuse_simmap_matches_reference(sd):
+    """Same with test.fuse_simmap = True: scores = sqrt(iou) * sqrt(clamp(mean prior over the mask + 0.5))."""
+    from oracle.make_goldens import PIPE_CFG, StandInDino, pipeline_image
+    g = _load("pipeline_test128_fuse.npz")
+    D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
+    np.random.seed(42)
+    cfg = dict(PIPE_CFG)
+    cfg["fuse_simmap"] = True
+    o = po.OracleCrowdSAM(sd, (depth, heads, gidx), StandInDino(), cfg, rng=np.random)
+    with torch.no_grad():
+        out = o.generate(pipeline_image())
+    np.testing.assert_array_equal(out["boxes"], g["boxes"])
+    np.testing.assert_array_equal(out["points"], g["points"])
+    np.testing.assert_allclose(out["scores"], g["scores"], rtol=1e-5, atol=1e-6)
+
+
 def po_counts(r):
     return _coco_decode(r["counts"])
 

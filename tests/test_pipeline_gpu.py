@@ -93,3 +93,53 @@ def test_generate_dense_sweep_matches_oracle(model, cuda):
     np.testing.assert_allclose(out["scores"][ka], ref["scores"][kb], rtol=0, atol=5e-3)
     assert np.abs(out["boxes"][ka] - ref["boxes"][kb]).max() <= 3
     assert np.all(np.diff(out["scores"]) <= 0)
+
+
+def test_generate_fuse_simmap_matches_reference_golden(cuda):
+    """test.fuse_simmap = True: prior-fused scores against the reference's own run."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG, pipeline_image
+    cfg = dict(PIPE_CFG)
+    cfg["fuse_simmap"] = True
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    g = np.load(os.path.join(G, "pipeline_test128_fuse.npz"), allow_pickle=True)
+    np.random.seed(42)
+    out = m.generate(pipeline_image())
+    assert out["boxes"].shape == g["boxes"].shape
+    np.testing.assert_array_equal(out["points"], g["points"])
+    np.testing.assert_allclose(out["scores"], g["scores"], rtol=0, atol=5e-3)
+
+
+def test_mask_mean_bilinear_matches_oracle(cuda):
+    from crowdsam_amd import hip
+    from oracle import pipeline_oracle as po
+    rs = np.random.RandomState(0)
+    H, W, fh, fw = 683, 1024, 43, 64
+    sim_full = torch.from_numpy(rs.rand(64, 64).astype(np.float32))
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.stack([((yy - rs.uniform(0, H)) / rs.uniform(5, 200)) ** 2 + ((xx - rs.uniform(0, W)) / rs.uniform(5, 300)) ** 2 <= 1
+                      for _ in range(9)] + [np.zeros((H, W), bool), np.ones((H, W), bool)])
+    iou = torch.from_numpy(rs.rand(len(masks)).astype(np.float32))
+    ref = po.fuse_simmap_scores(torch.from_numpy(masks), iou, sim_full[:fh, :fw], (H, W))
+    mean = hip.mask_mean_bilinear(torch.from_numpy(masks).to(cuda), sim_full.to(cuda)[:fh, :fw])
+    got = iou.to(cuda) ** 0.5 * torch.clamp(mean + 0.5, 0, 1) ** 0.5
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_generate_two_crop_layers_runs(cuda):
+    """crop_n_layers = 1: 1 + 4 crops, cross-crop NMS preferring small crops, per-crop rles_info
+    kept as a per-crop record (the reference index-filters that list and raises once > 2*n_crops masks survive)."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG, pipeline_image
+    cfg = dict(PIPE_CFG)
+    cfg.update(crop_n_layers=1, crop_nms_thresh=0.7, max_prompts=16)
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    np.random.seed(1)
+    img = pipeline_image()
+    out = m.generate(img)
+    b = out["boxes"]
+    assert b.ndim == 2 and b.shape[1] == 4 and len(out["scores"]) == len(b) == len(out["rles"])
+    assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= img.shape[1]).all() and (b[:, 3] <= img.shape[0]).all()
+    assert "crop_boxes" not in out
