@@ -506,6 +506,103 @@ __global__ __launch_bounds__(256) void pool_adjoint_v2_kernel(const float* __res
   }
 }
 
+// MFMA version of the same re-association: out = U^T E U with E = exp(x - max) in fp16 and U the dense form of
+// the (banded) 256 -> 73 adjoint taps.  ONE WAVE PER PLANE, no LDS traffic for the data and no barriers:
+//   T[Y,tj]   = sum_X E[Y,X] U[X,tj]    A = E rows straight from global (exp on the fly), B = packed U blocks
+//   out[ti,tj] = sum_Y U[Y,ti] T[Y,tj]   B = the fp16 T accumulators of two Y tiles (register chaining, the
+//                                        k-permutation is baked into the packed A blocks on the host)
+// Only the (tile, k-step) blocks the band touches are stored and multiplied (13 + 13 of 40 + 40).  The kernel
+// is then bound by the one fp32 read of the logits (1 MB / prompt) instead of LDS taps and 128 barriers.
+// band of the 256 -> 73 geometry: tile j of 16 coarse indices touches the 32-wide fine k-steps ADJ_LO[j]..ADJ_HI[j];
+// blocks are stored in (tile, k-step) order, so block id = ADJ_BASE[j] + kx - ADJ_LO[j]
+__device__ constexpr int ADJ_LO[5] = {0, 1, 3, 5, 6}, ADJ_HI[5] = {1, 3, 5, 7, 7}, ADJ_BASE[5] = {0, 2, 5, 8, 11};
+
+struct AdjMfma {
+  int idx1[5][8];          // block of (tj tile, X k-step) in blk1, or -1
+  int idx2[5][8];          // block of (ti tile, Y k-step) in blk2, or -1
+  int pad[48];
+  half8_t blk1[16][64];    // B fragments: lane (tj = 16j + l&15, g): U[32kx + 8g + e][tj]
+  half8_t blk2[16][64];    // A fragments: lane (ti = 16i + l&15, g): U[(2s + (e>=4))*16 + 4g + (e&3)][ti]
+};
+
+__global__ __launch_bounds__(256, 1) void pool_adjoint_mfma_kernel(const float* __restrict__ masks,
+                                                                   float* __restrict__ stats,
+                                                                   const AdjMfma* __restrict__ tab,
+                                                                   half_t* __restrict__ wout, long ldw, int rows) {
+  __shared__ AdjMfma T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < (int)(sizeof(AdjMfma) / 16); i += 256) ((floatx4*)&T)[i] = ((const floatx4*)tab)[i];
+  __syncthreads();
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const float L2E = 1.4426950408889634f;
+  const float nmx = -stats[r * 2] * L2E;
+  const float* src = masks + (r << 16) + fr * 256 + fg * 8;
+  floatx4 acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float esum = 0.f;
+#pragma unroll 1
+  for (int s = 0; s < 8; ++s) {
+    floatx4 t[2][5];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* rowp = src + (2 * s + h) * 16 * 256;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) t[h][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) {              // k-step outer: one E fragment live at a time
+        const floatx4 a = *(const floatx4*)(rowp + kx * 32), b = *(const floatx4*)(rowp + kx * 32 + 4);
+        half8_t ef;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ea = exp2f(fmaf(a[e], L2E, nmx)), eb = exp2f(fmaf(b[e], L2E, nmx));
+          esum += ea + eb;
+          ef[e] = (half_t)ea;
+          ef[4 + e] = (half_t)eb;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j)      // static band (checked against the host tables at launch): straight-line MFMAs
+          if (kx >= ADJ_LO[j] && kx <= ADJ_HI[j])
+            t[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ef, T.blk1[ADJ_BASE[j] + kx - ADJ_LO[j]][lane], t[h][j], 0, 0, 0);
+      }
+    }
+    half8_t tb[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tb[j][e] = (half_t)t[0][j][e];
+        tb[j][4 + e] = (half_t)t[1][j][e];
+      }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (s >= ADJ_LO[i] && s <= ADJ_HI[i]) {       // wave-uniform
+        const half8_t af = T.blk2[ADJ_BASE[i] + s - ADJ_LO[i]][lane];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, tb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  esum = csam_wave_sum(esum);
+  if (lane == 0) stats[r * 2 + 1] = esum;
+  half_t* o = wout + r * ldw;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tj = j * 16 + fr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ti = i * 16 + fg * 4 + e;
+        if (ti < 73 && tj < 73) o[ti * 73 + tj] = (half_t)acc[i][j][e];
+      }
+    }
+}
+
 // pooled[r,c] = P[r,c] / sum[r] + bias[c]
 __global__ __launch_bounds__(256) void rowscale_bias_kernel(const float* __restrict__ P,
                                                             const float* __restrict__ stats,
@@ -638,6 +735,18 @@ extern "C" int csam_pool_adjoint_v2(void* stream, const float* masks, float* sta
   hipLaunchKernelGGL(pool_adjoint_v2_kernel, dim3(rows), dim3(256), smem, (hipStream_t)stream, masks, stats,
                      (const AdjTaps*)taps_dev, (half_t*)w_f16, ldw);
   CSAM_LAUNCH_CHECK("csam_pool_adjoint_v2");
+  return CSAM_OK;
+}
+
+extern "C" int csam_adj_mfma_bytes(void) { return (int)sizeof(AdjMfma); }
+
+// MFMA variant of csam_pool_adjoint_v2 (same contract); tables_dev: an AdjMfma built by the host from the taps
+extern "C" int csam_pool_adjoint_mfma(void* stream, const float* masks, float* stats, const void* tables_dev,
+                                      void* w_f16, long ldw, int rows) {
+  CSAM_REQUIRE(masks && stats && tables_dev && w_f16 && rows > 0 && ldw >= 5329, "csam_pool_adjoint_mfma: bad args");
+  hipLaunchKernelGGL(pool_adjoint_mfma_kernel, dim3(csam_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, masks, stats,
+                     (const AdjMfma*)tables_dev, (half_t*)w_f16, ldw, rows);
+  CSAM_LAUNCH_CHECK("csam_pool_adjoint_mfma");
   return CSAM_OK;
 }
 

@@ -52,6 +52,46 @@ def _adjoint_taps(n_in=73, n_out=256):
     return torch.from_numpy(buf.copy())
 
 
+def _adjoint_mfma_tables(n_in=73, n_out=256):
+    """The same U^T as dense MFMA operand blocks (struct AdjMfma of decoder.hip): only the (16-wide tile, 32-deep
+    k-step) blocks the band touches are stored; blk2 carries the register-chaining k-permutation."""
+    raw = _adjoint_taps(n_in, n_out).numpy()
+    x0 = raw[:292].view(np.int32)
+    n = raw[292:584].view(np.int32)
+    w = raw[584:].view(np.float32).reshape(73, 8)
+    U = np.zeros((n_out, 80), np.float32)                 # U[X, t], t padded to 5 tiles of 16
+    for t in range(n_in):
+        U[x0[t]:x0[t] + n[t], t] = w[t, :n[t]]
+    lane = np.arange(64)
+    fr, fg = lane & 15, lane >> 4
+    e = np.arange(8)
+    idx1 = -np.ones((5, 8), np.int32)
+    idx2 = -np.ones((5, 8), np.int32)
+    blk1, blk2 = [], []
+    for j in range(5):
+        for k in range(8):
+            X = 32 * k + 8 * fg[:, None] + e[None, :]                                     # [64, 8]
+            b = U[X, (16 * j + fr)[:, None]]
+            if np.any(b != 0):
+                idx1[j, k] = len(blk1)
+                blk1.append(b)
+            Y = (2 * k + (e[None, :] >= 4)) * 16 + 4 * fg[:, None] + (e[None, :] & 3)
+            a = U[Y, (16 * j + fr)[:, None]]
+            if np.any(a != 0):
+                idx2[j, k] = len(blk2)
+                blk2.append(a)
+    assert len(blk1) <= 16 and len(blk2) <= 16
+    band = -np.ones((5, 8), np.int32)                    # the static band compiled into pool_adjoint_mfma_kernel
+    for j, (lo, hi, base) in enumerate(zip((0, 1, 3, 5, 6), (1, 3, 5, 7, 7), (0, 2, 5, 8, 11))):
+        band[j, lo:hi + 1] = base + np.arange(hi - lo + 1)
+    assert np.array_equal(idx1, band) and np.array_equal(idx2, band), "adjoint band differs from the compiled one"
+    pack = lambda bl: np.concatenate([np.stack(bl), np.zeros((16 - len(bl), 64, 8), np.float32)]).astype(np.float16)
+    buf = np.concatenate([idx1.reshape(-1).view(np.uint8), idx2.reshape(-1).view(np.uint8), np.zeros(48 * 4, np.uint8),
+                          pack(blk1).reshape(-1).view(np.uint8), pack(blk2).reshape(-1).view(np.uint8)])
+    assert buf.size == hip.lib().csam_adj_mfma_bytes()
+    return torch.from_numpy(buf.copy())
+
+
 def _kperm(K):
     """Column permutation that lets fp16 accumulator registers of one MFMA feed the next MFMA's B operand
     directly: k' = s*32 + g*8 + e  <->  k = (2s + (e>=4))*16 + g*4 + (e&3)   (decoder_fused.hip)."""
@@ -158,6 +198,7 @@ class DecoderPlan:
         self.dino_proj_w = f16(sd[M + "dino_proj.weight"])
         self.dino_proj_b = f32(sd[M + "dino_proj.bias"])
         self.taps = _adjoint_taps().to(device)
+        self.adj_tables = _adjoint_mfma_tables().to(device)
         self.state = None
         self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
@@ -366,7 +407,7 @@ class DecoderPlan:
         # ---- PWD-Net pooling + classifier (:186-192)
         R = B * 4
         if self.fused:      # plane max already in stats[:,0] (upscale kernel atomics); one pass over the logits
-            hip.pool_adjoint_v2(masks, ws["stats"], self.taps, ws["wadj"], R)
+            hip.pool_adjoint_mfma(masks, ws["stats"], self.adj_tables, ws["wadj"], R)
         else:
             hip.softmax_stats(masks, ws["stats"], R)
             hip.pool_adjoint(masks, ws["stats"], self.taps, ws["wadj"], R)

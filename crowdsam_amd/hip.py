@@ -61,6 +61,7 @@ SIGNATURES = {
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
+    "csam_pool_adjoint_mfma": [_P, _P, _P, _P, _P, _L, _I],
     "csam_t2i_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L],
     "csam_t2i_merge_launch": [_P, _P, _P, _I, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
@@ -99,6 +100,7 @@ def lib():
             fn.argtypes = argt
             fn.restype = _L
         L.csam_adj_taps_bytes.restype = _I
+        L.csam_adj_mfma_bytes.restype = _I
         _lib = L
     return _lib
 
@@ -568,6 +570,10 @@ def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B, s
     call("csam_upscale_fused", _stream(), _ptr(keys), _ptr(W1), _ptr(b1), _ptr(ln_g), _ptr(ln_b), float(eps),
          _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), _ptr(stats), B)
     return masks
+
+
+def pool_adjoint_mfma(masks, stats, tables, w, rows):
+    call("csam_pool_adjoint_mfma", _stream(), _ptr(masks), _ptr(stats), _ptr(tables), _ptr(w), w.stride(0), rows)
 
 
 def pool_adjoint_v2(masks, stats, taps, w, rows):

@@ -124,6 +124,11 @@ int csam_pool_adjoint(void* stream, const float* masks, const float* stats, cons
 /* one-pass variant: stats[r][0] = plane max (from csam_upscale_fused), writes stats[r][1] = sum exp */
 int csam_pool_adjoint_v2(void* stream, const float* masks, float* stats, const void* taps_dev, void* w_f16, long ldw,
                          int rows);
+/* the same on the matrix cores: out = U^T exp(x - max) U with the banded U packed into MFMA fragment blocks by the
+ * host (csam_adj_mfma_bytes() bytes, layout in decoder.hip); one wave per plane, bound by the fp32 read of the logits */
+int csam_adj_mfma_bytes(void);
+int csam_pool_adjoint_mfma(void* stream, const float* masks, float* stats, const void* tables_dev, void* w_f16,
+                           long ldw, int rows);
 int csam_rowscale_bias(void* stream, const float* P, const float* stats, const float* bias, float* out, int rows,
                        int N);
 

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_ctypes_table_matches_header():
     from crowdsam_amd import hip
-    bound = set(hip.SIGNATURES) | set(hip.LONG_RETURNS) | {"csam_abi_version", "csam_last_error", "csam_adj_taps_bytes"}
+    bound = set(hip.SIGNATURES) | set(hip.LONG_RETURNS) | {"csam_abi_version", "csam_last_error", "csam_adj_taps_bytes", "csam_adj_mfma_bytes"}
     assert set(_declared()) == bound
 
 
