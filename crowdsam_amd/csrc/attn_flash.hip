@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
                                                          float scale) {
   // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
   // batched GEMM;  Th[q][kh] = traw[q][qh - kh + 63],  Tw[q][kw] = traw[q][128 + qw - kw + 63]
-  // LDS: 2 stages x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 32 KB, filled by global_load_lds
-  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+  // LDS: 3-deep ring x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 48 KB, filled by global_load_lds;
+  // tile t+2 is issued while tile t is consumed, the wait per tile is a counted vmcnt (4 loads per lane per stage)
+  __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
   const int head = blockIdx.y;
@@ -138,15 +139,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
     }
   };
   stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (nt > 1) stage(1, 1);
 
   const float sl2 = scale * 1.4426950408889634f;
+  int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // tile t landed for every wave; everybody is done reading tile t-1's buffer
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) stage(cur == 0 ? 2 : cur - 1, t + 2);
     const char* Kc = smem + cur * 16384;
     const char* Vc = Kc + 8192;
+    cur = cur == 2 ? 0 : cur + 1;
 
     floatx4 s[2][4];
     float thv[2] = {0.f, 0.f};
@@ -175,38 +180,47 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
           s[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][ks], s[rt][kt], 0, 0, 0);
       }
     }
-    // ---- online softmax (base 2); lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr
-    const bool tail = (t + 1) * KT > T;
+    // ---- online softmax (base 2); lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr.
+    // VALU-bound part of the kernel (PMC: VALU 72 % busy, MFMA 14 %), so it is kept to max3 / fma / exp / add per
+    // score: the softmax scale lives in the exponent's fma (the running max is tracked on the raw scores, scale > 0),
+    // out-of-range keys are masked on the last tile only, and O is rescaled only when some row's max moved.
+    if ((t + 1) * KT > T) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) s[rt][kt][j] = -INFINITY;
+    }
     half8_t pf[2][2];
+    float alpha[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = s[rt][kt][j] * sl2;
-          if (tail && t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) v = -INFINITY;
-          s[rt][kt][j] = v;
-          mx = fmaxf(mx, v);
-        }
+      float mx = fmaxf(fmaxf(s[rt][0][0], s[rt][0][1]), s[rt][0][2]);
+      mx = fmaxf(fmaxf(mx, s[rt][0][3]), s[rt][1][0]);
+      mx = fmaxf(fmaxf(mx, s[rt][1][1]), s[rt][1][2]);
+      mx = fmaxf(fmaxf(mx, s[rt][1][3]), s[rt][2][0]);
+      mx = fmaxf(fmaxf(mx, s[rt][2][1]), s[rt][2][2]);
+      mx = fmaxf(fmaxf(mx, s[rt][2][3]), s[rt][3][0]);
+      mx = fmaxf(fmaxf(mx, s[rt][3][1]), s[rt][3][2]);
+      mx = fmaxf(mx, s[rt][3][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(m[rt], mx);
-      const float alpha = exp2f(m[rt] - mnew);
+      const float mnew = fmaxf(m[rt], mx);          // raw-score units
+      alpha[rt] = csam_exp2((m[rt] - mnew) * sl2);
       m[rt] = mnew;
+      const float nm = -mnew * sl2;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float e = exp2f(s[rt][kt][j] - mnew);
+          const float e = csam_exp2(fmaf(s[rt][kt][j], sl2, nm));
           s[rt][kt][j] = e;
           ps += e;
         }
-      l[rt] = l[rt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= alpha;
+      l[rt] = l[rt] * alpha[rt] + ps;
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -214,6 +228,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
           pf[rt][st][e] = (half_t)s[rt][2 * st][e];
           pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
         }
+    }
+    if (__ballot(alpha[0] != 1.f || alpha[1] != 1.f) != 0ull) {     // exact: alpha == 1 when no max moved
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= alpha[rt];
     }
     // ---- O^T += V^T P^T: V^T fragment = dims row dt*16+fr, keys 32 st + 8 fg .. +7 (one 16-B read)
 #pragma unroll
@@ -227,8 +247,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
           o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rt][st], o[rt][dt], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
 #pragma unroll

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict_
     for (int kt = 0; kt < 14; ++kt) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float e = exp2f(p[kt][j] - mx);
+        const float e = csam_exp2(p[kt][j] - mx);
         p[kt][j] = e;
         sum += e;
       }

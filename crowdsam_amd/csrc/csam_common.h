@@ -87,6 +87,11 @@ __device__ __forceinline__ float2_t csam_gelu_poly2(float2_t x) {
   return x * ph;
 }
 
+// exp2 for softmax arguments (<= 0, results in (0, 1]): the bare v_exp_f32.  exp2f() wraps it in a denormal-range
+// rescue (compare + 2 selects + ldexp per call) that only matters for results below 2^-126, which a softmax
+// weight may flush to zero.
+__device__ __forceinline__ float csam_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float csam_apply_act(float v, int act) {
   if (act == CSAM_ACT_GELU) return csam_gelu_erf(v);
   if (act == CSAM_ACT_RELU) return v > 0.f ? v : 0.f;

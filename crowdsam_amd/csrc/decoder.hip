@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void attn_t2i_kernel(const half_t* __restrict_
 #pragma unroll
     for (int qi = 0; qi < 7; ++qi) {
       const float mn = fmaxf(m[qi], fmaxf(s0[qi], s1[qi]));
-      const float alpha = exp2f(m[qi] - mn);
-      const float p0 = exp2f(s0[qi] - mn), p1 = exp2f(s1[qi] - mn);
+      const float alpha = csam_exp2(m[qi] - mn);
+      const float p0 = csam_exp2(s0[qi] - mn), p1 = csam_exp2(s1[qi] - mn);
       m[qi] = mn;
       l[qi] = l[qi] * alpha + p0 + p1;
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_t2i_kernel(const half_t* __restrict_
     for (int qi = 0; qi < 7; ++qi) {
       const float mo = __shfl_xor(m[qi], off, 64), lo = __shfl_xor(l[qi], off, 64);
       const float mn = fmaxf(m[qi], mo);
-      const float a = exp2f(m[qi] - mn), bb = exp2f(mo - mn);
+      const float a = csam_exp2(m[qi] - mn), bb = csam_exp2(mo - mn);
       l[qi] = l[qi] * a + lo * bb;
 #pragma unroll
       for (int d = 0; d < 16; ++d) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void t2i_merge_kernel(const float* __restrict__
     const float* src = part + ((((long)b * nparts + p) * 8 + h) * 7 + qi) * T2I_REC;
     const float mo = src[0], lo = src[1];
     const float mn = fmaxf(m, mo);
-    const float a = exp2f(m - mn), bb = exp2f(mo - mn);
+    const float a = csam_exp2(m - mn), bb = csam_exp2(mo - mn);
     l = l * a + lo * bb;
 #pragma unroll
     for (int d = 0; d < 16; ++d) acc[d] = acc[d] * a + src[2 + d] * bb;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_i2t_kernel(const half_t* __restrict_
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      s[j] = exp2f(s[j] - mx);
+      s[j] = csam_exp2(s[j] - mx);
       sum += s[j];
     }
     const float inv = 1.f / sum;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void pool_adjoint_mfma_kernel(const float* 
         half8_t ef;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ea = exp2f(fmaf(a[e], L2E, nmx)), eb = exp2f(fmaf(b[e], L2E, nmx));
+          const float ea = csam_exp2(fmaf(a[e], L2E, nmx)), eb = csam_exp2(fmaf(b[e], L2E, nmx));
           esum += ea + eb;
           ef[e] = (half_t)ea;
           ef[4 + e] = (half_t)eb;

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
       float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float p0 = v0 ? exp2f(s0 - mx) : 0.f, p1 = v1 ? exp2f(s1 - mx) : 0.f;
-      const float p2 = v2 ? exp2f(s2 - mx) : 0.f, p3 = v3 ? exp2f(s3 - mx) : 0.f;
+      const float p0 = v0 ? csam_exp2(s0 - mx) : 0.f, p1 = v1 ? csam_exp2(s1 - mx) : 0.f;
+      const float p2 = v2 ? csam_exp2(s2 - mx) : 0.f, p3 = v3 ? csam_exp2(s3 - mx) : 0.f;
       float sum = (p0 + p1) + (p2 + p3);
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
       half4_t pb;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pe = exp2f(s[mi][ni][e] - m);
+        const float pe = csam_exp2(s[mi][ni][e] - m);
         ls += pe;
         pb[e] = (half_t)pe;
       }
