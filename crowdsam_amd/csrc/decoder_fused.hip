@@ -661,8 +661,8 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
 
 // =====================================================================================================
 // csam_t2i_fused: token->image attention (transformer.py:173-177 and :105-112) with the K/V projections
-// of the per-prompt key state fused in -- K and V never touch HBM.  Per workgroup: 256 tokens of one
-// prompt, 8 waves x 32 tokens.
+// of the per-prompt key state fused in -- K and V never touch HBM.  Per workgroup: 128 tokens of one
+// prompt, 4 waves x 32 tokens, two workgroups per CU.
 //   K^T = Wk X^T            swapped MFMA orientation  -> lane (token fr, 4 consecutive dims)
 //   V   = X Wv^T            NON-swapped orientation    -> lane (dim l&15, 4 consecutive tokens)
 // (same LDS fragments, operands passed in the other order), which makes every later product chain
@@ -671,16 +671,20 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
 //   P   = exp2(S - m_wg)  (m_wg: workgroup-wide max per (query, head) through LDS)
 //   O  += P V     16x16x16, A = the P registers, B = the V registers    -> lane (dim d, queries 4g..)
 // The workgroup writes ONE partial record (m, l, O[16]) per (head, query); csam's merge kernel combines
-// the 16 partials of a prompt.  MODE 0 (layer 0): K / V^T of the shared image embedding are hoisted per
+// the 32 partials of a prompt.  MODE 0 (layer 0): K / V^T of the shared image embedding are hoisted per
 // image and simply loaded in those two layouts.
 // HBM per prompt: read 2 MB keys (+ 65 KB partials) instead of KV GEMM write/read + attention reads (6 MB).
 // =====================================================================================================
 namespace {
 
-constexpr int T2I_TOK = 256;
-constexpr int T2I_STAGE = 128 * 1024;          // 2 x (X 32 KB + W 32 KB)
-constexpr int T2I_QFR = T2I_STAGE;             // [8 h][64 lanes] half4 = 4 KB
-constexpr int T2I_SMEM = T2I_STAGE + 4096;
+constexpr int T2I_NW = 4;                       // waves per workgroup
+constexpr int T2I_TOK = T2I_NW * 32;            // 128 tokens -> 32 partial records per prompt
+constexpr int T2I_PARTS = 4096 / T2I_TOK;
+constexpr int T2I_NS = 3;                       // operand ring depth (K step = 32)
+constexpr int T2I_XB = T2I_TOK * 64, T2I_WB = 256 * 64;
+constexpr int T2I_STG = T2I_XB + T2I_WB;        // 24 KB per stage
+constexpr int T2I_QFR = T2I_NS * T2I_STG;       // [8 h][64 lanes] half4 = 4 KB behind the 72 KB ring
+constexpr int T2I_SMEM = T2I_QFR + 4096;        // 76 KB: two workgroups per CU
 constexpr int T2I_NREC = 18;
 
 struct T2iArgs {
@@ -691,11 +695,14 @@ struct T2iArgs {
   const half_t* K0;           // MODE 0: hoisted K [4096,128] (bias + pe included)
   const half_t* V0T;          // MODE 0: hoisted V^T [128, 4096] (bias included)
   const half_t* q;            // [B,7,128] projected queries
-  float* part;                // [B, 16, 8, 7, 18]
+  float* part;                // [B, T2I_PARTS, 8, 7, 18]
 };
 
+// 4 waves x 32 tokens per workgroup, 76 KB of LDS: two workgroups share a CU, so one's projection-load latency
+// and record tail hide behind the other's MFMA / softmax work (the 8-wave, 132 KB, one-per-CU layout this replaces
+// idled there).  Projection operands go through a 3-deep LDS ring of 32-wide K steps with counted vmcnt.
 template <int MODE>
-__global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
+__global__ __launch_bounds__(256, 2) void t2i_fused_kernel(T2iArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
@@ -704,25 +711,36 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
   half4_t* qfr = (half4_t*)(smem + T2I_QFR);
 
   // per-head q fragments (B operand of S = K q^T): lane (col j = l&15, dims 4g..4g+3); zero for j >= 7
-  {
-    const int h = tid >> 6, l = tid & 63, j = l & 15, g4 = (l >> 4) * 4;
+#pragma unroll
+  for (int i = tid; i < 512; i += 256) {
+    const int h = i >> 6, l = i & 63, j = l & 15, g4 = (l >> 4) * 4;
     half4_t v = {0, 0, 0, 0};
     if (j < 7) v = *(const half4_t*)(p.q + ((long)b * 7 + j) * 128 + h * 16 + g4);
-    qfr[tid] = v;   // 512 threads == 8 heads x 64 lanes
+    qfr[i] = v;
   }
 
   half4_t kf[2][8], vf[2][8];   // fp16 K (A operand of S) and V (B operand of PV) per (mi, head)
   if (MODE == 1) {
     const half_t* Xb = p.X + ((long)b * 4096 + t0) * 256;
-    auto stage = [&](int buf, int k0) {
-      // X: 256 rows x 8 slots = 2048 pieces; W: 256 rows x 8 = 2048 pieces -> 4 + 4 per thread
+    // 64-B LDS rows: slot ^= 3 * ((row >> 2) & 1) on the global source and on the fragment reads
+    const half_t* x_src[2];
+    const half_t* w_src[4];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int cc = tid + it * 512;
-        const int row = cc >> 3, sl = cc & 7;
-        glds16(Xb + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + buf * 65536 + (cc & ~63) * 16);
-        glds16(p.Wkv + (long)row * 256 + k0 + ((sl ^ (row & 7)) * 8), smem + buf * 65536 + 32768 + (cc & ~63) * 16);
-      }
+    for (int it = 0; it < 2; ++it) {              // X: 128 rows x 4 slots = 512 pieces
+      const int cc = tid + it * 256, row = cc >> 2, sl = cc & 3;
+      x_src[it] = Xb + (long)row * 256 + ((sl ^ (3 * ((row >> 2) & 1))) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {              // W: 256 rows x 4 slots = 1024 pieces
+      const int cc = tid + it * 256, row = cc >> 2, sl = cc & 3;
+      w_src[it] = p.Wkv + (long)row * 256 + ((sl ^ (3 * ((row >> 2) & 1))) * 8);
+    }
+    auto stage = [&](int buf, int k0) {
+      char* xb = smem + buf * T2I_STG;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) glds16(x_src[it] + k0, xb + ((tid + it * 256) & ~63) * 16);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) glds16(w_src[it] + k0, xb + T2I_XB + ((tid + it * 256) & ~63) * 16);
     };
     floatx4 ak[2][8], av[2][8];
 #pragma unroll
@@ -732,35 +750,33 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
         ak[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
         av[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
       }
-    const int sw = fr & 7;
+    const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    stage(1, 32);
+    int cur = 0;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < 4) stage(cur ^ 1, (kt + 1) * 64);
-      const char* xb = smem + cur * 65536;
-      const char* wb = xb + 32768;
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt < 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // one later stage (6 loads) may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < 8) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * 32);
+      const char* xb = smem + cur * T2I_STG;
+      const char* wb = xb + T2I_XB;
+      half8_t xf[2];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int coff = ((kk * 4 + fg) ^ sw) << 4;
-        half8_t xf[2];
+      for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const half8_t*)(xb + (wave * 32 + mi * 16 + fr) * 64 + coff);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const half8_t*)(xb + (wave * 32 + mi * 16 + fr) * 128 + coff);
+      for (int ni = 0; ni < 8; ++ni) {
+        const half8_t wk = *(const half8_t*)(wb + (ni * 16 + fr) * 64 + coff);
+        const half8_t wv = *(const half8_t*)(wb + (128 + ni * 16 + fr) * 64 + coff);
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-          const half8_t wk = *(const half8_t*)(wb + (ni * 16 + fr) * 128 + coff);
-          const half8_t wv = *(const half8_t*)(wb + (128 + ni * 16 + fr) * 128 + coff);
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            ak[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk, xf[mi], ak[mi][ni], 0, 0, 0);   // [n][t]
-            av[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mi], wv, av[mi][ni], 0, 0, 0);   // [t][n]
-          }
+        for (int mi = 0; mi < 2; ++mi) {
+          ak[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk, xf[mi], ak[mi][ni], 0, 0, 0);   // [n][t]
+          av[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mi], wv, av[mi][ni], 0, 0, 0);   // [t][n]
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      cur = cur == 2 ? 0 : cur + 1;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -786,12 +802,12 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
         vf[mi][ni] = *(const half4_t*)(p.V0T + (long)(ni * 16 + fr) * 4096 + tb + fg * 4);
       }
     }
-    __syncthreads();   // qfr visible
   }
+  __syncthreads();   // qfr visible; operand ring free (the reduction scratch below aliases it)
 
   // ---- S = K q^T per (mi, head): lane (query j = l&15, tokens 4g+r); workgroup max per (j, head)
-  float* wmax = (float*)smem;                    // [8 waves][8 h][16 j]   (aliases the staging region)
-  float* wred = (float*)(smem + 8192);           // [8 waves][8 h][7 j][17]: l, O[16]
+  float* wmax = (float*)smem;                    // [NW waves][8 h][16 j]
+  float* wred = (float*)(smem + 8192);           // [NW waves][8 h][7 j][17]: l, O[16]
   const float sc = 0.25f * 1.4426950408889634f;
   floatx4 s[2][8];
 #pragma unroll
@@ -816,7 +832,7 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
   for (int ni = 0; ni < 8; ++ni) {
     float m = wmax[ni * 16 + fr];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[(w * 8 + ni) * 16 + fr]);
+    for (int w = 1; w < T2I_NW; ++w) m = fmaxf(m, wmax[(w * 8 + ni) * 16 + fr]);
     mwg[ni] = m;
     o[ni] = floatx4{0.f, 0.f, 0.f, 0.f};
     float ls = 0.f;
@@ -835,8 +851,7 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
     ls += __shfl_xor(ls, 32, 64);
     lsum[ni] = ls;
   }
-  __syncthreads();   // wmax fully consumed before wred (disjoint, but keep phases clean)
-  // per-wave partials -> LDS: O lane = (d = l&15, queries j = 4g+r); l lane = (j = l&15)
+  // per-wave partials -> LDS (disjoint from wmax): O lane = (d = l&15, queries j = 4g+r); l lane = (j = l&15)
 #pragma unroll
   for (int ni = 0; ni < 8; ++ni) {
 #pragma unroll
@@ -847,19 +862,19 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
     if (fg == 0 && fr < 7) wred[((wave * 8 + ni) * 7 + fr) * 17] = lsum[ni];
   }
   // stash the workgroup max per (head, j) for the record writer
-  float* mrec = (float*)(smem + 8192 + 8 * 8 * 7 * 17 * 4);
+  float* mrec = (float*)(smem + 8192 + T2I_NW * 8 * 7 * 17 * 4);
   if (wave == 0 && fg == 0 && fr < 7) {
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) mrec[ni * 7 + fr] = mwg[ni];
   }
   __syncthreads();
-  // reduce the 8 waves (fixed order: deterministic) and write the record
-  for (int i = tid; i < 8 * 7 * 17; i += 512) {
+  // reduce the waves (fixed order: deterministic) and write the record
+  for (int i = tid; i < 8 * 7 * 17; i += 256) {
     const int e = i % 17, hj = i / 17;            // hj = h*7 + j
     float acc = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) acc += wred[(w * 56 + hj) * 17 + e];
-    float* rec = p.part + (((long)b * 16 + tile) * 56 + hj) * T2I_NREC;
+    for (int w = 0; w < T2I_NW; ++w) acc += wred[(w * 56 + hj) * 17 + e];
+    float* rec = p.part + (((long)b * T2I_PARTS + tile) * 56 + hj) * T2I_NREC;
     rec[1 + e] = acc;                              // e == 0 -> l, e >= 1 -> O[e-1]
     if (e == 0) rec[0] = mrec[hj];
   }
@@ -867,9 +882,112 @@ __global__ __launch_bounds__(512) void t2i_fused_kernel(T2iArgs p) {
 
 }  // namespace
 
+// =====================================================================================================
+// csam_t2i_shared: layer-0 token->image attention (transformer.py:173-177 with the shared image embedding).
+// K and V of layer 0 are per-IMAGE constants (hoisted), so the whole prompt batch is one attention problem per
+// head: (7 B) query rows x 4096 keys x 16 dims.  One wave = 16 query rows of one head, flash-style over all keys:
+//   S^T = K_tile Q^T   16x16x16 (K = the head dim: one MFMA per 16 keys)   lane (query l&15, keys 4g..4g+3)
+//   online softmax per 64 keys, scale in the exponent's fma
+//   O^T += V^T_tile P^T  16x16x16, B operand = the P registers            lane (query, dims 4g..4g+3)
+// K / V^T come as per-head tile-contiguous copies (512 B per 16 keys, built once per image), straight from L2 into
+// the MFMA A operands: no LDS, no barriers, no partial records, no merge kernel.
+// =====================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void t2i_shared_kernel(const half_t* __restrict__ q, const half_t* __restrict__ Kh,
+                                                         const half_t* __restrict__ Vh, half_t* __restrict__ out,
+                                                         int R) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int h = blockIdx.y;
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
+  if (row0 >= R) return;
+  const int row = min(row0 + fr, R - 1);
+  const half4_t qb = *(const half4_t*)(q + (long)row * 128 + h * 16 + fg * 4);     // B operand: (query, dims 4g..)
+  // per-head tiles: Kh [8][256 tiles][16 keys][16 d], Vh [8][256 tiles][16 d][16 keys]; lane reads its 8 bytes
+  const half_t* kp = Kh + (long)h * 4096 * 16 + fr * 16 + fg * 4;
+  const half_t* vp = Vh + (long)h * 4096 * 16 + fr * 16 + fg * 4;
+  const float sl2 = 0.25f * 1.4426950408889634f;
+  floatx4 o = {0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  half4_t kf[4], vf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    kf[i] = *(const half4_t*)(kp + i * 256);
+    vf[i] = *(const half4_t*)(vp + i * 256);
+  }
+  for (int step = 0; step < 64; ++step) {
+    half4_t kn[4], vn[4];
+    const int nx = step + 1 < 64 ? step + 1 : step;          // prefetch the next 64 keys
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kn[i] = *(const half4_t*)(kp + (nx * 4 + i) * 256);
+      vn[i] = *(const half4_t*)(vp + (nx * 4 + i) * 256);
+    }
+    floatx4 s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      s[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[i], qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+    mx = fmaxf(fmaxf(mx, s[0][3]), s[1][0]);
+    mx = fmaxf(fmaxf(mx, s[1][1]), s[1][2]);
+    mx = fmaxf(fmaxf(mx, s[1][3]), s[2][0]);
+    mx = fmaxf(fmaxf(mx, s[2][1]), s[2][2]);
+    mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
+    mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
+    mx = fmaxf(mx, s[3][3]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = csam_exp2((m - mnew) * sl2);
+    m = mnew;
+    const float nm = -mnew * sl2;
+    float ps = 0.f;
+    half4_t pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = csam_exp2(fmaf(s[i][e], sl2, nm));
+        ps += pe;
+        pb[i][e] = (half_t)pe;
+      }
+    l = l * alpha + ps;
+    o *= alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[i], pb[i], o, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kf[i] = kn[i];
+      vf[i] = vn[i];
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (row0 + fr < R) {
+    const float inv = 1.f / l;
+    half4_t r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (half_t)(o[e] * inv);
+    *(half4_t*)(out + (long)(row0 + fr) * 128 + h * 16 + fg * 4) = r;
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_t2i_shared(void* stream, const void* q_f16, const void* Kh_f16, const void* Vh_f16, void* out_f16,
+                               int B) {
+  CSAM_REQUIRE(q_f16 && Kh_f16 && Vh_f16 && out_f16 && B > 0, "csam_t2i_shared: bad args");
+  const int R = B * 7;
+  hipLaunchKernelGGL(t2i_shared_kernel, dim3(csam_cdiv(R, 64), 8), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)q_f16, (const half_t*)Kh_f16, (const half_t*)Vh_f16, (half_t*)out_f16, R);
+  CSAM_LAUNCH_CHECK("csam_t2i_shared");
+  return CSAM_OK;
+}
+
 extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
 
-extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * 16 * 56 * T2I_NREC * sizeof(float); }
+extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * T2I_PARTS * 56 * T2I_NREC * sizeof(float); }
 
 extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
                               const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
@@ -892,11 +1010,11 @@ extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f
     hipFuncSetAttribute((const void*)t2i_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_SMEM);
     attr_set = true;
   }
-  dim3 grid(16, B);
+  dim3 grid(T2I_PARTS, B);
   if (X_f16)
-    hipLaunchKernelGGL(t2i_fused_kernel<1>, grid, dim3(512), T2I_SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(t2i_fused_kernel<1>, grid, dim3(T2I_NW * 64), T2I_SMEM, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(t2i_fused_kernel<0>, grid, dim3(512), T2I_SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(t2i_fused_kernel<0>, grid, dim3(T2I_NW * 64), T2I_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_t2i_fused");
-  return csam_t2i_merge_launch(stream, (const float*)workspace, out_f16, B, 16);
+  return csam_t2i_merge_launch(stream, (const float*)workspace, out_f16, B, T2I_PARTS);
 }

@@ -232,7 +232,7 @@ class DecoderPlan:
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=dev)
         f = torch.float32
         self.state = dict(src16=e(T_IMG, 256), srcpe16=e(T_IMG, 256), src32=e(T_IMG, 256, dt=f), kv0=e(T_IMG, 256),
-                          qi0=e(T_IMG, 128), k0=e(T_IMG, 128), v0t=e(128, T_IMG), G=e(N_DINO, 256, dt=f),
+                          qi0=e(T_IMG, 128), k0=e(T_IMG, 128), v0t=e(128, T_IMG), k0h=e(8, 256, 16, 16), v0h=e(8, 256, 16, 16), G=e(N_DINO, 256, dt=f),
                           GT=e(256, N_DINO_PAD), g16=e(N_DINO, 256), fgh=e(N_DINO, 256, dt=f),
                           fg=e(N_DINO, self.n_class, dt=f), feat=None, dtok=None)
         self.state_graph = hip.GraphCache()
@@ -254,6 +254,9 @@ class DecoderPlan:
             # the same hoisted K / V in the two register layouts of the fused kernel: K [4096,128], V^T [128,4096]
             hip.gemm_f16(st["srcpe16"], L0["t2i_kv_w"][:128], out=st["k0"], bias=L0["t2i_kv_b"][:128])
             hip.gemm_f16(L0["t2i_kv_w"][128:], st["src16"], out=st["v0t"], residual=L0["t2i_v_bias_mat"], M=128)
+            # per-head 16-key tiles (512 contiguous bytes each) for csam_t2i_shared
+            st["k0h"].copy_(st["k0"].view(256, 16, 8, 16).permute(2, 0, 1, 3))
+            st["v0h"].copy_(st["v0t"].view(8, 16, 256, 16).permute(0, 2, 1, 3))
             # dino_proj, both orientations: G f32 [5329,256] (+bias) for the FG prior and
             # G^T f16 [256, 5376] (no bias; added after pooling) as the K-contiguous pooling operand.
             hip.gemm_f16(dino_tok16, self.dino_proj_w, out=st["G"], bias=self.dino_proj_b, M=N_DINO)
@@ -300,7 +303,9 @@ class DecoderPlan:
 
         def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None):
             hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
-            if fused_args is not None:
+            if fused_args is not None and "K0" in fused_args:
+                hip.t2i_shared(ws["t2i_q"], st["k0h"], st["v0h"], ws["t2i_o"], B)
+            elif fused_args is not None:
                 hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **fused_args)
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])

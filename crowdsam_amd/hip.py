@@ -61,6 +61,7 @@ SIGNATURES = {
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
+    "csam_t2i_shared": [_P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_mfma": [_P, _P, _P, _P, _P, _L, _I],
     "csam_t2i_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L],
     "csam_t2i_merge_launch": [_P, _P, _P, _I, _I],
@@ -584,6 +585,12 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out
+
+
+def t2i_shared(q, Kh, Vh, out, B):
+    """Layer-0 token->image attention of the whole prompt batch over the per-image K / V tiles."""
+    call("csam_t2i_shared", _stream(), _ptr(q), _ptr(Kh), _ptr(Vh), _ptr(out), B)
     return out
 
 

@@ -148,6 +148,9 @@ long csam_t2i_fused_workspace_bytes(int B);
 int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
                    const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
                    void* workspace, long workspace_bytes);
+/* layer-0 token->image attention over the SHARED (per-image) K / V: q f16 [B,7,128]; Kh f16 [8][256][16 keys][16 d] and
+ * Vh f16 [8][256][16 d][16 keys] = per-head 16-key tiles of the hoisted projections; out f16 [B,7,128] */
+int csam_t2i_shared(void* stream, const void* q_f16, const void* Kh_f16, const void* Vh_f16, void* out_f16, int B);
 int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
 
 /* ---- PWD-Net selection, fused mask post-processing, EPS occupancy */
