@@ -6,6 +6,8 @@ reset_image`` and ``model, dino_model, transform, features, dino_feats, original
 is_image_set, device``.  Per image: ONE H2D copy of the uint8 frame; the encoder, DINOv2 and the
 hoisted decoder constants stay resident in HBM until ``reset_image``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -16,12 +18,16 @@ from crowdsam_amd.dino import DinoV2
 from .utils.transforms import ResizeLongestSide
 
 
+_TWO_STREAMS = os.environ.get("CSAM_TWO_STREAMS", "1") != "0"
+
+
 class SamPredictor:
     def __init__(self, sam_model, dino_model):
         self.model = sam_model
         self.dino_model = dino_model
         self.transform = ResizeLongestSide(sam_model.image_encoder.img_size)
         self._dtok16 = None
+        self._side_stream = None
         self.reset_image()
 
     # ------------------------------------------------------------------------------------------
@@ -49,12 +55,26 @@ class SamPredictor:
             self.original_size = tuple(original_image_size)
             self.input_size = tuple(transformed_image.shape[-2:])
             raw = transformed_image[0].to(self.device).float().contiguous()      # [3,h,w], 0..255
-            self._feat_tok = self.model.image_encoder.forward_tokens(raw)
             if self._dtok16 is None or self._dtok16.device != raw.device:
                 self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
-            if isinstance(self.dino_model, DinoV2):
+            if isinstance(self.dino_model, DinoV2) and not _TWO_STREAMS:
+                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
                 self.dino_model.patch_tokens16(raw, self._dtok16)
+            elif isinstance(self.dino_model, DinoV2):
+                # the two backbones are independent until the decoder: DINOv2 runs on a side stream next to the SAM
+                # encoder, so one's under-filled launches (N = 1024 GEMMs, LayerNorms, the 2.6-workgroups-per-CU
+                # attention grid) fill the other's idle CUs
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=raw.device)
+                side = self._side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.dino_model.patch_tokens16(raw, self._dtok16)
+                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
+                main.wait_stream(side)
             else:   # third-party DINO object: feed it the reference's tensor (predictor.py:104-106)
+                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
                 x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
                 tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
                 self._dtok16[:N_DINO].copy_(tok.reshape(N_DINO, -1))
