@@ -121,12 +121,18 @@ def main():
     # (the timed region above replays hipGraphs, inside which per-launch events cannot be recorded).
     timer = None
     if not args.no_kernel_timer and rank == 0:
+        # per-launch durations must be the kernel's own: the side stream that overlaps DINOv2 with the SAM encoder in
+        # the timed region would let another kernel share the CUs of the launch being timed
+        import segment_anything_cs.predictor as _pred
+        two = _pred._TWO_STREAMS
+        _pred._TWO_STREAMS = False
         timer = hip.KernelTimer(["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"])
         hip.set_timer(timer)
         for i in range(args.warmup, args.warmup + args.steps):
             model.generate(frames[i])
         torch.cuda.synchronize()
         hip.set_timer(None)
+        _pred._TWO_STREAMS = two
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,7 +170,7 @@ def main():
                                "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
                                "gemm_ms_per_step": ms / args.steps,
                                "note": ("algorithmic 2*M*N*K of every GEMM launch / HIP-event time on the launch stream, measured on an "
-                                        "instrumented repeat of the K timed steps (graph replay disabled)")}
+                                        "instrumented repeat of the K timed steps (graph replay and the DINOv2 side stream disabled)")}
         if not args.no_cpu_baseline and world == 1:
             # CPU port of the path (oracle/) on the host cores, bounded sample, in a subprocess with a hard limit
             import subprocess
