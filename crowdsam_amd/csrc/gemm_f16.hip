@@ -262,6 +262,163 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves in two PING-PONG groups (cdna_hip_programming.md "256^2 8-phase" idea, own schedule):
+// for the wide fp16-output projections (qkv N = 3072, fc1 N = 4096) whose grid is <= one workgroup per CU, where
+// nothing else is resident to hide a workgroup's barrier / LDS-latency bubbles.  Group 1 (waves 4-7, rows
+// 128..255) runs one barrier behind group 0, so while one group issues its ds_reads + global_load_lds the other
+// owns the matrix pipe:
+//     tick 4s   : G0 loads {A rows 0-63 of its half, B}  of stage s     | G1 MFMAs of its previous phase
+//     tick 4s+1 : G0 16 MFMAs                                           | G1 loads ...
+// K step 32 per stage (64-B LDS rows, swizzle slot ^= 3*((row>>2)&1)), 4-slot ring of 32 KB stages, stage s+2 is
+// issued while stage s is consumed (the slot it overwrites was last read two stages earlier, so no WAR race with
+// the lagging group), one counted vmcnt(4) per stage.  Per wave 128 x 64 outputs = 32 accumulator tiles.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int G2_STAGE = 2 * 256 * 64;                  // A 256 rows + W 256 rows, 64 B each
+constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB ring; the 256x256 fp16 output tile reuses it
+
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int gx = p.N / 256;
+  int t = blockIdx.x;
+  if (p.xcd) {
+    const int ntiles = gridDim.x, b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int bn0 = (t % gx) * 256, bm0 = (t / gx) * 256;
+
+  // staging: a stage half (A or W) is 256 rows x 4 slots = 1024 16-B pieces, 2 per thread
+  const half_t* a_src[2];
+  const half_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (wave * 2 + i) * 64 + lane, row = c >> 2, sl = c & 3;
+    const int chunk = sl ^ (3 * ((row >> 2) & 1));
+    int gm = bm0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + (long)gm * p.lda + chunk * 8;
+    w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage_a = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_src[i] + k0, smem + slot * G2_STAGE + (wave * 2 + i) * 1024);
+  };
+  auto stage_w = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(w_src[i] + k0, smem + slot * G2_STAGE + 16384 + (wave * 2 + i) * 1024);
+  };
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
+  const int a_base = (wr * 128 + fr) * 64 + coff;                 // + i * 1024 per 16-row tile
+  const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
+
+  const int nst = p.K / 32;
+  stage_a(0, 0); stage_w(0, 0);
+  stage_a(1, 32); stage_w(1, 32);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                // my share of stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wr == 1) {                                                  // group 1 runs one barrier behind
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int slot = 0;
+  for (int s = 0; s < nst; ++s) {
+    const char* base = smem + slot * G2_STAGE;
+    const int pslot = (slot + 2) & 3;
+    half8_t af[4], wf[4];
+    // ---- phase a: rows 0..63 of the wave's half x all its 64 columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *(const half8_t*)(base + w_base + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
+    if (s + 2 < nst) stage_a(pslot, (s + 2) * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- phase b: rows 64..127, same W fragments
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + (4 + i) * 1024);
+    if (s + 2 < nst) {
+      stage_w(pslot, (s + 2) * 32);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // stage s+1 landed (stage s+2 may be in flight)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot = (slot + 1) & 3;
+  }
+  if (wr == 0) {                                                  // rejoin
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+
+  // ---- epilogue (fp16 out, bias + activation): tile staged in LDS [256 rows][512 B], 32 slots of 16 B, slot ^= row & 31
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wr * 128 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wc * 64 + j * 16 + fg * 4;
+      floatx4 v = acc[i][j];
+      if (p.bias) v += *(const floatx4*)(p.bias + bn0 + col);
+      if (p.act == CSAM_ACT_GELU) {
+        const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
+        v = floatx4{g0[0], g0[1], g1[0], g1[1]};
+      } else if (p.act == CSAM_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      half4_t h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+      const int sl = (col >> 3) ^ (row & 31);
+      *(half4_t*)(smem + row * 512 + sl * 16 + ((col >> 2) & 1) * 8) = h;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int c = tid + it * 512;                    // 256 rows x 32 slots
+    const int row = c >> 5, sl = c & 31;
+    const int m = bm0 + row;
+    if (m < p.M) {
+      const int n = bn0 + ((sl ^ (row & 31)) << 3);
+      *(half8_t*)((half_t*)p.C + (long)m * p.ldc + n) = *(const half8_t*)(smem + c * 16);
+    }
+  }
+}
+
 }  // namespace
 
 static int gemm_launch(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
@@ -296,6 +453,20 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     xcd = x ? atoi(x) : 1;
   }
   p.xcd = xcd;
+  // wide fp16-output projections whose 256x256 grid fits one round of workgroups: the ping-pong kernel
+  static int use256 = -1;
+  if (use256 < 0) {
+    const char* e = getenv("CSAM_GEMM_256");
+    use256 = e ? atoi(e) : 1;
+    hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+  }
+  if (use256 && batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 &&
+      (N / 256) * csam_cdiv(M, 256) <= 256 && K >= 64) {
+    dim3 g256((N / 256) * csam_cdiv(M, 256));
+    hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM, (hipStream_t)stream, p);
+    CSAM_LAUNCH_CHECK("csam_gemm_f16");
+    return CSAM_OK;
+  }
   dim3 grid((N / BN) * csam_cdiv(M, small ? 64 : BM), 1, batch);
 #define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
