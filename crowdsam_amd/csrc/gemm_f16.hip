@@ -271,8 +271,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 //     tick 4s   : G0 loads {A rows 0-63 of its half, B}  of stage s     | G1 MFMAs of its previous phase
 //     tick 4s+1 : G0 16 MFMAs                                           | G1 loads ...
 // K step 32 per stage (64-B LDS rows, swizzle slot ^= 3*((row>>2)&1)), 4-slot ring of 32 KB stages, stage s+2 is
-// issued while stage s is consumed (the slot it overwrites was last read two stages earlier, so no WAR race with
-// the lagging group), one counted vmcnt(4) per stage.  Per wave 128 x 64 outputs = 32 accumulator tiles.
+// issued 2.5 stages ahead of its use (never into a slot the lagging group may still be reading), one counted
+// vmcnt(6) per stage.  Per wave 128 x 64 outputs = 32 accumulator tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int G2_STAGE = 2 * 256 * 64;                  // A 256 rows + W 256 rows, 64 B each
 constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB ring; the 256x256 fp16 output tile reuses it
@@ -321,26 +321,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
 
   const int nst = p.K / 32;
+  // Prefetch runs 2.5 stages ahead: A(s+3) is issued in phase b of stage s, W(s+3) in phase a of stage s+1 -- two
+  // barriers after the last read of the slot they overwrite (stage s-1, lagging group's phase b), and the one wait
+  // per stage is vmcnt(6): three half-stages stay in flight.
   stage_a(0, 0); stage_w(0, 0);
   stage_a(1, 32); stage_w(1, 32);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                // my share of stage 0 has landed
+  if (nst > 2) {
+    stage_a(2, 64);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // my share of stage 0 has landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (wr == 1) {                                                  // group 1 runs one barrier behind
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  const bool noload = (p.xcd & 2) != 0;                           // developer ablation
   int slot = 0;
   for (int s = 0; s < nst; ++s) {
     const char* base = smem + slot * G2_STAGE;
-    const int pslot = (slot + 2) & 3;
     half8_t af[4], wf[4];
     // ---- phase a: rows 0..63 of the wave's half x all its 64 columns
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[j] = *(const half8_t*)(base + w_base + j * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
-    if (s + 2 < nst) stage_a(pslot, (s + 2) * 32);
+    if (s + 2 < nst && !noload) stage_w((slot + 2) & 3, (s + 2) * 32);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -356,9 +364,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // ---- phase b: rows 64..127, same W fragments
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + (4 + i) * 1024);
-    if (s + 2 < nst) {
-      stage_w(pslot, (s + 2) * 32);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // stage s+1 landed (stage s+2 may be in flight)
+    if (s + 3 < nst) {
+      if (!noload) stage_a((slot + 3) & 3, (s + 3) * 32);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // stage s+1 landed; A(s+3), W(s+2), A(s+2) in flight
+    } else if (s + 2 < nst) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
