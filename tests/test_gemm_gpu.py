@@ -70,3 +70,21 @@ def test_gemm_rejects_bad_shapes(cuda):
     w = torch.zeros(128, 60, device=cuda, dtype=torch.float16)
     with pytest.raises(RuntimeError):
         hip.gemm_f16(a, w)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 2048, 64, 0), (300, 2048, 128, 1), (4096, 3072, 1024, 0), (5330, 3072, 1024, 0),
+                                       (4096, 4096, 1024, 1), (1000, 2304, 4096, 2)])
+def test_gemm_pingpong_256(cuda, M, N, K, act):
+    """Shapes that dispatch to the 256x256 ping-pong kernel (fp16 out, no residual, N % 256 == 0, one round of tiles):
+    ragged M, the shortest K the prologue/tail logic allows (2 stages), GELU / ReLU epilogues."""
+    from crowdsam_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(cuda).half()
+    w = (torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).view(N, 1) * 1e-4).to(cuda).half()
+    bias = torch.randn(N, generator=g).to(cuda)
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=torch.float16)
+    hip.gemm_f16(a, w, out=out, bias=bias, act=act)
+    ref = _ref(a, w, bias, act, None, None)
+    assert torch.isfinite(out).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
