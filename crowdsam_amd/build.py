@@ -13,7 +13,7 @@ ARCH = "gfx950"
 # AGPRs and pays a v_accvgpr_read/write per element around the softmax (15 % of the flash-attention loop's VALU issue
 # slots).  Measured per file: +32 % on flash attention, +20 % on windowed attention; neutral or negative on the GEMM
 # and the fused decoder kernels, which keep the default.
-EXTRA_FLAGS = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+EXTRA_FLAGS = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("CSAM_FLASH_DEFS", "").split(),
                "attn_window.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 

@@ -64,8 +64,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
 // below), so the XOR term must separate rows by bits 1 and 3..4 rather than by (row & 7).
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
+#ifndef FLASH_NS
+#define FLASH_NS 3
+#endif
+#ifndef FLASH_OCC
+#define FLASH_OCC 1
+#endif
 template <bool BIAS>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
+__global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
                                                          int q_off, int k_off,
                                                          const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ traw,
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
   // batched GEMM;  Th[q][kh] = traw[q][qh - kh + 63],  Tw[q][kw] = traw[q][128 + qw - kw + 63]
   // LDS: 3-deep ring x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 48 KB, filled by global_load_lds;
   // tile t+2 is issued while tile t is consumed, the wait per tile is a counted vmcnt (4 loads per lane per stage)
-  __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
+  __shared__ __attribute__((aligned(16))) char smem[FLASH_NS * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
   const int head = blockIdx.y;
@@ -139,19 +145,23 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const half_t* __restric
     }
   };
   stage(0, 0);
-  if (nt > 1) stage(1, 1);
+  if (FLASH_NS == 3 && nt > 1) stage(1, 1);
 
   const float sl2 = scale * 1.4426950408889634f;
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (FLASH_NS == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // tile t landed for every wave; everybody is done reading tile t-1's buffer
     asm volatile("" ::: "memory");
-    if (t + 2 < nt) stage(cur == 0 ? 2 : cur - 1, t + 2);
+    if (FLASH_NS == 3) {
+      if (t + 2 < nt) stage(cur == 0 ? 2 : cur - 1, t + 2);
+    } else {
+      if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    }
     const char* Kc = smem + cur * 16384;
     const char* Vc = Kc + 8192;
-    cur = cur == 2 ? 0 : cur + 1;
+    cur = cur + 1 == FLASH_NS ? 0 : cur + 1;
 
     floatx4 s[2][4];
     float thv[2] = {0.f, 0.f};
