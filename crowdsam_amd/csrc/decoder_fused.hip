@@ -175,7 +175,10 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
   // accumulator registers (q -> fp16, P -> fp16); row max / sum need 2 shuffles each.
   half8_t of[2][4];
   const float sc = 0.25f * 1.4426950408889634f;
-  const bool v0 = fg * 4 + 0 < 7, v1 = fg * 4 + 1 < 7, v2 = fg * 4 + 2 < 7, v3 = fg * 4 + 3 < 7;
+  // keys 4 fg + r >= 7 do not exist: a per-lane additive -inf folds the masking into the scale fma (exp2 of -inf is 0)
+  floatx4 mb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mb[r] = fg * 4 + r < 7 ? 0.f : -INFINITY;
   if (p.dbg & 1) {
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni)
@@ -193,19 +196,19 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
       const floatx4 qq = q[mi][ni];
       const half4_t qb = {(half_t)qq[0], (half_t)qq[1], (half_t)qq[2], (half_t)qq[3]};
       floatx4 sacc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka, qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const float s0 = v0 ? sacc[0] * sc : -INFINITY, s1 = v1 ? sacc[1] * sc : -INFINITY;
-      const float s2 = v2 ? sacc[2] * sc : -INFINITY, s3 = v3 ? sacc[3] * sc : -INFINITY;
+      const float s0 = fmaf(sacc[0], sc, mb[0]), s1 = fmaf(sacc[1], sc, mb[1]);
+      const float s2 = fmaf(sacc[2], sc, mb[2]), s3 = fmaf(sacc[3], sc, mb[3]);
       float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float p0 = v0 ? csam_exp2(s0 - mx) : 0.f, p1 = v1 ? csam_exp2(s1 - mx) : 0.f;
-      const float p2 = v2 ? csam_exp2(s2 - mx) : 0.f, p3 = v3 ? csam_exp2(s3 - mx) : 0.f;
+      const float p0 = csam_exp2(s0 - mx), p1 = csam_exp2(s1 - mx);
+      const float p2 = csam_exp2(s2 - mx), p3 = csam_exp2(s3 - mx);
       float sum = (p0 + p1) + (p2 + p3);
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
       const half4_t pb = {(half_t)p0, (half_t)p1, (half_t)p2, (half_t)p3};
       const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const float inv = 1.f / sum;
+      const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
       for (int e = 0; e < 4; ++e) of[mi][ni >> 1][(ni & 1) * 4 + e] = (half_t)(o[e] * inv);
     }
