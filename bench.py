@@ -126,7 +126,10 @@ def main():
         import segment_anything_cs.predictor as _pred
         two = _pred._TWO_STREAMS
         _pred._TWO_STREAMS = False
-        timer = hip.KernelTimer(["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"])
+        GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
+        SWEEP_NAMES = ["csam_i2t_fused", "csam_t2i_fused", "csam_t2i_shared", "csam_upscale_fused",
+                       "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_write"]
+        timer = hip.KernelTimer(GEMM_NAMES + SWEEP_NAMES)
         hip.set_timer(timer)
         for i in range(args.warmup, args.warmup + args.steps):
             model.generate(frames[i])
@@ -158,10 +161,22 @@ def main():
                        "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}"},
         }
         if timer is not None:
-            summ = timer.summary()
+            full = timer.summary()
+            summ = {k: v for k, v in full.items() if k in GEMM_NAMES}
             ms = sum(v["ms"] for v in summ.values())
             work = sum(v["work"] for v in summ.values())
             calls = sum(v["calls"] for v in summ.values())
+            # secondary roofline: the decoder sweep is HBM-bound by construction -- 14.94 MB of
+            # compulsory traffic per prompt (six passes over the 2 MB fp16 key state + logits + mask bytes)
+            sweep_ms = sum(v["ms"] for k, v in full.items() if k in SWEEP_NAMES)
+            if sweep_ms > 0 and args.mode == "dense":
+                gbs = 14.94e6 * n_prompts * args.steps / (sweep_ms * 1e-3) / 1e9
+                res["roofline_decoder_sweep"] = {
+                    "bound": "hbm", "kernel": "fused decoder kernels (i2t / t2i / upscale / pool / mask post)",
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                    "traffic": pmc_traffic("i2t_fused_kernel")[0], "ms_per_step": sweep_ms / args.steps,
+                    "note": "algorithmic 14.94 MB/prompt x prompts / HIP-event time of the sweep kernels; traffic = "
+                            "PMC bytes per launch of the largest of them (i2t)"}
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_note = pmc_traffic("gemm_f16_kernel")
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (csam_gemm_f16*)", "achieved": achieved,
