@@ -44,7 +44,6 @@ struct I2tArgs {
   const float* gamma; const float* beta; float eps;
   half_t* out;                               // keys out [B*4096, 256]
   int T;                                     // 4096
-  int dbg;                                   // developer ablation bits (CSAM_DBG env)
 };
 
 template <int QMODE>
@@ -122,7 +121,6 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!(p.dbg & 4))
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int cur = kt & 1;
@@ -179,14 +177,6 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
   floatx4 mb;
 #pragma unroll
   for (int r = 0; r < 4; ++r) mb[r] = fg * 4 + r < 7 ? 0.f : -INFINITY;
-  if (p.dbg & 1) {
-#pragma unroll
-    for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) of[mi][ni >> 1][(ni & 1) * 4 + e] = (half_t)q[mi][ni][e];
-  } else
 #pragma unroll
   for (int ni = 0; ni < 8; ++ni) {
     const half4_t ka = kfr[ni * 64 + lane];
@@ -214,12 +204,6 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
     }
   }
 
-  if (p.dbg & 2) {
-    half_t* orow = p.out + ((long)b * p.T + t0 + wave * 32 + fr) * 256 + fg * 4;
-    *(half8_t*)orow = of[0][0];
-    *(half8_t*)(orow + 16 * 256) = of[1][0];
-    return;
-  }
   // ---- phase 3: out-proj  D^T = Wo' O^T  (K = 128, N = 256) from the prefetched LDS image of Wo'
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -328,11 +312,6 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
   a.kv_k = (const half_t*)k_f16; a.kv_v = (const half_t*)v_f16;
   a.Wo = (const half_t*)Wo_perm_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("CSAM_DBG_I2T"); dbg = e ? atoi(e) : 0; }
-    a.dbg = dbg;
-  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)i2t_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
