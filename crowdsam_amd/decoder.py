@@ -207,6 +207,7 @@ class DecoderPlan:
     def _alloc(self, B):
         dev = self.device
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=dev)
+        u = (lambda *s: e(1, s[-1])) if self.fused else e      # 8.5 MB / prompt the fused kernels never touch
         f = torch.float32
         BT = B * T_IMG
         self.ws = dict(
@@ -214,8 +215,9 @@ class DecoderPlan:
             q16=e(B * 7, 256), qpe16=e(B * 7, 256), sa_qk=e(B * 7, 512), sa_v=e(B * 7, 256), sa_o=e(B * 7, 256),
             t2i_q=e(B * 7, 128), t2i_o=e(B * 7, 128), mlp_h=e(B * 7, 2048),
             i2t_kv=e(B * 7, 256), i2t_k=e(B * 7, 128), i2t_v=e(B * 7, 128),
-            keysA=e(BT, 256), keysB=e(BT, 256), kv=e(BT, 256), qi=e(BT, 128), att=e(BT, 128),
-            up2=e(BT * 4, 128), masks=e(B, 4, 256, 256, dt=f),
+            keysA=e(BT, 256), keysB=e(BT, 256), masks=e(B, 4, 256, 256, dt=f),
+            # materialised K|V, Q, attention output and up-scaled feature maps: the unfused (round-1 baseline) path only
+            kv=u(BT, 256), qi=u(BT, 128), att=u(BT, 128), up2=u(BT * 4, 128),
             hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
             iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512), cls=e(B * 4, self.n_class, dt=f),
             hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f),
