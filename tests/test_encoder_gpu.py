@@ -107,3 +107,24 @@ def test_encoder_vs_reference_golden(cuda):
     err = np.abs(y[:, ::4, ::4, ::4].numpy() - g["sample"])
     assert err.max() < 5e-2 and err.mean() < 5e-3, (err.max(), err.mean())
     assert abs(float(y.double().abs().sum()) - float(g["abs_sum"])) < 2e-3 * float(g["abs_sum"])
+
+
+@pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
+def test_encoder_real_width_vs_oracle(cuda, D, heads):
+    """Two blocks (one windowed, one global) at the real ViT-B / ViT-L width against the CPU oracle: exercises the
+    production GEMM shapes (256x256 ping-pong kernel for qkv / fc1, 64-row tiles for proj / fc2) end to end."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.encoder import EncoderPlan
+    from oracle import sam_oracle as so
+    specs = [s for s in synth.sam_param_specs(D, 2, heads, (1,)) if s[0].startswith("image_encoder.")]
+    sd = synth.make_state_dict(specs, 5)
+    plan = EncoderPlan(sd, "image_encoder.", D, 2, heads, (1,), cuda)
+    x = torch.from_numpy(np.random.RandomState(1).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(3, 1, 1)
+    feat = plan.forward((x[0] * std + mean).to(cuda).contiguous())
+    y = feat.view(64, 64, 256).permute(2, 0, 1)[None].cpu()
+    with torch.no_grad():
+        ref = so.image_encoder(sd, x, 2, heads, (1,))
+    err = (y - ref).abs()
+    assert err.max().item() < 6e-2 and err.mean().item() < 6e-3, (err.max().item(), err.mean().item())
