@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
   // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
   // batched GEMM;  Th[q][kh] = traw[q][qh - kh + 63],  Tw[q][kw] = traw[q][128 + qw - kw + 63]
   // LDS: 3-deep ring x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 48 KB, filled by global_load_lds;
-  // tile t+2 is issued while tile t is consumed, the wait per tile is a counted vmcnt (4 loads per lane per stage)
+  // tile t+2 is issued while tile t is consumed; every tile is retired (vmcnt(0)) one iteration before it is read
   __shared__ __attribute__((aligned(16))) char smem[FLASH_NS * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
   const float sl2 = scale * 1.4426950408889634f;
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (FLASH_NS == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt(0): with the 3-slot ring this retires tile t+1 one iteration before it is read (a counted wait
+    // followed by a same-phase read of other waves' LDS-DMA data is not safe, see decoder_fused.hip t2i)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // tile t landed for every wave; everybody is done reading tile t-1's buffer
     asm volatile("" ::: "memory");
     if (FLASH_NS == 3) {

@@ -446,8 +446,7 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
     int cur = 0;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
-      if (kt < 7) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // one later stage (5 loads) may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retires stage kt+1 too; it is read one iteration later (see t2i)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt + 2 < 8) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * 32);
@@ -738,8 +737,11 @@ __global__ __launch_bounds__(256, 2) void t2i_fused_kernel(T2iArgs p) {
     int cur = 0;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
-      if (kt < 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // one later stage (6 loads) may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // vmcnt(0), not a counted wait: stage kt+1 (issued one iteration ago) is retired here and read only in the
+      // NEXT iteration.  A counted vmcnt(6) that retires stage kt and reads it right after the barrier was measured
+      // racy (LDS-DMA data of other waves not yet visible: non-repeatable V rows); reads must trail the retiring
+      // counted wait by a phase (cdna_hip_programming.md, 8-phase template rules).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt + 2 < 8) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * 32);

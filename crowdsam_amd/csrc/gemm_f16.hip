@@ -51,21 +51,12 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most `ahead` stages (L loads each) issued after the wanted one are still in flight
-template <int L, int MAXA>
-__device__ __forceinline__ void wait_stage(int ahead) {
-  if constexpr (MAXA == 0) {
-    wait_vmcnt<0>();
-  } else {
-    if (ahead >= MAXA) wait_vmcnt<MAXA * L>();
-    else wait_stage<L, MAXA - 1>(ahead);
-  }
-}
-
 // Tile configuration: WM x WN waves, each owning MI x NI MFMA 16x16 tiles; the workgroup tile is
 // (WM*MI*16) x 128 (WN*NI == 8).  NS = depth of the operand ring in LDS.  Stage kt+NS-1 is issued while stage
-// kt is consumed and the wait before each K step is a COUNTED vmcnt -- the prefetches stay in flight across the
-// (raw) barrier.  Shipped configurations:
+// kt is consumed.  The wait before each K step is vmcnt(0): a counted wait that retires a stage which is then read
+// in the same phase is not safe for other waves' LDS-DMA data (measured in decoder_fused.hip), so with NS = 3 a stage
+// is retired one iteration before its first read and the stage issued after the barrier is the one in flight.
+// Shipped configurations:
 //   <4,4,2,2,2>  128-row tile, 4 waves, 2 x 32 KB: two workgroups per CU
 //   <2,4,2,2,3>   64-row tile, 4 waves, 3 x 24 KB: two workgroups per CU; for grids that would leave CUs idle
 //   <4,2,2,4,4>  128-row tile, 8 waves, 4 x 32 KB: one workgroup per CU, two waves per SIMD, 3 stages in flight
@@ -161,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
     // done reading the buffer of stage kt-1, which the next prefetch overwrites
-    wait_stage<L, NS - 2>(min(NS - 2, nk - 1 - kt));
+    wait_vmcnt<0>();     // NS >= 3: this also retires the stages issued ahead, one iteration before they are read
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
@@ -271,8 +262,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 //     tick 4s   : G0 loads {A rows 0-63 of its half, B}  of stage s     | G1 MFMAs of its previous phase
 //     tick 4s+1 : G0 16 MFMAs                                           | G1 loads ...
 // K step 32 per stage (64-B LDS rows, swizzle slot ^= 3*((row>>2)&1)), 4-slot ring of 32 KB stages, stage s+2 is
-// issued 2.5 stages ahead of its use (never into a slot the lagging group may still be reading), one counted
-// vmcnt(6) per stage.  Per wave 128 x 64 outputs = 32 accumulator tiles.
+// issued ahead of its use (never into a slot the lagging group may still be reading) and retired by ONE counted
+// vmcnt per stage a full phase before anybody reads it.  Per wave 128 x 64 outputs = 32 accumulator tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int G2_STAGE = 2 * 256 * 64;                  // A 256 rows + W 256 rows, 64 B each
 constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB ring; the 256x256 fp16 output tile reuses it
@@ -321,17 +312,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
 
   const int nst = p.K / 32;
-  // Prefetch runs 2.5 stages ahead: A(s+3) is issued in phase b of stage s, W(s+3) in phase a of stage s+1 -- two
-  // barriers after the last read of the slot they overwrite (stage s-1, lagging group's phase b), and the one wait
-  // per stage is vmcnt(6): three half-stages stay in flight.
+  // Prefetch: A(s+3) is issued in phase b of stage s, W(s+3) in phase a of stage s+1 -- two barriers after the last
+  // read of the slot they overwrite (stage s-1, lagging group's phase b).  The one counted wait per stage sits in
+  // phase a and retires stage s+1 while stage s+2 stays in flight.
   stage_a(0, 0); stage_w(0, 0);
   stage_a(1, 32); stage_w(1, 32);
-  if (nst > 2) {
-    stage_a(2, 64);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // my share of stage 0 has landed
-  } else {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  }
+  if (nst > 2) stage_a(2, 64);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // prologue: everything issued so far has landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (wr == 1) {                                                  // group 1 runs one barrier behind
@@ -349,6 +336,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
     if (s + 2 < nst && !noload) stage_w((slot + 2) & 3, (s + 2) * 32);
+    // retire stage s+1 HERE, a full phase (two barriers) before either group reads it: a counted wait followed by
+    // a read in the same phase is not safe for the other waves' LDS-DMA data.  A(s+2) and W(s+2) may stay in flight.
+    if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -364,14 +355,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // ---- phase b: rows 64..127, same W fragments
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + (4 + i) * 1024);
-    if (s + 3 < nst) {
-      if (!noload) stage_a((slot + 3) & 3, (s + 3) * 32);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // stage s+1 landed; A(s+3), W(s+2), A(s+2) in flight
-    } else if (s + 2 < nst) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (s + 3 < nst && !noload) stage_a((slot + 3) & 3, (s + 3) * 32);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsam_hip.so")
+LIB_PATH = os.environ.get("CSAM_LIB") or os.path.join(_HERE, "libcsam_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DT_F16, DT_F32 = 0, 1
