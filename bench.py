@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="vit_l")
     ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--frame", type=int, default=1024, help="synthetic frame side in pixels (BASELINE configs[4]: 1500)")
     ap.add_argument("--points-per-batch", type=int, default=2048,
                     help="prompts per decoder batch (the dense sweep has no pruning, so results do not depend on it; "
                          "the reference's EPS default of 32 is used by the parity tests)")
@@ -94,7 +95,7 @@ def main():
     model = CrowdSAM(config, sam_state_dict=sam_sd, dino_state_dict=dino_sd)
 
     def frame(i):
-        return synth.synthetic_crowd_frame(1000 * rank + i, 1024, 150)
+        return synth.synthetic_crowd_frame(1000 * rank + i, args.frame, 150)
 
     frames = [frame(i) for i in range(args.warmup + args.steps)]
     np.random.seed(42 + rank)
@@ -145,17 +146,19 @@ def main():
         images = args.steps * world
         value = images / elapsed
         res = {
-            "metric": "images/sec (Crowd-SAM dense-prompt inference, 1024^2 image, 64x64 prompt grid, ViT-L)",
+            "metric": "images/sec (Crowd-SAM dense-prompt inference, %d^2 image, %dx%d prompt grid, %s)"
+                      % (1024 if args.frame <= 1024 else args.frame, args.grid, args.grid,
+                         {"vit_l": "ViT-L", "vit_h": "ViT-H", "vit_b": "ViT-B"}.get(args.arch, args.arch)),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("full pipeline per image: SAM %s encoder + DINOv2 ViT-L/14 + %s sweep of a %dx%d "
                                     "prompt grid (%d prompts, %d per decoder batch) + PWD-Net selection + fused mask "
-                                    "post + NMS + small-region clean-up + RLE; synthetic 1024x1024 crowd frames, "
+                                    "post + NMS + small-region clean-up + RLE; synthetic %dx%d crowd frames, "
                                     "seeded random weights; stability_score_thresh %.2f (calibrated so ~half of the "
                                     "prompts survive to NMS with random weights), other thresholds as shipped"
                                     % (args.arch, args.mode, args.grid, args.grid, n_prompts, args.points_per_batch,
-                                       args.stability_thresh)),
+                                       args.frame, args.frame, args.stability_thresh)),
                        "masks_per_sec": value * n_prompts if args.mode == "dense" else None,
                        "kept_masks_per_image": n_kept / args.steps,
                        "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}"},

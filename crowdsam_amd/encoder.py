@@ -15,7 +15,12 @@ class EncoderPlan:
 
     def __init__(self, sd, prefix, embed_dim, depth, heads, global_idx, device):
         D = embed_dim
-        assert D % heads == 0 and D // heads == 64, "HIP attention kernels are specialised for head_dim 64"
+        assert D % heads == 0
+        self.hd = hd = D // heads
+        # head_dim 64 (ViT-B/L) runs the fused flash / window kernels; any other head_dim <= 128 (ViT-H: 80) runs the
+        # materialised gather / batched-GEMM / softmax route of csrc/attn_generic.hip
+        self.fused_attn = hd == 64
+        assert hd <= 128 and hd % 8 == 0, "head_dim must be a multiple of 8, at most 128"
         assert D % 128 == 0, "GEMM tiles need embed_dim % 128 == 0"
         self.D, self.depth, self.heads, self.global_idx = D, depth, heads, tuple(global_idx)
         self.device = device
@@ -38,9 +43,15 @@ class EncoderPlan:
                 lin2_w=f16(sd[B + "mlp.lin2.weight"]), lin2_b=f32(sd[B + "mlp.lin2.bias"]),
                 is_global=i in self.global_idx))
             bl = self.blocks[-1]
-            bl["relcat"] = (hip.relcat_global if bl["is_global"] else hip.relcat_window)(bl["rel_h"], bl["rel_w"])
             L = 127 if i in self.global_idx else 27
-            assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, 64), "rel-pos table must be (2S-1, 64) at 1024^2"
+            assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, hd), "rel-pos table must be (2S-1, head_dim) at 1024^2"
+            if self.fused_attn:
+                bl["relcat"] = (hip.relcat_global if bl["is_global"] else hip.relcat_window)(bl["rel_h"], bl["rel_w"])
+            else:   # [256, 128]: rows 0..L-1 = rel_h, rows 128..128+L-1 = rel_w, head dims zero-padded to 128
+                rc = torch.zeros(256, 128, dtype=torch.float16, device=device)
+                rc[:L, :hd] = bl["rel_h"].to(torch.float16)
+                rc[128:128 + L, :hd] = bl["rel_w"].to(torch.float16)
+                bl["relcat"] = rc
         self.neck0_w = f16(sd[P + "neck.0.weight"].reshape(256, D))
         self.neck1_g, self.neck1_b = f32(sd[P + "neck.1.weight"]), f32(sd[P + "neck.1.bias"])
         # [co, ci, ky, kx] -> [co, (ky*3+kx)*256 + ci] to match csam_im2col3x3
@@ -53,6 +64,11 @@ class EncoderPlan:
             n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
             col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32),
             img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32))
+        if not self.fused_attn:
+            gmax = max(heads * 25 * 256, heads * 4096 if self.global_idx else 0)        # group rows, windowed vs global
+            smax = max(heads * 25 * 256 * 256, heads * 4096 * 4096 if self.global_idx else 0)
+            self.ws.update(gq=e(gmax, 128), gk=e(gmax, 128), gvt=e(gmax * 128), go=e(gmax, 128),
+                           gt=e(gmax, 256, dt=torch.float32), gs=e(smax, dt=torch.float32), gp=e(smax))
         self.graphs = hip.GraphCache()
 
     def forward_static(self, img_chw_f32):
@@ -68,14 +84,16 @@ class EncoderPlan:
         ``skip_im2col``: ws['col'] was already filled (API path with a pre-normalised tensor)."""
         D, nH = self.D, self.heads
         ws = self.ws
-        scale = 64 ** -0.5
+        scale = self.hd ** -0.5
         if not skip_im2col:
             hip.sam_im2col(img_chw_f32, ws["col"])
         x = hip.gemm_f16(ws["col"], self.patch_w, out=ws["x"], bias=self.patch_b, residual=self.pos)
         for b in self.blocks:
             hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
             hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
-            if b["is_global"]:
+            if not self.fused_attn:
+                self._attn_generic(b)
+            elif b["is_global"]:
                 hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)
                 hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"])
             else:
@@ -94,6 +112,21 @@ class EncoderPlan:
         hip.layernorm(ws["n2"], self.neck3_g, self.neck3_b, 1e-6, out=out)
         return out
 
+    def _attn_generic(self, b):
+        """ws['qkv'] -> ws['attn'] for any head_dim <= 128: per (window, head) group, S = (q*scale) k^T and the
+        decomposed rel-pos tables by batched GEMM, softmax+bias kernel, O = P v by batched GEMM
+        (image_encoder.py:224-240, 243-289, 325-361)."""
+        D, nH, hd, ws = self.D, self.heads, self.hd, self.ws
+        glob = b["is_global"]
+        G, Tp, Tv, side = (nH, 4096, 4096, 64) if glob else (nH * 25, 256, 196, 14)
+        scale = hd ** -0.5
+        hip.head_gather(ws["qkv"], b["qkv_b"], ws["gq"], ws["gk"], ws["gvt"], D, nH, hd, Tp, Tv, not glob, scale)
+        hip.gemm_f16_batched(ws["gq"], 128, Tp * 128, b["relcat"], 128, 0, ws["gt"], 256, Tp * 256, Tp, 256, 128, G)
+        hip.gemm_f16_batched(ws["gq"], 128, Tp * 128, ws["gk"], 128, Tp * 128, ws["gs"], Tp, Tp * Tp, Tp, Tp, 128, G)
+        hip.softmax_relpos(ws["gs"], ws["gt"], ws["gp"], G, Tp, Tv, side, 1.0 / scale)
+        hip.gemm_f16_batched(ws["gp"], Tp, Tp * Tp, ws["gvt"], Tp, 128 * Tp, ws["go"], 128, Tp * 128, Tp, 128, Tp, G)
+        hip.head_scatter(ws["go"], ws["attn"], D, nH, hd, Tp, Tv, not glob)
+
     def flops(self):
         """Required FLOPs per image (pad tokens of edge windows are not multiplied: their q/k/v are
         the bias, so QKV/proj run on the 4096 real tokens only)."""
@@ -102,8 +135,8 @@ class EncoderPlan:
         for b in self.blocks:
             f += 2 * 4096 * D * (3 * D + D + 8 * D)
             if b["is_global"]:
-                f += 4 * 4096 * 4096 * 64 * nH + 2 * 4096 * 128 * 64 * nH
+                f += 4 * 4096 * 4096 * self.hd * nH + 2 * 4096 * 128 * self.hd * nH
             else:
-                f += 25 * nH * (4 * 196 * 196 * 64 + 2 * 196 * 28 * 64)
+                f += 25 * nH * (4 * 196 * 196 * self.hd + 2 * 196 * 28 * self.hd)
         f += 2 * 4096 * D * 256 + 2 * 4096 * 2304 * 256
         return f

@@ -61,6 +61,9 @@ SIGNATURES = {
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
+    "csam_head_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F],
+    "csam_softmax_relpos": [_P, _P, _P, _P, _I, _I, _I, _I, _F],
+    "csam_head_scatter": [_P, _P, _P, _I, _I, _I, _I, _I, _I],
     "csam_t2i_shared": [_P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_mfma": [_P, _P, _P, _P, _P, _L, _I],
     "csam_t2i_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L],
@@ -586,6 +589,19 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
     return out
+
+
+def head_gather(qkv, qkv_bias, Qs, K, VT, D, nH, hd, Tp, T_valid, window, scale):
+    call("csam_head_gather", _stream(), _ptr(qkv), _ptr(qkv_bias), _ptr(Qs), _ptr(K), _ptr(VT), D, nH, hd, Tp, T_valid,
+         int(window), float(scale))
+
+
+def softmax_relpos(S, traw, P, G, Tp, T_valid, side, inv_scale):
+    call("csam_softmax_relpos", _stream(), _ptr(S), _ptr(traw), _ptr(P), G, Tp, T_valid, side, float(inv_scale))
+
+
+def head_scatter(O, out, D, nH, hd, Tp, T_valid, window):
+    call("csam_head_scatter", _stream(), _ptr(O), _ptr(out), D, nH, hd, Tp, T_valid, int(window))
 
 
 def t2i_shared(q, Kh, Vh, out, B):

@@ -91,6 +91,17 @@ int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out); /*
 /* relcat_f16 [64,64]: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero (fp16 like the other weights) */
 int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const void* relcat_f16, void* out_f16,
                   int D, int nH, float scale);
+/* generic head_dim (<= 128, multiple of 8; ViT-H: 80) attention = gather / batched GEMMs / softmax / scatter, the
+ * reference's materialised formulation (image_encoder.py:224-289,325-361).  Groups G = nH (global, Tp = 4096) or
+ * 25 windows x nH (Tp = 256, T_valid = 196); operands zero-padded to 128 dims; window pad tokens take the qkv bias. */
+int csam_head_gather(void* stream, const void* qkv_f16, const float* qkv_bias, void* Qs_f16, void* K_f16, void* VT_f16,
+                     int D, int nH, int head_dim, int Tp, int T_valid, int window, float scale);
+/* P = softmax over the T_valid keys of S + (Th[q,kh] + Tw[q,kw]) * inv_scale; relpos_raw f32 [G][Tp][256] = Qs . relcat^T
+ * (Th at [q][qh - kh + side - 1], Tw at [q][128 + qw - kw + side - 1]); side = 64 (global) or 14 (window) */
+int csam_softmax_relpos(void* stream, const float* S, const float* relpos_raw, void* P_f16, int G, int Tp, int T_valid,
+                        int side, float inv_scale);
+int csam_head_scatter(void* stream, const void* O_f16, void* out_f16, int D, int nH, int head_dim, int Tp, int T_valid,
+                      int window);
 /* flash-style global attention, head_dim 64: every DINOv2 block (relpos_raw == NULL, ragged T) and SAM's
  * global blocks: relpos_raw fp32 [nH][4096][256] = q . [rel_pos_h(127) | 0 | rel_pos_w(127) | 0]^T, produced by
  * one csam_gemm_f16_batched over the heads (image_encoder.py:349-350). */

@@ -1,5 +1,5 @@
 """Measurement for the SURVEY 8(f) rows: device kernel vs the CPU oracle on the same inputs (JSON on stdout).
-    python tools/bench_next_rows.py > profiles/r01_next_rows.json"""
+    python tests/measure_next_rows.py > profiles/r01_next_rows.json"""
 import json
 import os
 import sys

@@ -109,10 +109,11 @@ def test_encoder_vs_reference_golden(cuda):
     assert abs(float(y.double().abs().sum()) - float(g["abs_sum"])) < 2e-3 * float(g["abs_sum"])
 
 
-@pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
+@pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16), (640, 8), (1280, 16)])
 def test_encoder_real_width_vs_oracle(cuda, D, heads):
-    """Two blocks (one windowed, one global) at the real ViT-B / ViT-L width against the CPU oracle: exercises the
-    production GEMM shapes (256x256 ping-pong kernel for qkv / fc1, 64-row tiles for proj / fc2) end to end."""
+    """Two blocks (one windowed, one global) at the real ViT-B / ViT-L / ViT-H width against the CPU oracle: exercises
+    the production GEMM shapes (256x256 ping-pong kernel for qkv / fc1, 64-row tiles for proj / fc2) end to end.
+    head_dim 80 (640/8, 1280/16 = ViT-H) takes the materialised attention route of csrc/attn_generic.hip."""
     from crowdsam_amd import synth
     from crowdsam_amd.encoder import EncoderPlan
     from oracle import sam_oracle as so
