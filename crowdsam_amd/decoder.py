@@ -14,6 +14,8 @@ import ctypes
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -107,6 +109,10 @@ class DecoderPlan:
     def __init__(self, sd, device, n_class=1, max_batch=256, fused=True):
         self.device, self.n_class, self.maxB = device, n_class, max_batch
         self.fused = fused     # False: round-1 unfused kernel chain (kept as an A/B and debugging reference)
+        # persistent weight-stationary i2t kernel (csam_i2t_stream): parity-tested, measured EQUAL to the tile-per-workgroup
+        # kernel in round 1 (its eight waves run every phase in lock-step, so the LDS / MFMA / VALU pipes serialise;
+        # DESIGN.md section 6), so the older kernel stays the default
+        self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "0") == "1"
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -157,6 +163,9 @@ class DecoderPlan:
             d["t2i_bv"] = d["t2i_kv_b"][128:].contiguous()
             d["t2i_v_bias_mat"] = d["t2i_bv"].view(128, 1).expand(128, T_IMG).contiguous()
             d["i2t_o_w_perm"] = f16(i2t["o_w"][:, _kperm(128)])
+            # the streaming i2t kernel takes the token-side k pre-multiplied by softmax scale * log2(e) (exp2 units)
+            sc = 0.25 * 1.4426950408889634
+            d["i2t_k_w_s"], d["i2t_k_b_s"] = f16(i2t["k_w"].float() * sc), f32(i2t["k_b"].float() * sc)
             self.layers.append(d)
         fa = attn(T + "final_attn_token_to_image.")
         pk = pe_proj(fa["k_w"])
@@ -345,9 +354,19 @@ class DecoderPlan:
             hip.layernorm(ws["tmp32"][:M7], L["norm3_g"], L["norm3_b"], 1e-5, out=queries)
             # ---- image -> token cross attention (:186-190): keys = LN4(keys + out_proj(attn))
             cast_queries()
-            hip.gemm_f16(qpe16, L["i2t_k_w"], out=ws["i2t_k"][:M7], bias=L["i2t_k_b"])
+            stream = self.fused and self.i2t_stream
+            kw, kb = (L["i2t_k_w_s"], L["i2t_k_b_s"]) if stream else (L["i2t_k_w"], L["i2t_k_b"])
+            hip.gemm_f16(qpe16, kw, out=ws["i2t_k"][:M7], bias=kb)
             hip.gemm_f16(q16, L["i2t_v_w"], out=ws["i2t_v"][:M7], bias=L["i2t_v_b"])
-            if self.fused:
+            if stream:
+                if li == 0:
+                    hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                   L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
+                else:
+                    hip.i2t_stream(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                   L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],
+                                   qpe=L["i2t_q_peb"])
+            elif self.fused:
                 if li == 0:
                     hip.i2t_fused(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w_perm"], L["i2t_o_b"],
                                   L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)

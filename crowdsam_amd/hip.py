@@ -59,6 +59,7 @@ SIGNATURES = {
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
+    "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
     "csam_head_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F],
@@ -565,6 +566,14 @@ def i2t_fused(X, x_bstride, k, v, Wo_perm, bo, gamma, beta, eps, out, B, T, Q=No
     """Fused image->token half-block: [Q-proj] -> 7-key attention -> out-proj -> +residual -> LayerNorm."""
     call("csam_i2t_fused", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq), _ptr(qpe), _ptr(k), _ptr(v),
          _ptr(Wo_perm), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T)
+    return out
+
+
+def i2t_stream(X, x_bstride, k_scaled, v, Wo, bo, gamma, beta, eps, out, B, T, Q=None, q_bstride=0, Wq=None, qpe=None):
+    """Persistent weight-stationary form of ``i2t_fused`` (one 8-wave workgroup per CU streaming 128-token tiles).
+    ``k_scaled`` is the token-side k projection times 0.25*log2(e); ``Wo`` is the plain [256,128] out-proj weight."""
+    call("csam_i2t_stream", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq), _ptr(qpe), _ptr(k_scaled),
+         _ptr(v), _ptr(Wo), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T)
     return out
 
 

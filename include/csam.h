@@ -150,6 +150,13 @@ int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const 
                    const void* Wq_f16, const float* qpe, const void* k_f16, const void* v_f16,
                    const void* Wo_perm_f16, const float* bo, const float* gamma, const float* beta, float eps,
                    void* out_f16, int B, int T);
+/* same half-block as a persistent, weight-stationary stream (one 8-wave workgroup per CU walks 128-token tiles; the
+ * projection weights stay in registers, key tiles are LDS-DMA'd one tile ahead).  k_scaled_f16 [B,7,128] is the
+ * token-side k projection PRE-MULTIPLIED by 0.25*log2(e); Wo_f16 is the plain [256,128] out-proj weight. */
+int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                    const void* Wq_f16, const float* qpe, const void* k_scaled_f16, const void* v_f16,
+                    const void* Wo_f16, const float* bo, const float* gamma, const float* beta, float eps,
+                    void* out_f16, int B, int T);
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,

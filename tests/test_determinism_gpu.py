@@ -38,6 +38,7 @@ def test_fused_decoder_kernels_repeatable(cuda):
     g, be = torch.ones(256, device=cuda), torch.zeros(256, device=cuda)
     o2 = torch.zeros(B * 4096, 256, dtype=torch.float16, device=cuda)
     assert _repeat(lambda: hip.i2t_fused(X, 4096 * 256, k, v, Wo, bo, g, be, 1e-5, o2, B, 4096, Wq=Wq, qpe=qpe))
+    assert _repeat(lambda: hip.i2t_stream(X, 4096 * 256, k, v, Wo, bo, g, be, 1e-5, o2, B, 4096, Wq=Wq, qpe=qpe))
     W1, b1 = (torch.randn(256, 256, device=cuda) * 0.05).half(), torch.randn(256, device=cuda)
     W2, b2 = (torch.randn(128, 64, device=cuda) * 0.1).half(), torch.randn(128, device=cuda)
     hy, masks = torch.randn(B, 4, 32, device=cuda), torch.empty(B, 4, 256, 256, device=cuda)

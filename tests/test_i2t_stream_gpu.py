@@ -1,0 +1,68 @@
+"""GPU parity of the persistent image->token kernel (csam_i2t_stream) against a plain PyTorch fp32 statement of
+TwoWayAttentionBlock's image->token half (segment_anything_cs/modeling/transformer.py:186-190):
+    keys = LayerNorm4(keys + out_proj(softmax(q(keys + pe) k(tokens)^T / sqrt(16)) v(tokens)))
+for both forms (projection fused in / hoisted layer-0 Q with a shared source), odd batch sizes (workgroups whose tile
+range starts and ends mid-prompt), and against the tile-per-workgroup kernel it replaces."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SC = 0.25 * 1.4426950408889634
+
+
+def _ref(X, q, k, v, Wo, bo, g, be, eps):
+    """X [B,T,256] f32 residual, q [B,T,128], k/v [B,7,128] -> [B,T,256]"""
+    B, T, _ = X.shape
+    qh = q.view(B, T, 8, 16).transpose(1, 2)
+    kh = k.view(B, 7, 8, 16).transpose(1, 2)
+    vh = v.view(B, 7, 8, 16).transpose(1, 2)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) * 0.25, -1) @ vh
+    o = a.transpose(1, 2).reshape(B, T, 128) @ Wo.t() + bo
+    return torch.nn.functional.layer_norm(X + o, (256,), g, be, eps)
+
+
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_i2t_stream_projected(cuda, B):
+    from crowdsam_amd import hip
+    T = 4096
+    gen = torch.Generator().manual_seed(B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(cuda)
+    X = r(B * T, 256, sc=0.7).half()
+    k, v = r(B * 7, 128, sc=0.8), r(B * 7, 128, sc=0.8).half()
+    Wq, qpe = r(128, 256, sc=0.06).half(), r(T, 128, sc=0.5)
+    Wo, bo = r(256, 128, sc=0.08).half(), r(256, sc=0.2)
+    g, be = (torch.rand(256, generator=gen) + 0.5).to(cuda), r(256, sc=0.2)
+    out = torch.zeros(B * T, 256, dtype=torch.float16, device=cuda)
+    k_s = (k * SC).half()
+    hip.i2t_stream(X, T * 256, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, Wq=Wq, qpe=qpe)
+    Xf = X.float().view(B, T, 256)
+    q = Xf @ Wq.float().t() + qpe
+    ref = _ref(Xf, q, (k_s.float() / SC).view(B, 7, 128), v.float().view(B, 7, 128), Wo.float(), bo, g, be, 1e-5)
+    err = (out.float().view(B, T, 256) - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
+    # the kernel it replaces (same math, k unscaled, Wo columns permuted for its register chaining)
+    from crowdsam_amd.decoder import _kperm
+    out2 = torch.zeros_like(out)
+    hip.i2t_fused(X, T * 256, k.half(), v, Wo[:, _kperm(128)].contiguous(), bo, g, be, 1e-5, out2, B, T, Wq=Wq, qpe=qpe)
+    assert (out.float() - out2.float()).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("B", [2, 19])
+def test_i2t_stream_hoisted_q(cuda, B):
+    from crowdsam_amd import hip
+    T = 4096
+    gen = torch.Generator().manual_seed(100 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(cuda)
+    X = r(T, 256, sc=0.7).half()                         # shared source, prompt stride 0
+    Q = r(T, 128, sc=0.9).half()
+    k, v = r(B * 7, 128, sc=0.8), r(B * 7, 128, sc=0.8).half()
+    Wo, bo = r(256, 128, sc=0.08).half(), r(256, sc=0.2)
+    g, be = (torch.rand(256, generator=gen) + 0.5).to(cuda), r(256, sc=0.2)
+    out = torch.zeros(B * T, 256, dtype=torch.float16, device=cuda)
+    k_s = (k * SC).half()
+    hip.i2t_stream(X, 0, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, Q=Q, q_bstride=0)
+    Xf = X.float().view(1, T, 256).expand(B, T, 256)
+    q = Q.float().view(1, T, 128).expand(B, T, 128)
+    ref = _ref(Xf, q, (k_s.float() / SC).view(B, 7, 128), v.float().view(B, 7, 128), Wo.float(), bo, g, be, 1e-5)
+    err = (out.float().view(B, T, 256) - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
