@@ -342,45 +342,92 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
 //     the 4 lane groups by an fp32 16x16x4 MFMA with a ones operand, then across waves through 8 KB of LDS;
 //   * the normalised tile is written back over its own LDS image and leaves as whole 512-B rows.
 // The token-side k must arrive pre-multiplied by 0.25*log2(e) (host folds it into the projection weights).
-constexpr int I2S_TOK = 128;
-constexpr int I2S_BUF = 64 * 1024;
-constexpr int I2S_PART = 2 * I2S_BUF;                 // float2 [8 waves][128 tokens]
-constexpr int I2S_PAR = I2S_PART + 8 * 128 * 8;      // bo | gamma | beta fp32 [3][256]
-constexpr int I2S_SMEM = I2S_PAR + 3 * 256 * 4;
+// Geometry, templated on the number of waves NW (8 or 4): a tile has 16*NW tokens, a wave owns 8/NW heads and
+// 256/NW output channels.  NW = 8: one 512-thread workgroup per CU (128-token tiles, 139 KB LDS).  NW = 4: two
+// independent 256-thread workgroups per CU (64-token tiles, 70 KB LDS each) whose phases drift apart, so one's LDS /
+// barrier time overlaps the other's MFMA / VALU time.
+template <int NW, int MI_>
+struct I2S {
+  static constexpr int TOK = 16 * MI_;
+  static constexpr int NT = 64 * NW;                  // threads
+  static constexpr int BUF = TOK * 512;               // one key tile, [TOK][256] fp16
+  static constexpr int PART = 2 * BUF;                // float2 [NW waves][TOK tokens]
+  static constexpr int PAR = PART + NW * TOK * 8;     // bo | gamma | beta fp32 [3][256]
+  static constexpr int SMEM = PAR + 3 * 256 * 4;
+  static constexpr int HPW = 8 / NW;                  // heads per wave
+  static constexpr int NIO = 16 / NW;                 // 16-channel output tiles per wave
+  static constexpr int MI = MI_;                      // 16-token tiles per workgroup tile
+  static constexpr int NP = TOK * 32 / NT;            // 16-B pieces per thread and tile
+};
+
+// In-loop global memory traffic of the stream kernel goes through inline asm with scalar base + 32-bit lane offset:
+// (1) no 64-bit address pairs to spill, (2) the compiler's waitcnt pass does not see these operations.  gfx9 counts
+// loads and stores in ONE vmcnt and LLVM, seeing mixed types pending, answers every tracked load's first use with
+// vmcnt(0) -- which would drain the next tile's LDS-DMA and the previous tile's stores in the middle of a tile.
+// The kernel retires everything itself with the one s_waitcnt vmcnt(0) at barrier (d).
+__device__ __forceinline__ void i2s_glds16(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ floatx4 i2s_load16(const char* sbase, unsigned voff) {
+  floatx4 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ half4_t i2s_load8(const char* sbase, unsigned voff) {
+  half4_t r;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ void i2s_store16(char* sbase, unsigned voff, half8_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 
 #define I2S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int QMODE>
-__global__ __launch_bounds__(512, 1) void i2t_stream_kernel(I2tArgs p, int n_tiles, int tiles_per_wg) {
+template <int QMODE, int NW, int MI_>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, int n_tiles, int tiles_per_wg) {
+  typedef I2S<NW, MI_> G;
+  constexpr int MI = G::MI, HPW = G::HPW, NIO = G::NIO, TOK = G::TOK;
+  // Projected form with 4 waves: Wq + Wo slices already take 128 VGPRs per wave, so fragments are single-buffered and
+  // the Q seeds are fetched at the top of their own tile instead of under the previous LayerNorm (the co-resident
+  // workgroup covers the exposed latency).
+  constexpr bool LEAN = false;
+  constexpr int NFB = 2;                   // fragment buffers
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS-DMA bases and weight slices are per wave
   const int fr = lane & 15, fg = lane >> 4;
-  // byte offset of this thread's 16-B piece inside a [128][256] fp16 tile row block (source-side swizzle of the
-  // lane-linear LDS image): identical for the 8 pieces a thread moves (they are 16 rows = 8 KB apart)
+  // byte offset of this thread's 16-B piece inside a [TOK][256] fp16 tile (source-side swizzle of the lane-linear LDS
+  // image).  The NT threads cover NT/32 rows per piece; with 8 rows per piece (NW = 4) bit 3 of the row alternates
+  // between pieces, which flips bit 3 of the swizzled slot: xoff ^ ((i & 1) << 7).
   const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;
-  const int tpp = p.T / I2S_TOK;                       // tiles per prompt
+  constexpr int PIECE = G::NT * 16;                   // bytes one piece (one instruction of every thread) covers
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;    // LDS byte address of the dynamic segment
+  const int tpp = p.T / TOK;                          // tiles per prompt
   const int first = blockIdx.x * tiles_per_wg;
   const int last = min(first + tiles_per_wg, n_tiles);
   if (first >= last) return;
 
   // ---- launch-resident operands
-  half8_t wq[8];
+  half8_t wq[HPW][8];
   if (QMODE == 1) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) wq[ks] = *(const half8_t*)(p.Wq + (long)(wave * 16 + fr) * 256 + ks * 32 + fg * 8);
-  }
-  half8_t wo[2][4];
+    for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+      for (int ks = 0; ks < 8; ++ks)
+        wq[hh][ks] = *(const half8_t*)(p.Wq + (long)((wave * HPW + hh) * 16 + fr) * 256 + ks * 32 + fg * 8);
+  }
+  half8_t wo[NIO][4];
+#pragma unroll
+  for (int ni = 0; ni < NIO; ++ni)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      wo[ni][ks] = *(const half8_t*)(p.Wo + (long)(wave * 32 + ni * 16 + fr) * 128 + ks * 32 + fg * 8);
-  float* par = (float*)(smem + I2S_PAR);
-  if (tid < 256) {
-    par[tid] = p.bo[tid];
-    par[256 + tid] = p.gamma[tid];
-    par[512 + tid] = p.beta[tid];
+      wo[ni][ks] = *(const half8_t*)(p.Wo + (long)((wave * NIO + ni) * 16 + fr) * 128 + ks * 32 + fg * 8);
+  float* par = (float*)(smem + G::PAR);
+  for (int i = tid; i < 256; i += G::NT) {
+    par[i] = p.bo[i];
+    par[256 + i] = p.gamma[i];
+    par[512 + i] = p.beta[i];
   }
   half4_t eye, ones;
 #pragma unroll
@@ -391,38 +438,50 @@ __global__ __launch_bounds__(512, 1) void i2t_stream_kernel(I2tArgs p, int n_til
   const float mb3 = fg == 1 ? -INFINITY : 0.f;          // key 7 does not exist (lane group 1, r = 3)
 
   auto issue_x = [&](int t, int buf) {
-    const int b = t / tpp, t0 = (t - b * tpp) * I2S_TOK;
+    const int b = t / tpp, t0 = (t - b * tpp) * TOK;
     const char* src = (const char*)(p.X + (long)b * p.x_bstride + (long)t0 * 256);
-    char* dst = smem + buf * I2S_BUF + wave * 1024;
+    const unsigned dst = lds0 + buf * G::BUF + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)                       // 128 rows x 32 slots, lane-linear LDS-DMA, source-side swizzle
-      glds16(src + i * 8192 + xoff, dst + i * 8192);
+    for (int i = 0; i < G::NP; ++i)                   // TOK rows x 32 slots, lane-linear LDS-DMA, source-side swizzle
+      i2s_glds16(src + i * PIECE, NW == 4 ? xoff ^ ((i & 1) << 7) : xoff, dst + i * PIECE);
   };
   // per-tile register operands, fetched one tile ahead: the Q accumulator seed (QMODE 1: pe Wq^T + bq) or the hoisted
-  // Q itself (QMODE 0), and the prompt's k / v^T fragments of this wave's head
-  floatx4 qa[8];
-  half4_t qh[8];
-  half4_t ka, va;
+  // Q itself (QMODE 0), and the prompt's k / v^T fragments of this wave's heads
+  floatx4 qa[HPW][MI];
+  half4_t qh[HPW][MI];
+  half4_t ka[HPW], va[HPW];
   auto fetch_q = [&](int t) {
-    const int b = t / tpp, t0 = (t - b * tpp) * I2S_TOK;
-    if (QMODE == 1) {
+    const int b = t / tpp, t0 = (t - b * tpp) * TOK;
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-        qa[mi] = *(const floatx4*)(p.qpe + (long)(t0 + mi * 16 + fr) * 128 + wave * 16 + fg * 4);
-    } else {
-      const half_t* Qb = p.Q + (long)b * p.q_bstride;
+    for (int hh = 0; hh < HPW; ++hh) {
+      const unsigned el = fr * 128 + (wave * HPW + hh) * 16 + fg * 4;      // element offset inside a 16-token slab
+      if (QMODE == 1) {
+        const char* base = (const char*)(p.qpe + (long)t0 * 128);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) qh[mi] = *(const half4_t*)(Qb + (long)(t0 + mi * 16 + fr) * 128 + wave * 16 + fg * 4);
+        for (int mi = 0; mi < MI; ++mi) qa[hh][mi] = i2s_load16(base + mi * 16 * 128 * 4, el * 4);
+      } else {
+        const char* base = (const char*)(p.Q + (long)b * p.q_bstride + (long)t0 * 128);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) qh[hh][mi] = i2s_load8(base + mi * 16 * 128 * 2, el * 2);
+      }
     }
   };
   auto fetch_kv = [&](int b) {
-    ka = half4_t{0, 0, 0, 0};
-    if (fr < 7) ka = *(const half4_t*)(p.kv_k + ((long)b * 7 + fr) * 128 + wave * 16 + fg * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = fg * 4 + r;
-      va[r] = j < 7 ? p.kv_v[((long)b * 7 + j) * 128 + wave * 16 + fr] : (half_t)0.f;
+    for (int hh = 0; hh < HPW; ++hh) {
+      const int hc = (wave * HPW + hh) * 16;
+      ka[hh] = half4_t{0, 0, 0, 0};
+      if (fr < 7) ka[hh] = *(const half4_t*)(p.kv_k + ((long)b * 7 + fr) * 128 + hc + fg * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = fg * 4 + r;
+        va[hh][r] = j < 7 ? p.kv_v[((long)b * 7 + j) * 128 + hc + fr] : (half_t)0.f;
+      }
     }
+    // compiler-tracked loads: a use right here makes the compiler place its (full) wait in this once-per-prompt
+    // path and not at the first use inside every tile
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) asm volatile("" : "+v"(ka[hh]), "+v"(va[hh]));
   };
 
   issue_x(first, 0);
@@ -432,105 +491,126 @@ __global__ __launch_bounds__(512, 1) void i2t_stream_kernel(I2tArgs p, int n_til
 
   for (int t = first; t < last; ++t) {
     const int cur = (t - first) & 1;
-    char* xb = smem + cur * I2S_BUF;
-    const int b = t / tpp, t0 = (t - b * tpp) * I2S_TOK;
+    char* xb = smem + cur * G::BUF;
+    const int b = t / tpp, t0 = (t - b * tpp) * TOK;
     // (a) tile t has landed -- every thread retired its own pieces at barrier (d) of the previous tile, BEFORE that
     // tile's stores were issued, so the stores drain under this tile instead of being waited for here (gfx9 counts
     // loads and stores in the same vmcnt) -- and every thread is done reading the other buffer (its store source)
     I2S_BARRIER();
+    if (t > first && t0 == 0) fetch_kv(b);            // new prompt (once per T/TOK tiles; the compiler drains here)
     if (t + 1 < last) issue_x(t + 1, cur ^ 1);
 
     // ---- Q^T = Wq_h X^T (+ seed), K = 256: A = resident weight fragments, B = tile fragments from LDS
     // (fragments of step ks+1 are read while the MFMAs of step ks run; the fence keeps the compiler from hoisting
     // the whole tile into registers)
     if (QMODE == 1) {
-      half8_t xf[2][8];
+      half8_t xf[NFB][MI];
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
+      for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) {
+        if (NFB == 2 && ks + 1 < 8) {
 #pragma unroll
-          for (int mi = 0; mi < 8; ++mi)
-            xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+          for (int mi = 0; mi < MI; ++mi)
+            xf[(ks + 1) % NFB][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
         }
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) qa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ks], xf[ks & 1][mi], qa[mi], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int hh = 0; hh < HPW; ++hh)
+            qa[hh][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[hh][ks], xf[ks % NFB][mi], qa[hh][mi], 0, 0, 0);
         asm volatile("" ::: "memory");
+        if (NFB == 1 && ks + 1 < 8) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+        }
       }
     }
-    // ---- 7-key attention of head `wave` for the 128 tokens
-    half4_t oh[8];
+    // ---- 7-key attention of this wave's heads for the tile's tokens
+    half4_t oh[HPW][MI];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      half4_t qb;
-      if (QMODE == 1) qb = half4_t{(half_t)qa[mi][0], (half_t)qa[mi][1], (half_t)qa[mi][2], (half_t)qa[mi][3]};
-      else qb = qh[mi];
-      const floatx4 sacc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka, qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const float s3 = sacc[3] + mb3;
-      float mx = fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], s3));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      const half4_t pb = {(half_t)csam_exp2(sacc[0] - mx), (half_t)csam_exp2(sacc[1] - mx),
-                          (half_t)csam_exp2(sacc[2] - mx), (half_t)csam_exp2(s3 - mx)};
-      const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const floatx4 sm = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const float inv = __builtin_amdgcn_rcpf(sm[0]);
-      oh[mi] = half4_t{(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
-    }
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        half4_t qb;
+        if (QMODE == 1) {
+          const floatx4 qq = qa[hh][mi];
+          qb = half4_t{(half_t)qq[0], (half_t)qq[1], (half_t)qq[2], (half_t)qq[3]};
+        } else {
+          qb = qh[hh][mi];
+        }
+        const floatx4 sacc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka[hh], qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float s3 = sacc[3] + mb3;
+        float mx = fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], s3));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        const half4_t pb = {(half_t)csam_exp2(sacc[0] - mx), (half_t)csam_exp2(sacc[1] - mx),
+                            (half_t)csam_exp2(sacc[2] - mx), (half_t)csam_exp2(s3 - mx)};
+        const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va[hh], pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const floatx4 sm = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float inv = __builtin_amdgcn_rcpf(sm[0]);
+        oh[hh][mi] = half4_t{(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
+        if (LEAN && (mi & 1)) asm volatile("" ::: "memory");   // bound the number of chains in flight (registers)
+      }
     asm volatile("" ::: "memory");
     // ---- out-proj accumulators start from bias + residual (identity MFMA on the tile's own fragments)
-    floatx4 acc[2][8];
+    floatx4 acc[NIO][MI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const floatx4 bo_r = *(const floatx4*)(par + wave * 32 + ni * 16 + fg * 4);
+    for (int ni = 0; ni < NIO; ++ni) {
+      const floatx4 bo_r = *(const floatx4*)(par + (wave * NIO + ni) * 16 + fg * 4);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         const int row = mi * 16 + fr;
-        const int chunk = wave * 4 + ni * 2 + (fg >> 1);
+        const int chunk = (wave * NIO + ni) * 2 + (fg >> 1);
         const half4_t r = *(const half4_t*)(xb + row * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8);
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(eye, r, bo_r, 0, 0, 0);
       }
+      if (LEAN) asm volatile("" ::: "memory");
     }
     I2S_BARRIER();                                      // (e) every wave is done reading the key tile
-    // ---- O exchange: [128 tokens][128 dims] fp16 over the first 32 KB of the tile buffer
+    // ---- O exchange: [TOK][128 dims] fp16 over the first half of the tile buffer
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int row = mi * 16 + fr;
-      *(half4_t*)(xb + row * 256 + (((wave * 2 + (fg >> 1)) ^ fr) << 4) + (fg & 1) * 8) = oh[mi];
-    }
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = mi * 16 + fr;
+        *(half4_t*)(xb + row * 256 + ((((wave * HPW + hh) * 2 + (fg >> 1)) ^ fr) << 4) + (fg & 1) * 8) = oh[hh][mi];
+      }
     I2S_BARRIER();                                      // (b)
     // ---- out-proj, K = 128 (O fragments double-buffered like the key fragments above)
     {
-      half8_t of[2][8];
+      half8_t of[NFB][MI];
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) of[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((fg ^ fr) << 4));
+      for (int mi = 0; mi < MI; ++mi) of[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((fg ^ fr) << 4));
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) {
+        if (NFB == 2 && ks + 1 < 4) {
 #pragma unroll
-          for (int mi = 0; mi < 8; ++mi)
-            of[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+          for (int mi = 0; mi < MI; ++mi)
+            of[(ks + 1) % NFB][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
         }
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[ni][ks], of[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+          for (int ni = 0; ni < NIO; ++ni)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[ni][ks], of[ks % NFB][mi], acc[ni][mi], 0, 0, 0);
         asm volatile("" ::: "memory");
+        if (NFB == 1 && ks + 1 < 4) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            of[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+        }
       }
     }
     // next tile's register operands (their registers are dead now; the loads fly under the LayerNorm)
-    if (t + 1 < last) {
-      fetch_q(t + 1);
-      if ((t + 1) / tpp != b) fetch_kv((t + 1) / tpp);
-    }
-    // ---- LayerNorm partials of this wave's 32 channels: in-lane (8 values), lane groups by a ones MFMA (fp32)
-    float2_t* part = (float2_t*)(smem + I2S_PART);
+    if (t + 1 < last) fetch_q(t + 1);
+    // ---- LayerNorm partials of this wave's channels: in-lane, then over the 4 lane groups by a ones MFMA (fp32)
+    float2_t* part = (float2_t*)(smem + G::PART);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NIO; ++ni) {
         const float2_t a = {acc[ni][mi][0], acc[ni][mi][1]}, c2 = {acc[ni][mi][2], acc[ni][mi][3]};
         s2 += a;
         q2 = __builtin_elementwise_fma(a, a, q2);
@@ -539,45 +619,62 @@ __global__ __launch_bounds__(512, 1) void i2t_stream_kernel(I2tArgs p, int n_til
       }
       const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      if (fg == 0) part[wave * 128 + mi * 16 + fr] = float2_t{ssum[0], qsum[0]};
+      if (fg == 0) part[wave * TOK + mi * 16 + fr] = float2_t{ssum[0], qsum[0]};
+      if (LEAN) asm volatile("" ::: "memory");
     }
     I2S_BARRIER();                                      // (c) partials visible; O no longer read
-    // ---- combine over the 8 waves, normalise, write the fp16 tile back over its LDS image
+    // ---- combine over the waves, normalise, write the fp16 tile back over its LDS image
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       const int row = mi * 16 + fr;
       float2_t tot = part[row];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) tot += part[w * 128 + row];
+      for (int w = 1; w < NW; ++w) tot += part[w * TOK + row];
       const float mean = tot[0] * (1.f / 256.f);
       const float var = fmaxf(tot[1] * (1.f / 256.f) - mean * mean, 0.f);
       const float rstd = rsqrtf(var + p.eps);
       const float2_t rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const floatx4 ga_r = *(const floatx4*)(par + 256 + wave * 32 + ni * 16 + fg * 4);
-        const floatx4 be_r = *(const floatx4*)(par + 512 + wave * 32 + ni * 16 + fg * 4);
+      for (int ni = 0; ni < NIO; ++ni) {
+        const floatx4 ga_r = *(const floatx4*)(par + 256 + (wave * NIO + ni) * 16 + fg * 4);
+        const floatx4 be_r = *(const floatx4*)(par + 512 + (wave * NIO + ni) * 16 + fg * 4);
         const float2_t g0 = {ga_r[0], ga_r[1]}, g1 = {ga_r[2], ga_r[3]};
         const float2_t b0 = {be_r[0], be_r[1]}, b1 = {be_r[2], be_r[3]};
         const float2_t v0 = {acc[ni][mi][0], acc[ni][mi][1]}, v1 = {acc[ni][mi][2], acc[ni][mi][3]};
         const float2_t y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(v0, rs2, nm2), g0, b0);
         const float2_t y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(v1, rs2, nm2), g1, b1);
-        const int chunk = wave * 4 + ni * 2 + (fg >> 1);
+        const int chunk = (wave * NIO + ni) * 2 + (fg >> 1);
         *(half4_t*)(xb + row * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
             half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
       }
+      if (LEAN) asm volatile("" ::: "memory");
     }
     // (d) tile complete; also retires the next tile's LDS-DMA (a whole tile old) and register operands
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
       char* obase = (char*)(p.out + ((long)b * p.T + t0) * 256);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const half8_t v = *(const half8_t*)(xb + tid * 16 + i * 8192);
-        *(half8_t*)(obase + i * 8192 + xoff) = v;
+      for (int i = 0; i < G::NP; ++i) {
+        const half8_t v = *(const half8_t*)(xb + tid * 16 + i * PIECE);
+        i2s_store16(obase + i * PIECE, NW == 4 ? xoff ^ ((i & 1) << 7) : xoff, v);
       }
     }
   }
+}
+
+template <int QMODE, int NW, int MI_>
+static void i2t_stream_launch(const I2tArgs& a, int B, int n_cu, hipStream_t stream) {
+  typedef I2S<NW, MI_> G;
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)i2t_stream_kernel<QMODE, NW, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+    set = true;
+  }
+  const int n_tiles = B * (a.T / G::TOK);
+  const int slots = n_cu * (8 / NW);                  // resident workgroups
+  const int per = csam_cdiv(n_tiles, slots);
+  dim3 grid(csam_cdiv(n_tiles, per));
+  hipLaunchKernelGGL((i2t_stream_kernel<QMODE, NW, MI_>), grid, dim3(G::NT), G::SMEM, stream, a, n_tiles, per);
 }
 
 extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16,
@@ -587,7 +684,7 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
   CSAM_REQUIRE(X_f16 && k_scaled_f16 && v_f16 && Wo_f16 && bo && gamma && beta && out_f16, "csam_i2t_stream: null pointer");
   CSAM_REQUIRE((Q_f16 != nullptr) != (Wq_f16 != nullptr), "csam_i2t_stream: give either Q (hoisted) or Wq");
   CSAM_REQUIRE(!Wq_f16 || qpe, "csam_i2t_stream: qpe required with Wq");
-  CSAM_REQUIRE(B > 0 && T > 0 && T % I2S_TOK == 0, "csam_i2t_stream: T must be a multiple of %d", I2S_TOK);
+  CSAM_REQUIRE(B > 0 && T > 0 && T % 128 == 0, "csam_i2t_stream: T must be a multiple of 128");
   I2tArgs a;
   a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride;
   a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
@@ -595,22 +692,23 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
   a.kv_k = (const half_t*)k_scaled_f16; a.kv_v = (const half_t*)v_f16;
   a.Wo = (const half_t*)Wo_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
-  static int n_cu = 0;
+  static int n_cu = 0, nw_q = 4, nw_p = 4;
   if (!n_cu) {
     int dev = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    hipFuncSetAttribute((const void*)i2t_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, I2S_SMEM);
-    hipFuncSetAttribute((const void*)i2t_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, I2S_SMEM);
+    const char* e = getenv("CSAM_I2T_NW");            // "<hoisted-Q form><projected form>", e.g. 48
+    if (e && (e[0] == '4' || e[0] == '8')) nw_q = e[0] - '0';
+    if (e && e[0] && (e[1] == '4' || e[1] == '8')) nw_p = e[1] - '0';
   }
-  const int n_tiles = B * (T / I2S_TOK);
-  const int per = csam_cdiv(n_tiles, n_cu);
-  dim3 grid(csam_cdiv(n_tiles, per));
-  if (Wq_f16)
-    hipLaunchKernelGGL(i2t_stream_kernel<1>, grid, dim3(512), I2S_SMEM, (hipStream_t)stream, a, n_tiles, per);
-  else
-    hipLaunchKernelGGL(i2t_stream_kernel<0>, grid, dim3(512), I2S_SMEM, (hipStream_t)stream, a, n_tiles, per);
+  if (Wq_f16) {
+    if (nw_p == 4) i2t_stream_launch<1, 4, 2>(a, B, n_cu, (hipStream_t)stream);       // 32-token tiles (Wq + Wo = 128 VGPRs)
+    else i2t_stream_launch<1, 8, 8>(a, B, n_cu, (hipStream_t)stream);
+  } else {
+    if (nw_q == 4) i2t_stream_launch<0, 4, 4>(a, B, n_cu, (hipStream_t)stream);
+    else i2t_stream_launch<0, 8, 8>(a, B, n_cu, (hipStream_t)stream);
+  }
   CSAM_LAUNCH_CHECK("csam_i2t_stream");
   return CSAM_OK;
 }

@@ -109,10 +109,8 @@ class DecoderPlan:
     def __init__(self, sd, device, n_class=1, max_batch=256, fused=True):
         self.device, self.n_class, self.maxB = device, n_class, max_batch
         self.fused = fused     # False: round-1 unfused kernel chain (kept as an A/B and debugging reference)
-        # persistent weight-stationary i2t kernel (csam_i2t_stream): parity-tested, measured EQUAL to the tile-per-workgroup
-        # kernel in round 1 (its eight waves run every phase in lock-step, so the LDS / MFMA / VALU pipes serialise;
-        # DESIGN.md section 6), so the older kernel stays the default
-        self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "0") == "1"
+        # persistent weight-stationary i2t kernel (csam_i2t_stream); 0 = tile-per-workgroup kernel
+        self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "1") != "0"
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
