@@ -1355,6 +1355,213 @@ extern "C" int csam_t2i_shared(void* stream, const void* q_f16, const void* Kh_f
   return CSAM_OK;
 }
 
+// =====================================================================================================
+// csam_t2i_stream: csam_t2i_fused<MODE 1> as a persistent, weight-stationary flash pass (the structure that took the
+// image->token kernels from 5.7 to 3.9 ms per 2048 prompts).  A 4-wave workgroup (two per CU) walks WHOLE prompts:
+//   * wave w owns heads 2w, 2w+1: its Wk and Wv row slices (4 x 16 rows x 256) stay in 128 VGPRs for the launch, so
+//     the 128 KB of projection weights are no longer re-staged through LDS for every 128 tokens of keys;
+//   * 32-key tiles (16 KB) are LDS-DMA'd one tile ahead into a double buffer; ONE barrier per tile;
+//   * K^T = Wk X^T (+ pe Wk^T + bk as the accumulator seed, fetched a tile ahead) and V = X Wv^T (+ bv seed) chain
+//     through registers into S = K q^T and O^T += V^T P^T with the query on the lane index in both, so the online
+//     softmax (m, l, O rescale) is lane-local; the result leaves once per prompt -- no partial records, no merge.
+// In-loop global traffic uses the inline-asm helpers above (no compiler-inserted vmcnt(0) drains).
+// =====================================================================================================
+namespace {
+
+constexpr int T2S_MI = 2;                        // 16-key tiles per workgroup tile
+constexpr int T2S_TOK = 16 * T2S_MI;             // 32 keys
+constexpr int T2S_BUF = T2S_TOK * 512;           // 16 KB
+constexpr int T2S_SMEM = 2 * T2S_BUF;
+constexpr int T2S_NP = T2S_TOK * 32 / 256;       // 16-B pieces per thread and tile
+
+struct T2sArgs {
+  const half_t* X; const half_t* Wkv; const float* kpe; const float* bv; const half_t* q; half_t* out;
+  int B; int T;
+};
+
+__global__ __launch_bounds__(256, 2) void t2i_stream_kernel(T2sArgs p, int prompts_per_wg) {
+  constexpr int MI = T2S_MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
+  constexpr int PIECE = 256 * 16;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  const int tpp = p.T / T2S_TOK;
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, p.B);
+  if (b_first >= b_last) return;
+  const int first = b_first * tpp, last = b_last * tpp;
+
+  // ---- launch-resident weight slices: rows of Wk (0..127) and Wv (128..255) of this wave's two heads
+  half8_t wk[2][8], wv[2][8];
+  float bv_r[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = (wave * 2 + hh) * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      wk[hh][ks] = *(const half8_t*)(p.Wkv + (long)row * 256 + ks * 32 + fg * 8);
+      wv[hh][ks] = *(const half8_t*)(p.Wkv + (long)(128 + row) * 256 + ks * 32 + fg * 8);
+    }
+    bv_r[hh] = p.bv[row];
+  }
+
+  auto issue_x = [&](int t, int buf) {
+    const char* src = (const char*)(p.X + (long)t * T2S_TOK * 256);      // prompts are contiguous: tile t of the batch
+    const unsigned dst = lds0 + buf * T2S_BUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < T2S_NP; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
+  };
+  floatx4 ak[2][MI];                             // K^T accumulators, seeded with (pe Wk^T + bk)[key]
+  auto fetch_seed = [&](int t) {
+    const int t0 = (t % tpp) * T2S_TOK;
+    const char* base = (const char*)(p.kpe + (long)t0 * 128);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        ak[hh][mi] = i2s_load16(base + mi * 16 * 128 * 4, (fr * 128 + (wave * 2 + hh) * 16 + fg * 4) * 4);
+  };
+  half4_t qb[2];
+  floatx4 o[2];
+  float m[2], l[2];
+  auto new_prompt = [&](int b) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      qb[hh] = half4_t{0, 0, 0, 0};
+      if (fr < 7) qb[hh] = *(const half4_t*)(p.q + ((long)b * 7 + fr) * 128 + (wave * 2 + hh) * 16 + fg * 4);
+      asm volatile("" : "+v"(qb[hh]));             // tracked load: the compiler's (full) wait lands here, once per prompt
+      o[hh] = floatx4{0.f, 0.f, 0.f, 0.f};
+      m[hh] = -INFINITY;
+      l[hh] = 0.f;
+    }
+  };
+
+  const float sc = 0.25f * 1.4426950408889634f;
+  issue_x(first, 0);
+  fetch_seed(first);
+  for (int t = first; t < last; ++t) {
+    const int cur = (t - first) & 1;
+    const char* xb = smem + cur * T2S_BUF;
+    const int tp = t % tpp;
+    if (tp == 0) new_prompt(t / tpp);
+    // tile t and its seeds have landed (issued a tile ago); everyone is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < last) issue_x(t + 1, cur ^ 1);
+
+    // ---- projections, K = 256 channels in 8 steps; one key fragment feeds 4 MFMAs (K and V of both heads)
+    floatx4 av[2][MI];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[hh][mi] = floatx4{bv_r[hh], bv_r[hh], bv_r[hh], bv_r[hh]};
+    half8_t xf[2][MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          ak[hh][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[hh][ks], xf[ks & 1][mi], ak[hh][mi], 0, 0, 0);   // [d][key]
+          av[hh][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks & 1][mi], wv[hh][ks], av[hh][mi], 0, 0, 0);   // [key][d]
+        }
+      asm volatile("" ::: "memory");
+    }
+    half4_t kf[2][MI], vf[2][MI];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kf[hh][mi][e] = (half_t)ak[hh][mi][e];
+          vf[hh][mi][e] = (half_t)av[hh][mi][e];
+        }
+    asm volatile("" ::: "memory");
+    if (t + 1 < last) fetch_seed(t + 1);           // the K accumulators are free: next tile's seeds fly under the softmax
+
+    // ---- online softmax + PV per head; query on the lane index in S, P^T and O^T
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      floatx4 sa[MI];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        sa[mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[hh][mi], qb[hh], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        mx = fmaxf(mx, fmaxf(fmaxf(sa[mi][0], sa[mi][1]), fmaxf(sa[mi][2], sa[mi][3])));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[hh], mx);
+      const float alpha = csam_exp2((m[hh] - mnew) * sc);
+      m[hh] = mnew;
+      const float nm = -mnew * sc;
+      float ps = 0.f;
+      half4_t pb[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = csam_exp2(fmaf(sa[mi][e], sc, nm));
+          ps += pe;
+          pb[mi][e] = (half_t)pe;
+        }
+      l[hh] = l[hh] * alpha + ps;
+      o[hh] *= alpha;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) o[hh] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[hh][mi], pb[mi], o[hh], 0, 0, 0);
+    }
+
+    if (tp == tpp - 1) {                           // prompt complete: normalise and write [7][128] fp16
+      const int b = t / tpp;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float ls = l[hh];
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        const float inv = 1.f / ls;
+        if (fr < 7) {
+          half4_t r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = (half_t)(o[hh][e] * inv);
+          *(half4_t*)(p.out + ((long)b * 7 + fr) * 128 + (wave * 2 + hh) * 16 + fg * 4) = r;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
+                               const void* q_f16, void* out_f16, int B, int T) {
+  CSAM_REQUIRE(X_f16 && Wkv_f16 && kpe && bv && q_f16 && out_f16, "csam_t2i_stream: null pointer");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % T2S_TOK == 0, "csam_t2i_stream: T must be a multiple of %d", T2S_TOK);
+  T2sArgs a;
+  a.X = (const half_t*)X_f16; a.Wkv = (const half_t*)Wkv_f16; a.kpe = kpe; a.bv = bv;
+  a.q = (const half_t*)q_f16; a.out = (half_t*)out_f16; a.B = B; a.T = T;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int per = csam_cdiv(B, 2 * n_cu);           // whole prompts per workgroup, two workgroups per CU
+  hipLaunchKernelGGL(t2i_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
+  CSAM_LAUNCH_CHECK("csam_t2i_stream");
+  return CSAM_OK;
+}
+
 extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
 
 extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * T2I_PARTS * 56 * T2I_NREC * sizeof(float); }

@@ -111,6 +111,7 @@ class DecoderPlan:
         self.fused = fused     # False: round-1 unfused kernel chain (kept as an A/B and debugging reference)
         # persistent weight-stationary i2t kernel (csam_i2t_stream); 0 = tile-per-workgroup kernel
         self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "1") != "0"
+        self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -314,6 +315,10 @@ class DecoderPlan:
             hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
             if fused_args is not None and "K0" in fused_args:
                 hip.t2i_shared(ws["t2i_q"], st["k0h"], st["v0h"], ws["t2i_o"], B)
+            elif fused_args is not None and self.t2i_stream and B >= 256:
+                # whole prompts per workgroup: needs about one prompt per resident workgroup (512) to fill the chip
+                hip.t2i_stream(ws["t2i_q"], ws["t2i_o"], B, fused_args["X"], fused_args["Wkv"], fused_args["kpe"],
+                               fused_args["bv"], T_IMG)
             elif fused_args is not None:
                 hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **fused_args)
             else:

@@ -59,6 +59,7 @@ SIGNATURES = {
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
+    "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
@@ -597,6 +598,12 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out
+
+
+def t2i_stream(q, out, B, X, Wkv, kpe, bv, T=4096):
+    """Persistent weight-stationary token->image attention (K/V projections fused, online softmax, no partials)."""
+    call("csam_t2i_stream", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(q), _ptr(out), B, T)
     return out
 
 

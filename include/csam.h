@@ -150,6 +150,11 @@ int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const 
                    const void* Wq_f16, const float* qpe, const void* k_f16, const void* v_f16,
                    const void* Wo_perm_f16, const float* bo, const float* gamma, const float* beta, float eps,
                    void* out_f16, int B, int T);
+/* token->image attention with the K/V projections fused in (csam_t2i_fused with keys + weights) as a persistent,
+ * weight-stationary flash pass: 4-wave workgroups walk whole prompts, Wk/Wv slices in registers, 32-key tiles LDS-DMA'd a
+ * tile ahead, online softmax, out [B,7,128] written once per prompt (no workspace, no merge). transformer.py:173-177,105-112 */
+int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
+                    const void* q_f16, void* out_f16, int B, int T);
 /* same half-block as a persistent, weight-stationary stream (one 8-wave workgroup per CU walks 128-token tiles; the
  * projection weights stay in registers, key tiles are LDS-DMA'd one tile ahead).  k_scaled_f16 [B,7,128] is the
  * token-side k projection PRE-MULTIPLIED by 0.25*log2(e); Wo_f16 is the plain [256,128] out-proj weight. */
