@@ -439,6 +439,15 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   // 64-row tiles when 128-row tiles would leave CUs without a workgroup (measured: pays at <= 256 tiles,
   // loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU)
   const bool small = (long)(N / BN) * csam_cdiv(M, BM) * batch <= 256;
+  // 96-row tiles when 128-row tiles would fill only part of ONE round of the 512 resident workgroups and 96-row tiles
+  // still fit that round (DINOv2 proj / fc2: M = 5376, N = 1024: 336 -> 448 workgroups)
+  const long t128 = (long)(N / BN) * csam_cdiv(M, BM) * batch, t96 = (long)(N / BN) * csam_cdiv(M, 96) * batch;
+  static int use96 = -1;
+  if (use96 < 0) {
+    const char* e = getenv("CSAM_GEMM_96");
+    use96 = e ? atoi(e) : 1;
+  }
+  const bool mid = use96 && !small && t128 < 512 && t96 <= 512;
   static int variant = -1, xcd = 1;
   if (variant < 0) {
     const char* e = getenv("CSAM_GEMM_VARIANT");
@@ -461,7 +470,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }
-  dim3 grid((N / BN) * csam_cdiv(M, small ? 64 : BM), 1, batch);
+  dim3 grid((N / BN) * csam_cdiv(M, small ? 64 : mid ? 96 : BM), 1, batch);
 #define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
@@ -475,7 +484,9 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     }                                                                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
   }
-  if (small) {
+  if (mid) {
+    CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
+  } else if (small) {
     if (variant == 0) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
     else if (variant == 1) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 4, 32)
     else CSAM_GEMM_LAUNCH(2, 4, 2, 2, 6, 32)

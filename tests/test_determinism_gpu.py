@@ -47,7 +47,8 @@ def test_fused_decoder_kernels_repeatable(cuda):
                                               W2, b2, hy, masks, B, stats=stats), masks)[1])
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 3072, 1024), (5330, 4096, 1024), (4096, 1024, 4096), (8192, 4096, 4096)])
+@pytest.mark.parametrize("M,N,K", [(4096, 3072, 1024), (5330, 4096, 1024), (4096, 1024, 4096), (8192, 4096, 4096),
+                                   (5330, 1024, 4096)])
 def test_gemm_repeatable(cuda, M, N, K):
     from crowdsam_amd import hip
     torch.manual_seed(1)

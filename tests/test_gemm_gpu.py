@@ -21,7 +21,8 @@ def _ref(a, w, bias, act, colscale, residual):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (4096, 1024, 1024),
-                                   (5330, 3072, 1024), (77, 256, 192), (4900, 128, 4096)])
+                                   (5330, 3072, 1024), (77, 256, 192), (4900, 128, 4096),
+                                   (5330, 1024, 1024), (5376, 1024, 4096), (4000, 1536, 256)])   # 96-row tile dispatch
 def test_gemm_shapes(cuda, M, N, K):
     from crowdsam_amd import hip
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
