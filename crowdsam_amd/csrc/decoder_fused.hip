@@ -991,6 +991,245 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
 
 }  // namespace
 
+// =====================================================================================================
+// csam_upscale_stream: csam_upscale_fused as a persistent, weight-stationary stream.  PMC/ablation of the tile-per-
+// workgroup kernel: GEMM1 alone 2.5 ms per 2048 prompts because every 64-token workgroup re-stages the 128 KB of W1
+// from L2 through LDS (21 GB of L2->LDS traffic per launch, ~8.6 TB/s: L2-bound), phases 2-4 alone 3.3 ms (VALU).
+// Here a 4-wave workgroup (two per CU) walks WHOLE prompts in 32-token tiles (half a row of the 64x64 grid):
+//   * wave = first-conv position; its W1 slice (64 rows x 256) stays in 128 VGPRs for the launch;
+//   * key tiles (16 KB) are LDS-DMA'd one tile ahead into a double buffer, every wave reads all of it as B fragments;
+//   * LN2d + GELU -> GEMM2 (W2' resident in LDS) -> +bias, GELU -> hyper product exactly as in upscale_fused;
+//   * the 16 output half-rows (4 masks x 4 rows x 128 px fp32) leave through LDS as whole 512-B segments, the stores
+//     draining under the next tile; the per-plane max for the PWD-Net softmax is carried in registers across the
+//     prompt and written once (no atomics, no init kernel dependence).
+// =====================================================================================================
+namespace {
+
+constexpr int US_TOK = 32;
+constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
+constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
+constexpr int US_OUT = US_W2S + 16 * 1024;         // [16 rows][128 px] fp32 = 8 KB
+constexpr int US_HFR = US_OUT + 8 * 1024;          // hyper fragments hi | lo, 2 KB
+constexpr int US_PAR = US_HFR + 2048;              // b2 [128] | b1 [256] | ln_g [64] | ln_b [64] fp32 = 2 KB
+constexpr int US_WMX = US_PAR + 2048;              // [4 waves][2]
+constexpr int US_SMEM = US_WMX + 64;
+
+__global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B, int prompts_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int pos = wave;
+  const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
+  constexpr int PIECE = 256 * 16;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  constexpr int TPP = 4096 / US_TOK;                 // 128 tiles per prompt
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, B);
+  if (b_first >= b_last) return;
+  const int first = b_first * TPP, last = b_last * TPP;
+
+  // ---- launch-resident: W1 slice in registers, W2' and the small parameter vectors in LDS
+  half8_t w1[4][8];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      w1[ni][ks] = *(const half8_t*)(p.W1 + (long)(pos * 64 + ni * 16 + fr) * 256 + ks * 32 + fg * 8);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                   // W2': 128 rows x 8 slots, 128-B rows, slot ^= row & 7
+    const int cc = tid + it * 256;
+    const int row = cc >> 3, sl = cc & 7;
+    glds16(p.W2 + (long)row * 64 + ((sl ^ (row & 7)) * 8), smem + US_W2S + (cc & ~63) * 16);
+  }
+  float* par = (float*)(smem + US_PAR);
+  if (tid < 128) par[tid] = p.b2[tid];
+  par[128 + tid] = p.b1[tid];
+  if (tid < 64) {
+    par[384 + tid] = p.ln_g[tid];
+    par[448 + tid] = p.ln_b[tid];
+  }
+  float* outs = (float*)(smem + US_OUT);
+  float* wmx = (float*)(smem + US_WMX);
+
+  auto issue_x = [&](int t, int buf) {
+    const char* src = (const char*)(p.X + (long)t * US_TOK * 256);
+    const unsigned dst = lds0 + buf * US_BUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
+  };
+
+  half8_t hhi, hlo;
+  float pmax0 = -INFINITY, pmax1 = -INFINITY;        // running max of the planes this thread stores (l0, l0 + 2)
+  issue_x(first, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int t = first; t < last; ++t) {
+    const int cur = (t - first) & 1;
+    const char* xb = smem + cur * US_BUF;
+    const int b = t / TPP, tp = t - b * TPP;
+    const int i0 = tp >> 1, half = tp & 1;
+    if (tp == 0 && tid < 64) {                       // new prompt: hyper-network A fragments (hi/lo fp16 split)
+      half8_t hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int i = tid & 15, g = tid >> 4;
+      if (i < 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cch = ((e >= 4) ? 16 : 0) + g * 4 + (e & 3);
+          const float h = p.hyper[((long)b * 4 + i) * 32 + cch];
+          hi[e] = (half_t)h;
+          lo[e] = (half_t)(h - (float)hi[e]);
+        }
+      }
+      *(half8_t*)(smem + US_HFR + tid * 16) = hi;
+      *(half8_t*)(smem + US_HFR + 1024 + tid * 16) = lo;
+    }
+    // (a) tile t landed (retired at barrier (b) of the previous tile, before its stores); outs free again
+    I2S_BARRIER();
+    if (t + 1 < last) issue_x(t + 1, cur ^ 1);
+    if (tp == 0) {
+      hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
+      hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
+    }
+
+    // ---- GEMM1: [64 co of this position] x [32 tokens], K = 256; accumulators seeded with b1
+    floatx4 a1[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const floatx4 b1v = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
+      a1[0][ni] = b1v;
+      a1[1][ni] = b1v;
+    }
+    {
+      half8_t xf[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            a1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks & 1][mi], a1[mi][ni], 0, 0, 0);
+        asm volatile("" ::: "memory");
+      }
+    }
+
+    // ---- phases 2-4 per 16-token tile (same arithmetic as upscale_fused_kernel)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      half8_t xf2[2];
+      {
+        float sum = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) sum += (a1[mi][ni][0] + a1[mi][ni][1]) + (a1[mi][ni][2] + a1[mi][ni][3]);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.f / 64.f);
+        float var = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = a1[mi][ni][e] - mean;
+            var += d * d;
+          }
+        var += __shfl_xor(var, 16, 64);
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
+          const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float2_t av = {a1[mi][ni][e], a1[mi][ni][e + 1]};
+            const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
+            const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
+            const float2_t ge = csam_gelu_poly2(__builtin_elementwise_fma(nrm, g2, b2));
+            xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)ge[0];
+            xf2[ni >> 1][(ni & 1) * 4 + e + 1] = (half_t)ge[1];
+          }
+        }
+      }
+      floatx4 a2[8];
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) {
+          const int row = n2 * 16 + fr;
+          const half8_t wf = *(const half8_t*)(smem + US_W2S + row * 128 + (((s2 * 4 + fg) ^ (row & 7)) << 4));
+          a2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[s2], a2[n2], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int pos2 = 0; pos2 < 4; ++pos2) {
+        half8_t ub;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const floatx4 bb = *(const floatx4*)(par + (pos2 * 2 + h2) * 16 + fg * 4);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float2_t z = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]} + (float2_t){bb[e], bb[e + 1]};
+            const float2_t ge = csam_gelu_poly2(z);
+            ub[h2 * 4 + e] = (half_t)ge[0];
+            ub[h2 * 4 + e + 1] = (half_t)ge[1];
+          }
+        }
+        floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
+        if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+          const int yy = (pos >> 1) * 2 + (pos2 >> 1);
+          const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+#pragma unroll
+          for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
+        }
+      }
+    }
+    // (b) output half-rows complete; also retires the next tile's LDS-DMA (a whole tile old) BEFORE this tile's stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rowid = it * 8 + (tid >> 5), x4 = tid & 31;      // rowid = l*4 + yy
+        const floatx4 v = *(const floatx4*)(outs + rowid * 128 + x4 * 4);
+        const int l = rowid >> 2, yy = rowid & 3;
+        char* dst = (char*)(p.masks + (((long)b * 4 * 256) + 4 * i0) * 256 + half * 128);     // uniform base
+        const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(dst) : "memory");
+        const float mxv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (it == 0) pmax0 = fmaxf(pmax0, mxv);
+        else pmax1 = fmaxf(pmax1, mxv);
+      }
+    }
+    if (tp == TPP - 1 && p.stats) {                  // prompt complete: per-plane max (planes l0 = tid>>7 and l0 + 2)
+      const float m0 = csam_wave_max(pmax0), m1 = csam_wave_max(pmax1);
+      if (lane == 0) {
+        wmx[wave * 2] = m0;
+        wmx[wave * 2 + 1] = m1;
+      }
+      I2S_BARRIER();
+      if (tid < 4) {   // plane tid: waves (tid & 1) * 2 and +1 hold it, slot tid >> 1
+        const int w0 = (tid & 1) * 2, sl = tid >> 1;
+        const float m = fmaxf(wmx[w0 * 2 + sl], wmx[(w0 + 1) * 2 + sl]);
+        p.stats[((long)b * 4 + tid) * 2] = m;
+        p.stats[((long)b * 4 + tid) * 2 + 1] = 0.f;
+      }
+      pmax0 = -INFINITY;
+      pmax1 = -INFINITY;
+    }
+  }
+}
+
+}  // namespace
+
 __global__ void stats_init_kernel(float* stats, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < rows) {
@@ -1023,6 +1262,29 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   else if (abl == 2) hipLaunchKernelGGL(upscale_fused_kernel<2>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(upscale_fused_kernel<0>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_upscale_fused");
+  return CSAM_OK;
+}
+
+extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
+                                   const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
+                                   const float* b2, const float* hyper, float* masks, float* stats_or_null, int B) {
+  CSAM_REQUIRE(keys_f16 && W1_f16 && b1 && ln_gamma && ln_beta && W2_perm_f16 && b2 && hyper && masks && B > 0,
+               "csam_upscale_stream: bad args");
+  UpArgs a;
+  a.X = (const half_t*)keys_f16; a.W1 = (const half_t*)W1_f16; a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta;
+  a.eps = eps; a.W2 = (const half_t*)W2_perm_f16; a.b2 = b2; a.hyper = hyper; a.masks = masks;
+  a.stats = stats_or_null;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute((const void*)upscale_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, US_SMEM);
+  }
+  const int per = csam_cdiv(B, 2 * n_cu);
+  hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
+  CSAM_LAUNCH_CHECK("csam_upscale_stream");
   return CSAM_OK;
 }
 

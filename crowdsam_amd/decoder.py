@@ -112,6 +112,7 @@ class DecoderPlan:
         # persistent weight-stationary i2t kernel (csam_i2t_stream); 0 = tile-per-workgroup kernel
         self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "1") != "0"
         self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
+        self.up_stream = os.environ.get("CSAM_UP_STREAM", "1") != "0"     # persistent upscaler (B >= 256)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -416,7 +417,8 @@ class DecoderPlan:
                                128, 32, B, 32, 256, 4)
         masks = ws["masks"][:B]
         if self.fused:
-            hip.upscale_fused(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,
+            up = hip.upscale_stream if (self.up_stream and B >= 256) else hip.upscale_fused
+            up(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,
                               self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
         else:
             hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)

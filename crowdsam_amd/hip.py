@@ -59,6 +59,7 @@ SIGNATURES = {
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
+    "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
@@ -599,6 +600,13 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
     return out
+
+
+def upscale_stream(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B, stats=None):
+    """Persistent weight-stationary form of ``upscale_fused`` (whole prompts per workgroup, W1 slices in registers)."""
+    call("csam_upscale_stream", _stream(), _ptr(keys), _ptr(W1), _ptr(b1), _ptr(ln_g), _ptr(ln_b), float(eps),
+         _ptr(W2_perm), _ptr(b2), _ptr(hyper), _ptr(masks), _ptr(stats), B)
+    return masks
 
 
 def t2i_stream(q, out, B, X, Wkv, kpe, bv, T=4096):

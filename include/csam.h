@@ -166,6 +166,11 @@ int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_stride, const
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
                        const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
+/* same as a persistent, weight-stationary stream: 4-wave workgroups walk whole prompts in 32-token tiles, W1 slices in
+ * registers, key tiles LDS-DMA'd a tile ahead; stats column 0 (per-plane max) written once per prompt, no atomics */
+int csam_upscale_stream(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
+                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
+                        const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
 /* token->image attention with the K/V projections fused in (transformer.py:173-177,105-112) */
 long csam_t2i_fused_workspace_bytes(int B);
 int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
