@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--arch", default="vit_l")
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--frame", type=int, default=1024, help="synthetic frame side in pixels (BASELINE configs[4]: 1500)")
-    ap.add_argument("--points-per-batch", type=int, default=2048,
+    ap.add_argument("--points-per-batch", type=int, default=4096,
                     help="prompts per decoder batch (the dense sweep has no pruning, so results do not depend on it; "
                          "the reference's EPS default of 32 is used by the parity tests)")
     ap.add_argument("--mode", default="dense", choices=["dense", "eps"])
