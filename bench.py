@@ -128,7 +128,8 @@ def main():
         two = _pred._TWO_STREAMS
         _pred._TWO_STREAMS = False
         GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
-        SWEEP_NAMES = ["csam_i2t_fused", "csam_t2i_fused", "csam_t2i_shared", "csam_upscale_fused",
+        SWEEP_NAMES = ["csam_i2t_fused", "csam_i2t_stream", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_shared",
+                       "csam_upscale_fused", "csam_upscale_stream",
                        "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_write"]
         timer = hip.KernelTimer(GEMM_NAMES + SWEEP_NAMES)
         hip.set_timer(timer)
@@ -175,9 +176,9 @@ def main():
             if sweep_ms > 0 and args.mode == "dense":
                 gbs = 14.94e6 * n_prompts * args.steps / (sweep_ms * 1e-3) / 1e9
                 res["roofline_decoder_sweep"] = {
-                    "bound": "hbm", "kernel": "fused decoder kernels (i2t / t2i / upscale / pool / mask post)",
+                    "bound": "hbm", "kernel": "persistent decoder kernels (i2t / t2i / upscale streams, pool, mask post)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                    "traffic": pmc_traffic("i2t_fused_kernel")[0], "ms_per_step": sweep_ms / args.steps,
+                    "traffic": pmc_traffic("i2t_stream_kernel")[0], "ms_per_step": sweep_ms / args.steps,
                     "note": "algorithmic 14.94 MB/prompt x prompts / HIP-event time of the sweep kernels; traffic = "
                             "PMC bytes per launch of the largest of them (i2t)"}
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
