@@ -122,11 +122,13 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
     }
   }
   floatx4 o[2][4];
-  float m[2], l[2];
+  float m[2];
+  floatx4 l[2];
+  const half8_t ones8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     m[rt] = -INFINITY;
-    l[rt] = 0.f;
+    l[rt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[rt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
@@ -222,16 +224,10 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
       alpha[rt] = csam_exp2((m[rt] - mnew) * sl2);
       m[rt] = mnew;
       const float nm = -mnew * sl2;
-      float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float e = csam_exp2(fmaf(s[rt][kt][j], sl2, nm));
-          s[rt][kt][j] = e;
-          ps += e;
-        }
-      l[rt] = l[rt] * alpha[rt] + ps;
+        for (int j = 0; j < 4; ++j) s[rt][kt][j] = csam_exp2(fmaf(s[rt][kt][j], sl2, nm));
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -242,10 +238,18 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
     }
     if (__ballot(alpha[0] != 1.f || alpha[1] != 1.f) != 0ull) {     // exact: alpha == 1 when no max moved
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt) {
+        l[rt] *= alpha[rt];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= alpha[rt];
+      }
     }
+    // row sums on the matrix pipe (the loop is VALU-bound): l^T += 1 . P^T, every lane of a query receives the sum of
+    // the fp16 probabilities the PV product uses
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) l[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][st], l[rt], 0, 0, 0);
     // ---- O^T += V^T P^T: V^T fragment = dims row dt*16+fr, keys 32 st + 8 fg .. +7 (one 16-B read)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -262,10 +266,7 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
 
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    float lt = l[rt];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
-    const float inv = 1.0f / lt;
+    const float inv = 1.0f / l[rt][0];
     if (qrow[rt] < T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {

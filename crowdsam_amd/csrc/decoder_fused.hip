@@ -699,14 +699,15 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
     const char* e = getenv("CSAM_I2T_NW");            // "<hoisted-Q form><projected form>", e.g. 48
-    if (e && (e[0] == '4' || e[0] == '8')) nw_q = e[0] - '0';
+    if (e && (e[0] == '4' || e[0] == '8' || e[0] == '2')) nw_q = e[0] - '0';   // '2' = 4 waves, 32-token tiles
     if (e && e[0] && (e[1] == '4' || e[1] == '8')) nw_p = e[1] - '0';
   }
   if (Wq_f16) {
     if (nw_p == 4) i2t_stream_launch<1, 4, 2>(a, B, n_cu, (hipStream_t)stream);       // 32-token tiles (Wq + Wo = 128 VGPRs)
     else i2t_stream_launch<1, 8, 8>(a, B, n_cu, (hipStream_t)stream);
   } else {
-    if (nw_q == 4) i2t_stream_launch<0, 4, 4>(a, B, n_cu, (hipStream_t)stream);
+    if (nw_q == 2) i2t_stream_launch<0, 4, 2>(a, B, n_cu, (hipStream_t)stream);
+    else if (nw_q == 4) i2t_stream_launch<0, 4, 4>(a, B, n_cu, (hipStream_t)stream);
     else i2t_stream_launch<0, 8, 8>(a, B, n_cu, (hipStream_t)stream);
   }
   CSAM_LAUNCH_CHECK("csam_i2t_stream");
