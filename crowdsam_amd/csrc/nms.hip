@@ -95,11 +95,16 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict
   for (int tile = 0; tile < ntile; ++tile) {
     const int r0 = tile * 64;
     const int nr = min(64, N - r0);
-    // stage rows r0..r0+nr-1, words >= tile only (lower words are never set)
-    for (int r = 0; r < nr; ++r)
-      for (int w = lane; w < nw; w += 64) rows[r * nw + w] = (w >= tile) ? mask[(long)(r0 + r) * nw + w] : 0ull;
-    __syncthreads();
     uint64_t cur = __shfl(removed[tile >> 6], tile & 63, 64);
+    // candidates of this tile already suppressed by earlier tiles can never be kept: their rows are not needed
+    const uint64_t valid = nr == 64 ? ~0ull : ((1ull << nr) - 1ull);
+    if ((cur & valid) == valid) continue;
+    // stage the remaining rows r0..r0+nr-1, words >= tile only (lower words are never set)
+    for (int r = 0; r < nr; ++r) {
+      if ((cur >> r) & 1ull) continue;
+      for (int w = lane; w < nw; w += 64) rows[r * nw + w] = (w >= tile) ? mask[(long)(r0 + r) * nw + w] : 0ull;
+    }
+    __syncthreads();
     for (int r = 0; r < nr; ++r) {
       if (!((cur >> r) & 1ull)) {
         if (lane == 0) keep[nkeep] = (long)order[r0 + r];
