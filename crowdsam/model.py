@@ -284,9 +284,10 @@ class CrowdSAM:
         tmp = None
         if tuple(p.input_size) != (H, W):
             tmp = torch.empty(B, p.input_size[0], p.input_size[1], dtype=torch.float32, device=dev)
-        # pass 1: statistics of every selected candidate (no mask bytes)
-        hip.mask_post(low, sel, B, p.input_size, (H, W), p.model.mask_threshold, self.stability_score_offset,
-                      None, inter, uni, box, tmp)
+        # pass 1: statistics of the selected candidates that pass the predicted-IoU filter (the reference filters on
+        # it before it computes stability, crowdsam/model.py:371-376 there); no mask bytes yet
+        hip.mask_post_scored(low, sel, score, self.pred_iou_thresh, B, p.input_size, (H, W), p.model.mask_threshold,
+                             self.stability_score_offset, inter, uni, box, tmp)
         keep = torch.empty(B, dtype=torch.uint8, device=dev)
         occ = torch.empty(B, dtype=torch.uint8, device=dev)
         slot = i32(B)

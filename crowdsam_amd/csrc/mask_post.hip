@@ -84,6 +84,8 @@ struct PostArgs {
   const uint8_t* keep;  // optional [B]: prompts with keep[b]==0 are skipped entirely
   const int* slot;      // optional [B]: mask bytes of prompt b go to out_mask[slot[b]] (compacted store)
   int stats;            // mode 1: accumulate counts / bbox
+  const float* score = nullptr;   // optional [B]: prompts with score[b] <= score_thr are skipped (they are dropped by
+  float score_thr = 0.f;          // the predicted-IoU filter BEFORE stability is looked at, crowdsam/model.py:371-376)
 };
 
 constexpr int POST_ROWS = 16;   // output rows per workgroup
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   if (a.keep && !a.keep[b]) return;
+  if (a.score && !(a.score[b] > a.score_thr)) return;
   const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (a.sel ? (long)a.sel[b] * a.plane : 0);
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   if (a.keep && !a.keep[b]) return;
+  if (a.score && !(a.score[b] > a.score_thr)) return;
   const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (long)a.sel[b] * a.plane;
   const int i = blockIdx.x;                      // 16 output rows: y = 16 i .. 16 i + 15
@@ -439,8 +443,10 @@ extern "C" int csam_select_masks(void* stream, const float* iou, const float* cl
 // only: the bytes of the prompts that survive the filters are produced later by csam_mask_write).
 static int post_launch(hipStream_t s, const float* lowres, const int* sel, const uint8_t* keep, const int* slot,
                        int B, int in_h, int in_w, int out_h, int out_w, float thr, float off, void* out_mask_u8,
-                       int* inter, int* uni, int* box, float* tmp_f32, int do_stats) {
+                       int* inter, int* uni, int* box, float* tmp_f32, int do_stats, const float* score = nullptr,
+                       float score_thr = 0.f) {
   PostArgs a;
+  a.score = score; a.score_thr = score_thr;
   a.thr = thr; a.off = off;
   a.inter = inter; a.uni = uni; a.box = box; a.keep = keep; a.slot = slot; a.stats = do_stats;
   if (in_h == out_h && in_w == out_w) {
@@ -481,6 +487,23 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
                              inter, uni, box, tmp_f32, 1);
   if (rc) return rc;
   CSAM_LAUNCH_CHECK("csam_mask_post");
+  return CSAM_OK;
+}
+
+// Statistics pass that skips the prompts the predicted-IoU filter drops anyway (score[b] <= score_thr, or
+// score_thr <= 0: none): their inter / uni / box keep the initial values and post_finalize* rejects them on the score.
+extern "C" int csam_mask_post_scored(void* stream, const float* lowres, const int* sel, const float* score,
+                                     float score_thr, int B, int in_h, int in_w, int out_h, int out_w, float thr,
+                                     float off, int* inter, int* uni, int* box, float* tmp_f32) {
+  CSAM_REQUIRE(lowres && sel && score && inter && uni && box && B > 0, "csam_mask_post_scored: bad args");
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+               "csam_mask_post_scored: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
+  const int rc = post_launch(s, lowres, sel, nullptr, nullptr, B, in_h, in_w, out_h, out_w, thr, off, nullptr, inter, uni,
+                             box, tmp_f32, 1, score_thr > 0.f ? score : nullptr, score_thr);
+  if (rc) return rc;
+  CSAM_LAUNCH_CHECK("csam_mask_post_scored");
   return CSAM_OK;
 }
 

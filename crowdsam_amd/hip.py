@@ -46,6 +46,7 @@ SIGNATURES = {
     "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "csam_mask_post_scored": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
     "csam_mask_write": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
@@ -428,6 +429,12 @@ def select_masks(iou, cls, n_class, sel, score, category, fused, B):
 def mask_post(lowres, sel, B, in_hw, out_hw, thr, off, out_mask, inter, uni, box, tmp=None):
     call("csam_mask_post", _stream(), _ptr(lowres), _ptr(sel), B, in_hw[0], in_hw[1], out_hw[0], out_hw[1],
          float(thr), float(off), _ptr(out_mask), _ptr(inter), _ptr(uni), _ptr(box), _ptr(tmp))
+
+
+def mask_post_scored(lowres, sel, score, score_thr, B, in_hw, out_hw, thr, off, inter, uni, box, tmp=None):
+    """Statistics pass (counts + box) of the selected candidates, skipping prompts with score <= score_thr."""
+    call("csam_mask_post_scored", _stream(), _ptr(lowres), _ptr(sel), _ptr(score), float(score_thr), B, in_hw[0], in_hw[1],
+         out_hw[0], out_hw[1], float(thr), float(off), _ptr(inter), _ptr(uni), _ptr(box), _ptr(tmp))
 
 
 def post_finalize(score, inter, uni, box, pred_iou_thresh, stab_thresh, filter_thresh, stability, keep, occ, B):

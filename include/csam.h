@@ -190,6 +190,12 @@ int csam_select_masks(void* stream, const float* iou, const float* cls, int n_cl
 int csam_mask_post(void* stream, const float* lowres, const int* sel, int B, int in_h, int in_w, int out_h,
                    int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni, int* box,
                    float* tmp_f32);
+/* statistics pass of csam_mask_post that skips the prompts the predicted-IoU filter drops anyway (score[b] <= score_thr;
+ * score_thr <= 0: none skipped), as the reference filters on iou_preds before it computes stability
+ * (crowdsam/model.py:371-381) */
+int csam_mask_post_scored(void* stream, const float* lowres, const int* sel, const float* score, float score_thr, int B,
+                          int in_h, int in_w, int out_h, int out_w, float thr, float off, int* inter, int* uni,
+                          int* box, float* tmp_f32);
 /* two-pass mode: csam_mask_post with out_mask_u8 == NULL gives the statistics only; after csam_post_finalize
  * the bytes of the surviving prompts (keep[b] != 0) are produced by csam_mask_write. */
 int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, const int* slot_or_null,
