@@ -78,6 +78,38 @@ def test_mask_post_matches_oracle(cuda, in_hw, out_hw):
     assert torch.equal(occ.cpu().bool(), exp_keep & (score.cpu() > 0.7))
 
 
+@pytest.mark.parametrize("in_hw,out_hw", [((1024, 1024), (1024, 1024)), ((683, 1024), (600, 900))])
+def test_mask_post_scored_skips_only_what_the_iou_filter_drops(cuda, in_hw, out_hw):
+    """csam_mask_post_scored == csam_mask_post for prompts with score > thr; the others keep the initial statistics and
+    are rejected by the finalize step exactly as before (same keep / occ flags)."""
+    from crowdsam_amd import hip
+    B = 6
+    low = _smooth_logits(B, 5).to(cuda)
+    sel = torch.tensor([0, 1, 2, 3, 1, 0], dtype=torch.int32, device=cuda)
+    score = torch.tensor([0.05, 0.3, 0.1, 0.8, 0.0999, 0.11], device=cuda)
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=cuda)
+    tmp = torch.empty(B, in_hw[0], in_hw[1], device=cuda) if in_hw != out_hw else None
+    ia, ua, ba = i32(B), i32(B), i32(B, 4)
+    ib, ub, bb = i32(B), i32(B), i32(B, 4)
+    hip.mask_post(low, sel, B, in_hw, out_hw, 0.0, 1.0, None, ia, ua, ba, tmp)
+    hip.mask_post_scored(low, sel, score, 0.1, B, in_hw, out_hw, 0.0, 1.0, ib, ub, bb, tmp)
+    act = (score > 0.1).cpu()
+    assert torch.equal(ia.cpu()[act], ib.cpu()[act]) and torch.equal(ua.cpu()[act], ub.cpu()[act])
+    assert torch.equal(ba.cpu()[act], bb.cpu()[act])
+    assert (ib.cpu()[~act] == 0).all() and (ub.cpu()[~act] == 0).all()
+    outs = []
+    for (i, u, b) in ((ia, ua, ba), (ib, ub, bb)):
+        stab = torch.empty(B, device=cuda)
+        keep = torch.empty(B, dtype=torch.uint8, device=cuda)
+        occ = torch.empty(B, dtype=torch.uint8, device=cuda)
+        hip.post_finalize(score, i, u, b, 0.1, 0.5, 0.7, stab, keep, occ, B)
+        outs.append((keep.cpu(), occ.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # threshold <= 0 disables the skip (the reference only filters when pred_iou_thresh > 0)
+    hip.mask_post_scored(low, sel, score, 0.0, B, in_hw, out_hw, 0.0, 1.0, ib, ub, bb, tmp)
+    assert torch.equal(ia.cpu(), ib.cpu()) and torch.equal(ua.cpu(), ub.cpu())
+
+
 def test_occupancy_lookup(cuda):
     from crowdsam_amd import hip
     g = torch.Generator().manual_seed(2)
