@@ -87,6 +87,30 @@ __device__ __forceinline__ float2_t csam_gelu_poly2(float2_t x) {
   return x * ph;
 }
 
+// N independent pairs at once, coefficient-major: consecutive instructions belong to different Horner chains.  A
+// v_pk_fma_f32 whose input is the previous instruction's result costs an s_nop on gfx950 (the single-pair form above
+// compiles to fma / s_nop / fma / s_nop ...: 9 wasted issue slots per pair); interleaved chains have none.
+template <int N>
+__device__ __forceinline__ void csam_gelu_poly2_n(float2_t (&x)[N]) {
+  const float c = 4.4f;
+  const float k[9] = {4.471991608e-11f, -4.528126140e-09f, 2.016253663e-07f, -5.250151905e-06f, 9.008348436e-05f,
+                      -1.092016766e-03f, 9.773204936e-03f, -6.629599897e-02f, 3.988868129e-01f};
+  float2_t xc[N], u[N], r[N];
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    xc[p] = float2_t{__builtin_amdgcn_fmed3f(x[p][0], -c, c), __builtin_amdgcn_fmed3f(x[p][1], -c, c)};
+    u[p] = xc[p] * xc[p];
+  }
+#pragma unroll
+  for (int p = 0; p < N; ++p) r[p] = __builtin_elementwise_fma((float2_t){k[0], k[0]}, u[p], (float2_t){k[1], k[1]});
+#pragma unroll
+  for (int i = 2; i < 9; ++i)
+#pragma unroll
+    for (int p = 0; p < N; ++p) r[p] = __builtin_elementwise_fma(r[p], u[p], (float2_t){k[i], k[i]});
+#pragma unroll
+  for (int p = 0; p < N; ++p) x[p] = x[p] * __builtin_elementwise_fma(xc[p], r[p], (float2_t){0.5f, 0.5f});
+}
+
 // exp2 for softmax arguments (<= 0, results in (0, 1]): the bare v_exp_f32.  exp2f() wraps it in a denormal-range
 // rescue (compare + 2 selects + ldexp per call) that only matters for results below 2^-126, which a softmax
 // weight may flush to zero.

@@ -1144,17 +1144,26 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
         const float nmr = -mean * rstd;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
-          const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
+        for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time: registers
+          float2_t z[4];
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const float2_t av = {a1[mi][ni][e], a1[mi][ni][e + 1]};
-            const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
-            const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
-            const float2_t ge = csam_gelu_poly2(__builtin_elementwise_fma(nrm, g2, b2));
-            xf2[ni >> 1][(ni & 1) * 4 + e] = (half_t)ge[0];
-            xf2[ni >> 1][(ni & 1) * 4 + e + 1] = (half_t)ge[1];
+          for (int n2 = 0; n2 < 2; ++n2) {
+            const int ni = nh * 2 + n2;
+            const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
+            const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const float2_t av = {a1[mi][ni][e], a1[mi][ni][e + 1]};
+              const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
+              const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
+              z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
+            }
+          }
+          csam_gelu_poly2_n<4>(z);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
+            xf2[nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
+            xf2[nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
           }
         }
       }
@@ -1173,16 +1182,19 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
 #pragma unroll
       for (int pos2 = 0; pos2 < 4; ++pos2) {
         half8_t ub;
+        float2_t z[4];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const floatx4 bb = *(const floatx4*)(par + (pos2 * 2 + h2) * 16 + fg * 4);
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const float2_t z = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]} + (float2_t){bb[e], bb[e + 1]};
-            const float2_t ge = csam_gelu_poly2(z);
-            ub[h2 * 4 + e] = (half_t)ge[0];
-            ub[h2 * 4 + e + 1] = (half_t)ge[1];
-          }
+          for (int e = 0; e < 4; e += 2)
+            z[h2 * 2 + (e >> 1)] = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]} + (float2_t){bb[e], bb[e + 1]};
+        }
+        csam_gelu_poly2_n<4>(z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ub[q * 2] = (half_t)z[q][0];
+          ub[q * 2 + 1] = (half_t)z[q][1];
         }
         floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
