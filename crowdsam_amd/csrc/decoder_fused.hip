@@ -388,11 +388,6 @@ template <int QMODE, int NW, int MI_>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, int n_tiles, int tiles_per_wg) {
   typedef I2S<NW, MI_> G;
   constexpr int MI = G::MI, HPW = G::HPW, NIO = G::NIO, TOK = G::TOK;
-  // Projected form with 4 waves: Wq + Wo slices already take 128 VGPRs per wave, so fragments are single-buffered and
-  // the Q seeds are fetched at the top of their own tile instead of under the previous LayerNorm (the co-resident
-  // workgroup covers the exposed latency).
-  constexpr bool LEAN = false;
-  constexpr int NFB = 2;                   // fragment buffers
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS-DMA bases and weight slices are per wave
@@ -504,27 +499,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
     // (fragments of step ks+1 are read while the MFMAs of step ks run; the fence keeps the compiler from hoisting
     // the whole tile into registers)
     if (QMODE == 1) {
-      half8_t xf[NFB][MI];
+      half8_t xf[2][MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (NFB == 2 && ks + 1 < 8) {
+        if (ks + 1 < 8) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            xf[(ks + 1) % NFB][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+            xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int hh = 0; hh < HPW; ++hh)
-            qa[hh][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[hh][ks], xf[ks % NFB][mi], qa[hh][mi], 0, 0, 0);
+            qa[hh][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[hh][ks], xf[ks & 1][mi], qa[hh][mi], 0, 0, 0);
         asm volatile("" ::: "memory");
-        if (NFB == 1 && ks + 1 < 8) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
-        }
       }
     }
     // ---- 7-key attention of this wave's heads for the tile's tokens
@@ -550,7 +540,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
         const floatx4 sm = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const float inv = __builtin_amdgcn_rcpf(sm[0]);
         oh[hh][mi] = half4_t{(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
-        if (LEAN && (mi & 1)) asm volatile("" ::: "memory");   // bound the number of chains in flight (registers)
       }
     asm volatile("" ::: "memory");
     // ---- out-proj accumulators start from bias + residual (identity MFMA on the tile's own fragments)
@@ -565,7 +554,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
         const half4_t r = *(const half4_t*)(xb + row * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8);
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(eye, r, bo_r, 0, 0, 0);
       }
-      if (LEAN) asm volatile("" ::: "memory");
     }
     I2S_BARRIER();                                      // (e) every wave is done reading the key tile
     // ---- O exchange: [TOK][128 dims] fp16 over the first half of the tile buffer
@@ -579,27 +567,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
     I2S_BARRIER();                                      // (b)
     // ---- out-proj, K = 128 (O fragments double-buffered like the key fragments above)
     {
-      half8_t of[NFB][MI];
+      half8_t of[2][MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) of[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((fg ^ fr) << 4));
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (NFB == 2 && ks + 1 < 4) {
+        if (ks + 1 < 4) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            of[(ks + 1) % NFB][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+            of[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NIO; ++ni)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[ni][ks], of[ks % NFB][mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[ni][ks], of[ks & 1][mi], acc[ni][mi], 0, 0, 0);
         asm volatile("" ::: "memory");
-        if (NFB == 1 && ks + 1 < 4) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            of[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 256 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
-        }
       }
     }
     // next tile's register operands (their registers are dead now; the loads fly under the LayerNorm)
@@ -620,7 +603,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
       const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       if (fg == 0) part[wave * TOK + mi * 16 + fr] = float2_t{ssum[0], qsum[0]};
-      if (LEAN) asm volatile("" ::: "memory");
     }
     I2S_BARRIER();                                      // (c) partials visible; O no longer read
     // ---- combine over the waves, normalise, write the fp16 tile back over its LDS image
@@ -647,7 +629,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
         *(half4_t*)(xb + row * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
             half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
       }
-      if (LEAN) asm volatile("" ::: "memory");
     }
     // (d) tile complete; also retires the next tile's LDS-DMA (a whole tile old) and register operands
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
