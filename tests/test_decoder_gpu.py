@@ -75,3 +75,26 @@ def test_batch_invariance(plan, cuda):
     m_one, iou_one, cls_one = plan.run_batch(coords[2:3].contiguous())
     assert (m_all[2] - m_one[0]).abs().max().item() < 1e-3
     assert (iou_all[2] - iou_one[0]).abs().max().item() < 1e-4
+
+
+def test_large_batch_stream_kernels_match_small_batch_path(cuda):
+    """One 320-prompt batch runs the persistent token->image / upscaler kernels (>= 256 prompts); the same prompts in
+    chunks of 64 run the tile-per-workgroup kernels the reference golden above pins.  Both must give the same
+    low-res logits, IoU and class outputs (different kernels, same arithmetic up to fp16 / accumulation order)."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    sd = synth.make_sam_state_dict("vit_test128")
+    big = DecoderPlan(sd, cuda, n_class=1, max_batch=320)
+    _set_image(big, cuda)
+    assert big.t2i_stream and big.up_stream and big.i2t_stream
+    rs = np.random.RandomState(5)
+    coords = torch.from_numpy(rs.uniform(0, 1023, size=(320, 2)).astype(np.float32)).to(cuda)
+    m_big, iou_big, cls_big = [t.clone() for t in big.run_batch(coords)]
+    for c0 in range(0, 320, 64):
+        m, iou, cls = big.run_batch(coords[c0:c0 + 64].contiguous())
+        scale = m.abs().mean().item()
+        err = (m - m_big[c0:c0 + 64]).abs()
+        assert err.max().item() < 0.05 * max(scale, 1.0) and err.mean().item() < 2e-3 * max(scale, 1.0), \
+            (c0, err.max().item(), err.mean().item(), scale)
+        assert (iou - iou_big[c0:c0 + 64]).abs().max().item() < 5e-3
+        assert (cls - cls_big[c0:c0 + 64]).abs().max().item() < 5e-3
