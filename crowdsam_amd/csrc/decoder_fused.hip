@@ -1106,23 +1106,22 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
     for (int mi = 0; mi < 2; ++mi) {
       half8_t xf2[2];
       {
-        float sum = 0.f;
+        // LayerNorm2d statistics over the 64 channels of this pixel: in-lane partial sums (16 channels, packed),
+        // the four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)
+        float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) sum += (a1[mi][ni][0] + a1[mi][ni][1]) + (a1[mi][ni][2] + a1[mi][ni][3]);
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.f / 64.f);
-        float var = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float d = a1[mi][ni][e] - mean;
-            var += d * d;
-          }
-        var += __shfl_xor(var, 16, 64);
-        var += __shfl_xor(var, 32, 64);
-        const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
+        for (int ni = 0; ni < 4; ++ni) {
+          const float2_t lo = {a1[mi][ni][0], a1[mi][ni][1]}, hi = {a1[mi][ni][2], a1[mi][ni][3]};
+          s2 += lo;
+          q2 = __builtin_elementwise_fma(lo, lo, q2);
+          s2 += hi;
+          q2 = __builtin_elementwise_fma(hi, hi, q2);
+        }
+        const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float mean = ssum[0] * (1.f / 64.f);
+        const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + p.eps);
         const float nmr = -mean * rstd;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time: registers
