@@ -696,6 +696,251 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
 }
 
 // =====================================================================================================
+// csam_i2t_rank: the hoisted-Q (layer 0) image->token half-block in its rank-56 form.  With q (and the residual source)
+// shared by all prompts, a prompt enters only through its 7 token keys / values:
+//     out_proj(softmax(q K_b^T) V_b) = P_b M_b,   M_b[(h, j), :] = Wo[:, h] v_b[j, h]     (56 x 256, built per prompt)
+// so the PV product, the O exchange between waves and half of the out-proj MFMA work disappear, and -- the point --
+// every WAVE can own 16 tokens with ALL 256 channels: attention, out-proj, residual, LayerNorm and the store staging
+// are wave-local, there is NO barrier inside a prompt, and the waves of a workgroup run free (the ablation of the
+// 5-barrier stream kernel showed its phases simply add up).  M_b^T (32 KB) sits in LDS per prompt; scores of two heads
+// come from ONE 16x16x32 MFMA (A = [K_h0 | 0 ; 0 | K_h1], B = 32 q dims), two such results pack the 8 k-slots of a
+// P.M operand: slot (ks, fg, e) <-> head 4 ks + 2 (e >> 2) + (fg >> 1), key 4 (fg & 1) + (e & 3).
+// =====================================================================================================
+namespace {
+
+constexpr int IR_M_BYTES = 256 * 64 * 2;            // M_b^T [256 channels][64 k-slots] fp16
+constexpr int IR_SLICE = 16 * 512;                  // per-wave output staging, 16 tokens x 256 ch fp16
+constexpr int IR_PAR = IR_M_BYTES + 4 * IR_SLICE;   // bo | gamma | beta fp32
+constexpr int IR_SMEM = IR_PAR + 3 * 256 * 4;
+
+struct IrArgs {
+  const half_t* X; long x_bstride; const half_t* Q; long q_bstride;
+  const half_t* ks;          // [B,7,128] token-side k, pre-multiplied by 0.25 log2(e)
+  const half_t* M;           // [B][256][64] from i2t_rank_prep_kernel
+  const float* bo; const float* gamma; const float* beta; float eps;
+  half_t* out; int B; int T;
+};
+
+// M_b^T[c][slot] = sum_d Wo[c][head*16 + d] v[b][j][head*16 + d]  (j = 7: zero), slot order as in the header
+__global__ __launch_bounds__(256) void i2t_rank_prep_kernel(const half_t* __restrict__ v, const half_t* __restrict__ Wo,
+                                                            half_t* __restrict__ M) {
+  __shared__ float vs[7 * 128];
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int i = c; i < 7 * 128; i += 256) vs[i] = (float)v[(long)b * 7 * 128 + i];
+  __syncthreads();
+  float w[128];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const half8_t h = *(const half8_t*)(Wo + (long)c * 128 + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[i * 8 + e] = (float)h[e];
+  }
+  half_t* dst = M + ((long)b * 256 + c) * 64;
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {              // s8 = ks * 4 + fg
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ks = s8 >> 2, fg = s8 & 3;
+      const int head = 4 * ks + 2 * (e >> 2) + (fg >> 1), j = 4 * (fg & 1) + (e & 3);
+      float acc = 0.f;
+      if (j < 7) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc = fmaf(w[head * 16 + d], vs[j * 128 + head * 16 + d], acc);
+      }
+      o[e] = (half_t)acc;
+    }
+    *(half8_t*)(dst + s8 * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  char* slice = smem + IR_M_BYTES + wave * IR_SLICE;
+  float* par = (float*)(smem + IR_PAR);
+  par[tid] = p.bo[tid];
+  par[256 + tid] = p.gamma[tid];
+  par[512 + tid] = p.beta[tid];
+  const int tpp = p.T / 16;
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, p.B);
+  // residual: acc[2 nj + h] += E_h . X^T with E_0 = [I16 | 0], E_1 = [0 | I16] over a 32-channel (16 B per lane) fragment
+  half8_t eye_lo, eye_hi;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    eye_lo[e] = (half_t)((fg < 2 && fg * 8 + e == fr) ? 1.f : 0.f);
+    eye_hi[e] = (half_t)((fg >= 2 && (fg - 2) * 8 + e == fr) ? 1.f : 0.f);
+  }
+  const bool key7 = (fg & 1) == 1;                   // this lane's 4th key is the non-existent 8th of its head
+
+  floatx4 qraw[4];                                   // 4 x half8: 32 q dims of head pair pr for token fr
+  floatx4 xres[8];                                   // 8 x half8 residual fragments: channels nj*32 + fg*8 .. +7 of token fr
+  for (int b = b_first; b < b_last; ++b) {
+    __syncthreads();                                 // every wave is done with the previous prompt's M
+    {
+      const char* src = (const char*)(p.M + (long)b * 256 * 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                  // 256 rows x 8 slots of 16 B, slot ^= row & 7
+        const int c = tid + i * 256, row = c >> 3, sl = c & 7;
+        i2s_glds16(src, (unsigned)(row * 128 + ((sl ^ (row & 7)) << 4)), lds0 + (unsigned)(wave * 1024 + i * 4096));
+      }
+    }
+    // paired-head key fragments: rows 0-7 = K_h0 (dims in k 0..15), rows 8-15 = K_h1 (dims in k 16..31)
+    half8_t kfr[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      half8_t kv = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int j = fr & 7, hsel = fr >> 3;          // row -> key j of head 2 pr + hsel
+      if (j < 7 && (fg >> 1) == hsel)
+        kv = *(const half8_t*)(p.ks + ((long)b * 7 + j) * 128 + (2 * pr + hsel) * 16 + (fg & 1) * 8);
+      kfr[pr] = kv;
+      asm volatile("" : "+v"(kfr[pr]));              // tracked loads: the compiler's wait lands here, once per prompt
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto prefetch = [&](int tile) {
+      const int t0 = tile * 16;
+      const char* qb = (const char*)(p.Q + (long)b * p.q_bstride + (long)t0 * 128);
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) qraw[pr] = i2s_load16(qb + pr * 64, (unsigned)(fr * 256 + fg * 16));
+      const char* xb = (const char*)(p.X + (long)b * p.x_bstride + (long)t0 * 256);
+#pragma unroll
+      for (int nj = 0; nj < 8; ++nj) xres[nj] = i2s_load16(xb + nj * 64, (unsigned)(fr * 512 + fg * 16));
+    };
+    prefetch(wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    for (int tile = wave; tile < tpp; tile += 4) {
+      const int t0 = tile * 16;
+      // ---- scores of the 8 heads (two per MFMA) and their softmax over the 7 keys
+      half8_t pf[2];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        half8_t qf;
+        __builtin_memcpy(&qf, &qraw[pr], 16);
+        const floatx4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[pr], qf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float s3 = key7 ? -INFINITY : s4[3];
+        float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        const float p0 = csam_exp2(s4[0] - mx), p1 = csam_exp2(s4[1] - mx);
+        const float p2 = csam_exp2(s4[2] - mx), p3 = csam_exp2(s3 - mx);
+        float sum = (p0 + p1) + (p2 + p3);
+        sum += __shfl_xor(sum, 16, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const int o = (pr & 1) * 4;
+        pf[pr >> 1][o] = (half_t)(p0 * inv);
+        pf[pr >> 1][o + 1] = (half_t)(p1 * inv);
+        pf[pr >> 1][o + 2] = (half_t)(p2 * inv);
+        pf[pr >> 1][o + 3] = (half_t)(p3 * inv);
+      }
+      // ---- accumulators = out-proj bias + residual (identity MFMA on the prefetched fragments)
+      floatx4 acc[16];
+#pragma unroll
+      for (int nj = 0; nj < 8; ++nj) {
+        half8_t xf;
+        __builtin_memcpy(&xf, &xres[nj], 16);
+        const floatx4 b0 = *(const floatx4*)(par + nj * 32 + fg * 4);
+        const floatx4 b1 = *(const floatx4*)(par + nj * 32 + 16 + fg * 4);
+        acc[2 * nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_lo, xf, b0, 0, 0, 0);
+        acc[2 * nj + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_hi, xf, b1, 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+      if (tile + 4 < tpp) prefetch(tile + 4);          // the q / residual registers are free: next tile's operands
+      // ---- P . M_b : [256 channels] x [16 tokens], K = 64 slots
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) {
+          if ((ni & 3) == 0) asm volatile("" ::: "memory");
+          const int row = ni * 16 + fr;
+          const half8_t mf = *(const half8_t*)(smem + row * 128 + (((ks * 4 + fg) ^ (row & 7)) << 4));
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf, pf[ks], acc[ni], 0, 0, 0);
+        }
+      }
+      // ---- LayerNorm over the 256 channels of token fr: in-lane 64 values, lane groups by an fp32 ones-MFMA
+      float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+      for (int ni = 0; ni < 16; ++ni) {
+        const float2_t a = {acc[ni][0], acc[ni][1]}, c2 = {acc[ni][2], acc[ni][3]};
+        s2 += a;
+        q2 = __builtin_elementwise_fma(a, a, q2);
+        s2 += c2;
+        q2 = __builtin_elementwise_fma(c2, c2, q2);
+      }
+      const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const float mean = ssum[0] * (1.f / 256.f);
+      const float var = fmaxf(qsum[0] * (1.f / 256.f) - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + p.eps);
+      const float2_t rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
+#pragma unroll
+      for (int ni = 0; ni < 16; ++ni) {
+        if ((ni & 3) == 0) asm volatile("" ::: "memory");
+        const floatx4 g = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
+        const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
+        const float2_t g0 = {g[0], g[1]}, g1 = {g[2], g[3]}, b0 = {be[0], be[1]}, b1 = {be[2], be[3]};
+        const float2_t v0 = {acc[ni][0], acc[ni][1]}, v1 = {acc[ni][2], acc[ni][3]};
+        const float2_t y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(v0, rs2, nm2), g0, b0);
+        const float2_t y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(v1, rs2, nm2), g1, b1);
+        const int chunk = ni * 2 + (fg >> 1);
+        *(half4_t*)(slice + fr * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
+            half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
+      }
+      // next tile's operands have had the whole tile to land; retire them BEFORE this tile's stores are issued
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      char* obase = (char*)(p.out + ((long)b * p.T + t0) * 256);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = lane + i * 64, row = idx >> 5, sl = idx & 31;
+        const half8_t v = *(const half8_t*)(slice + idx * 16);
+        i2s_store16(obase, (unsigned)(row * 512 + ((sl ^ (row & 15)) << 4)), v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is rewritten by the next tile
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long csam_i2t_rank_workspace_bytes(int B) { return (long)B * 256 * 64 * 2; }
+
+extern "C" int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                             const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
+                             const float* gamma, const float* beta, float eps, void* out_f16, int B, int T,
+                             void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(X_f16 && Q_f16 && k_scaled_f16 && v_f16 && Wo_f16 && bo && gamma && beta && out_f16 && workspace,
+               "csam_i2t_rank: null pointer");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % 64 == 0, "csam_i2t_rank: T must be a multiple of 64");
+  if (workspace_bytes < csam_i2t_rank_workspace_bytes(B)) {
+    csam_set_error("csam_i2t_rank: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute((const void*)i2t_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IR_SMEM);
+  }
+  hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)v_f16,
+                     (const half_t*)Wo_f16, (half_t*)workspace);
+  IrArgs a;
+  a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
+  a.ks = (const half_t*)k_scaled_f16; a.M = (const half_t*)workspace; a.bo = bo; a.gamma = gamma; a.beta = beta;
+  a.eps = eps; a.out = (half_t*)out_f16; a.B = B; a.T = T;
+  const int per = csam_cdiv(B, 2 * n_cu);
+  hipLaunchKernelGGL(i2t_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), IR_SMEM, (hipStream_t)stream, a, per);
+  CSAM_LAUNCH_CHECK("csam_i2t_rank");
+  return CSAM_OK;
+}
+
+// =====================================================================================================
 // csam_upscale_fused: mask_decoder.py:172-181 in ONE kernel, one pass over the final key state:
 //   up1 = ConvT(256->64,k2,s2)(keys)  ->  LayerNorm2d(64) -> GELU  ->  ConvT(64->32,k2,s2) -> GELU
 //   masks[b,l,Y,X] = sum_c hyper[b,l,c] * up2[b,c,Y,X]

@@ -113,6 +113,7 @@ class DecoderPlan:
         self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "1") != "0"
         self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
         self.up_stream = os.environ.get("CSAM_UP_STREAM", "1") != "0"     # persistent upscaler (B >= 256)
+        self.i2t_rank = os.environ.get("CSAM_I2T_RANK", "1") != "0"       # rank-56 layer-0 image->token (B >= 256)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -233,7 +234,9 @@ class DecoderPlan:
             pooled16=e(B * 4, 256),
             stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
-            t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev))
+            t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev),
+            # per-prompt M_b^T of the rank-56 layer-0 image->token kernel (32 KB / prompt; only used from 256 prompts)
+            i2t_rank_ws=e(hip.i2t_rank_workspace_bytes(B if B >= 256 else 1) // 2))
         self.allocB = B
         self.batch_graphs.clear()
 
@@ -363,7 +366,11 @@ class DecoderPlan:
             hip.gemm_f16(qpe16, kw, out=ws["i2t_k"][:M7], bias=kb)
             hip.gemm_f16(q16, L["i2t_v_w"], out=ws["i2t_v"][:M7], bias=L["i2t_v_b"])
             if stream:
-                if li == 0:
+                if li == 0 and self.i2t_rank and B >= 256:
+                    # hoisted-Q layer in its rank-56 form (whole prompts per workgroup: needs >= 256 prompts)
+                    hip.i2t_rank(st["src16"], 0, st["qi0"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                 L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, ws["i2t_rank_ws"])
+                elif li == 0:
                     hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
                                    L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
                 else:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
+    "csam_i2t_rank": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _L],
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
@@ -83,6 +84,7 @@ LONG_RETURNS = {
     "csam_small_regions_workspace_bytes": [_I, _I, _I],
     "csam_t2i_fused_workspace_bytes": [_I],
     "csam_flash_attn_workspace_bytes": [_I, _I],
+    "csam_i2t_rank_workspace_bytes": [_I],
 }
 
 _lib = None
@@ -606,6 +608,18 @@ def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None
     """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out
+
+
+def i2t_rank_workspace_bytes(B):
+    return lib().csam_i2t_rank_workspace_bytes(B)
+
+
+def i2t_rank(X, x_bstride, Q, q_bstride, k_scaled, v, Wo, bo, gamma, beta, eps, out, B, T, workspace):
+    """Hoisted-Q image->token half-block in its rank-56 form (wave-local, barrier-free inside a prompt)."""
+    call("csam_i2t_rank", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(k_scaled), _ptr(v), _ptr(Wo), _ptr(bo),
+         _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T, _ptr(workspace),
+         workspace.numel() * workspace.element_size())
     return out
 
 

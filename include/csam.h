@@ -162,6 +162,14 @@ int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_stride, const
                     const void* Wq_f16, const float* qpe, const void* k_scaled_f16, const void* v_f16,
                     const void* Wo_f16, const float* bo, const float* gamma, const float* beta, float eps,
                     void* out_f16, int B, int T);
+/* the hoisted-Q (layer 0) form of the same half-block in its rank-56 formulation: out_proj(softmax(q K_b^T) V_b) = P_b M_b
+ * with M_b[(head, key), :] = Wo[:, head] v_b[key, head] built per prompt into `workspace` (csam_i2t_rank_workspace_bytes).
+ * Every wave owns 16 tokens with all 256 channels, so there is no barrier inside a prompt.  Q_f16 [T,128] is the hoisted
+ * projection (bias + pe included), k_scaled_f16 as for csam_i2t_stream, Wo_f16 the plain [256,128] out-proj weight. */
+long csam_i2t_rank_workspace_bytes(int B);
+int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                  const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo, const float* gamma,
+                  const float* beta, float eps, void* out_f16, int B, int T, void* workspace, long workspace_bytes);
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,

@@ -66,3 +66,37 @@ def test_i2t_stream_hoisted_q(cuda, B):
     ref = _ref(Xf, q, (k_s.float() / SC).view(B, 7, 128), v.float().view(B, 7, 128), Wo.float(), bo, g, be, 1e-5)
     err = (out.float().view(B, T, 256) - ref).abs()
     assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("B", [1, 2, 19, 530])
+def test_i2t_rank_hoisted_q(cuda, B):
+    """csam_i2t_rank (rank-56, wave-local form of the hoisted-Q layer) against the same fp32 reference and against
+    csam_i2t_stream; bitwise repeatable."""
+    from crowdsam_amd import hip
+    T = 4096
+    gen = torch.Generator().manual_seed(200 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(cuda)
+    X = r(T, 256, sc=0.7).half()
+    Q = r(T, 128, sc=0.9).half()
+    k, v = r(B * 7, 128, sc=0.8), r(B * 7, 128, sc=0.8).half()
+    Wo, bo = r(256, 128, sc=0.08).half(), r(256, sc=0.2)
+    g, be = (torch.rand(256, generator=gen) + 0.5).to(cuda), r(256, sc=0.2)
+    k_s = (k * SC).half()
+    ws = torch.empty(hip.i2t_rank_workspace_bytes(B) // 2, dtype=torch.float16, device=cuda)
+    out = torch.zeros(B * T, 256, dtype=torch.float16, device=cuda)
+    hip.i2t_rank(X, 0, Q, 0, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, ws)
+    nref = min(B, 6)                                     # reference on the first prompts and the last one
+    idx = list(range(nref - 1)) + [B - 1] if B > 1 else [0]
+    sel = torch.tensor(idx, device=cuda)
+    Xf = X.float().view(1, T, 256).expand(len(idx), T, 256)
+    q = Q.float().view(1, T, 128).expand(len(idx), T, 128)
+    ref = _ref(Xf, q, (k_s.float() / SC).view(B, 7, 128)[sel], v.float().view(B, 7, 128)[sel], Wo.float(), bo, g, be, 1e-5)
+    err = (out.float().view(B, T, 256)[sel] - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
+    out2 = torch.zeros_like(out)
+    hip.i2t_stream(X, 0, k_s, v, Wo, bo, g, be, 1e-5, out2, B, T, Q=Q, q_bstride=0)
+    d = (out.float() - out2.float()).abs()
+    assert d.max().item() < 2e-2 and d.mean().item() < 1e-3, (d.max().item(), d.mean().item())
+    out3 = torch.zeros_like(out)
+    hip.i2t_rank(X, 0, Q, 0, k_s, v, Wo, bo, g, be, 1e-5, out3, B, T, ws)
+    assert torch.equal(out.view(torch.int16), out3.view(torch.int16))
