@@ -1392,9 +1392,9 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
           }
         }
       }
-      floatx4 a2[8];
+      floatx4 a2[8];                                    // seeded with the second conv's bias
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) a2[n2] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int n2 = 0; n2 < 8; ++n2) a2[n2] = *(const floatx4*)(par + n2 * 16 + fg * 4);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -1409,12 +1409,9 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         half8_t ub;
         float2_t z[4];
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const floatx4 bb = *(const floatx4*)(par + (pos2 * 2 + h2) * 16 + fg * 4);
+        for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-          for (int e = 0; e < 4; e += 2)
-            z[h2 * 2 + (e >> 1)] = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]} + (float2_t){bb[e], bb[e + 1]};
-        }
+          for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]};
         csam_gelu_poly2_n<4>(z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
