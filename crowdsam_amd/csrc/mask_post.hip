@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
   const float* p = a.src + (long)b * a.src_bstride + (long)a.sel[b] * a.plane;
   const int i = blockIdx.x;                      // 16 output rows: y = 16 i .. 16 i + 15
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+  // PASS 0 box: per-pixel work is one OR into a column flag and one into the row flag; the extents are taken from the
+  // flags once per row (y) and once per thread (x) instead of four predicated min / max per pixel
+  uint32_t colany[4] = {0u, 0u, 0u, 0u};
   // source columns t-1, t, t+1 and rows 4i-1 .. 4i+4 (clamped)
   const int c0 = max(tid - 1, 0), c1 = tid, c2 = min(tid + 1, 255);
   float v[6][3];
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
       const int k0 = (yy < 2) ? 0 : (yy < 6) ? 1 : (yy < 10) ? 2 : (yy < 14) ? 3 : 4;
       const bool same = (y1 == y0);
       const float w0y = 1.f - ly;
-      uint32_t packed = 0;
+      uint32_t packed = 0, rowany = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int x = x4 + e;
@@ -251,16 +254,18 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
             cnt_i += val > hi_t;
             cnt_u += val > lo_t;
           }
-          if (val > a.thr) {
+          if (PASS == 0) {
+            const uint32_t in = val > a.thr ? 1u : 0u;
+            colany[e] |= in;
+            rowany |= in;
+          } else if (val > a.thr) {
             packed |= 1u << (8 * e);
-            if (PASS == 0) {
-              xmin = min(xmin, x);
-              xmax = max(xmax, x);
-              ymin = min(ymin, y);
-              ymax = max(ymax, y);
-            }
           }
         }
+      }
+      if (PASS == 0 && rowany) {
+        ymin = min(ymin, y);
+        ymax = max(ymax, y);
       }
       if (PASS == 1) {
         const long o = ((long)(a.slot ? a.slot[b] : b) * a.H + y) * a.W + x4;
@@ -273,6 +278,12 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
     }
   }
   if (PASS == 1) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (colany[e]) {
+      xmin = min(xmin, x4 + e);
+      xmax = max(xmax, x4 + e);
+    }
   __shared__ int red[4][6];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
