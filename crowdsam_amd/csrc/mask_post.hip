@@ -9,6 +9,7 @@
 // (256 KB/prompt, L2-resident) and each output pixel is produced once: bilinear x4 -> thresholds
 // -> u8 mask byte + wave-reduced stability counts and bbox extents (integer atomics, deterministic).
 #include "csam_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -228,55 +229,63 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
       hl[k][e] = w0x * t0 + lx * t1;
     }
   }
-  if (x4 < a.W) {
-    const float hi_t = a.thr + a.off, lo_t = a.thr - a.off;
+  // The row loop exists twice: FULL (the whole 16 x 1024 tile lies inside the mask: no per-pixel bounds tests, which
+  // hipcc otherwise turns into an exec-mask branch per pixel -- 24 VALU + 9 SALU instructions per pixel measured) and
+  // the general edge version.
+  const float hi_t = a.thr + a.off, lo_t = a.thr - a.off;
+  auto rows = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int yy = 0; yy < 16; ++yy) {
       const int y = i * 16 + yy;
-      if (y >= a.H) break;
-      int y0, y1;
-      float ly;
-      src_index(0.25f, y, 256, y0, y1, ly);
+      if (!FULL && y >= a.H) break;
       // static row slots: y0 = 4i + o, o = floor(0.25*yy - 0.375) in {-1,0,1,2,3}; y1 is the next slot
       // (clamping only ever selects a row whose weight is exactly 0, or the same clamped row)
       const int k0 = (yy < 2) ? 0 : (yy < 6) ? 1 : (yy < 10) ? 2 : (yy < 14) ? 3 : 4;
-      const bool same = (y1 == y0);
+      bool same = false;
+      float ly;
+      if (FULL) {      // interior tile: src = (y + 0.5) / 4 - 0.5 is never clamped, its fraction depends on yy only
+        ly = (float)((yy + 2) & 3) * 0.25f + 0.125f;
+      } else {
+        int y0, y1;
+        src_index(0.25f, y, 256, y0, y1, ly);
+        same = (y1 == y0);
+      }
       const float w0y = 1.f - ly;
       uint32_t packed = 0, rowany = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int x = x4 + e;
-        if (x < a.W) {
+        if (FULL || x < a.W) {
           const float tt = hl[k0][e];
           const float bb = same ? hl[k0][e] : hl[k0 + 1][e];
           const float val = w0y * tt + ly * bb;
           if (PASS == 0) {
             cnt_i += val > hi_t;
             cnt_u += val > lo_t;
-          }
-          if (PASS == 0) {
-            const uint32_t in = val > a.thr ? 1u : 0u;
-            colany[e] |= in;
-            rowany |= in;
-          } else if (val > a.thr) {
-            packed |= 1u << (8 * e);
+            colany[e] = val > a.thr ? 1u : colany[e];
+            rowany = val > a.thr ? 1u : rowany;
+          } else {
+            packed |= (val > a.thr ? 1u : 0u) << (8 * e);
           }
         }
       }
-      if (PASS == 0 && rowany) {
-        ymin = min(ymin, y);
-        ymax = max(ymax, y);
+      if (PASS == 0) {
+        ymin = min(ymin, rowany ? y : (1 << 30));
+        ymax = max(ymax, rowany ? y : -1);
       }
       if (PASS == 1) {
         const long o = ((long)(a.slot ? a.slot[b] : b) * a.H + y) * a.W + x4;
-        if (x4 + 3 < a.W && (o & 3) == 0) {
+        if (FULL || (x4 + 3 < a.W && (o & 3) == 0)) {
           *(uint32_t*)(a.out_mask + o) = packed;
         } else {
           for (int e = 0; e < 4 && x4 + e < a.W; ++e) a.out_mask[o + e] = (packed >> (8 * e)) & 1;
         }
       }
     }
-  }
+  };
+  if (a.W == 1024 && a.H == 1024 && i > 0 && i < 63) rows(std::true_type{});
+  else if (x4 < a.W) rows(std::false_type{});
   if (PASS == 1) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
