@@ -91,8 +91,15 @@ class CrowdSAM:
         self.pos_sim_thresh = t["pos_sim_thresh"]
         self.output_rles = t["output_rles"]
         self.mask_nms_thresh = float(t.get("mask_nms_thresh", 0.0))     # build's opt-in knob, see _process_crop
-        if self.mask_selection != "max_iou":
-            raise NotImplementedError("only mask_selection='max_iou' (the shipped config) runs on the fused HIP path")
+        if self.mask_selection == "all":
+            # the reference's own 'all' branch returns a float tensor that is then used as an index
+            # (crowdsam/model.py:326-327,355) and raises IndexError: there is no behaviour to reproduce
+            raise NotImplementedError("mask_selection='all' is broken in the reference (float tensor used as an index)")
+        if self.mask_selection not in ("max_iou", "max_area", "min_area"):
+            raise NotImplementedError(f"unknown mask_selection '{self.mask_selection}'")
+        if self.max_size > 1024:
+            # the mask post-processing kernels keep a 1024-pixel output row in registers (256 lanes x 4 pixels)
+            raise NotImplementedError("test.max_size > 1024 is not supported by the fused mask post-processing kernels")
         if self.apply_box_offsets:
             raise NotImplementedError("apply_box_offsets is off in the shipped config (the decoder has no offset head)")
         self.timings = {}
@@ -118,9 +125,20 @@ class CrowdSAM:
         if not isinstance(image, np.ndarray):
             image = np.array(image, dtype=np.uint8)
         self.orig_image = image
-        image, r = utils.resize_image(image[y0:y1, x0:x1, :], self.max_size)
-        self.image = image
+        # utils.resize_image of the reference (cv2.resize) on the GPU: the crop is uploaded ONCE (the one H2D per
+        # crop) and resized there; ``self.image`` (the reference's ndarray attribute) is materialised lazily
+        crop = image[y0:y1, x0:x1, :]
+        self._frame_u8, self._frame_f32, r = utils.resize_frame_device(crop, self.max_size, self.device)
+        self._image_np = np.ascontiguousarray(crop) if self._frame_f32 is None else None
+        self.image_hw = tuple(self._frame_u8.shape[:2])
         self.downscale = r
+
+    @property
+    def image(self):
+        """The resized crop as an ndarray (reference attribute, crowdsam/model.py:130); one D2H on first access."""
+        if self._image_np is None:
+            self._image_np = self._frame_u8.cpu().numpy()
+        return self._image_np
 
     @torch.no_grad()
     def generate(self, image):
@@ -146,8 +164,15 @@ class CrowdSAM:
         if len(data._stats.keys()) > 0:
             del data["iou_preds"]
         else:
+            # no detection at all (crowdsam/model.py:181-183 sets boxes / scores only; tools/test.py:71 copes by
+            # filtering on the keys present).  The remaining per-mask fields are set empty as well so that callers
+            # indexing them directly do not raise.
             data["boxes"] = torch.zeros(0, 4)
             data["scores"] = torch.zeros(0, 4)
+            data["categories"] = torch.zeros(0, dtype=torch.long)
+            data["points"] = torch.zeros(0, 2)
+            data["stability_score"] = torch.zeros(0)
+            data["fboxes"] = torch.zeros(0, 4)
         data["rles"] = [coco_encode_rle(r) for r in data["rles"]] if "rles" in data else []
         data.to_numpy()
         return data
@@ -155,7 +180,7 @@ class CrowdSAM:
     # ------------------------------------------------------------------------------------------
     def sample_prompts(self):
         """FG prior -> grid -> threshold -> pixel coordinates (crowdsam/model.py:196-223)."""
-        h, w = self.image.shape[:2]
+        h, w = self.image_hw
         g = self.grid_size
         img_size = torch.tensor([h, w])
         feat_size = (img_size * min(g / img_size)).int()
@@ -188,9 +213,9 @@ class CrowdSAM:
     def _process_crop(self, image, crop_box):
         t0 = time.perf_counter()
         self.crop_image(image, crop_box)
-        self.predictor.set_image(self.image)
+        self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
         t0 = self._tick("set_image", t0)
-        H, W = self.image.shape[:2]
+        H, W = self.image_hw
         orig_h, orig_w = self.orig_image.shape[:2]
         points_for_image = self.sample_prompts()
         t0 = self._tick("sample_prompts", t0)
@@ -226,10 +251,6 @@ class CrowdSAM:
         data = MaskData(masks=store["masks"][:n].view(torch.bool), iou_preds=store["score"][:n],
                         points=store["points"][:n].long(), categories=store["category"][:n].long(),
                         stability_score=store["stability"][:n], boxes=store["boxes"][:n].long())
-        if self.crop_n_layers > 0:
-            keep = ~utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h], self.downscale)
-            if not torch.all(keep):
-                data.filter(keep)
         t0 = self._tick("gather", t0)
 
         keep = batched_nms(data["boxes"].float(), data["iou_preds"], None, self.box_nms_thresh)
@@ -261,9 +282,18 @@ class CrowdSAM:
         return data
 
     def select_mask(self, masks, iou_preds):
-        if self.mask_selection != "max_iou":
+        """API mirror of crowdsam/model.py:318-331 for materialised [B,4,H,W] logits (the fused path selects inside
+        _process_batch without materialising them)."""
+        bin_masks = masks > self.predictor.model.mask_threshold
+        if self.mask_selection == "max_area":
+            ind = bin_masks.sum(dim=[-1, -2]).max(dim=-1)[1]
+        elif self.mask_selection == "min_area":
+            ind = bin_masks.sum(dim=[-1, -2]).min(dim=-1)[1]
+        elif self.mask_selection == "max_iou":
+            ind = iou_preds.max(dim=-1)[1]
+        else:
             raise NotImplementedError
-        return torch.arange(len(masks)), iou_preds.max(dim=-1)[1]
+        return torch.arange(len(masks)), ind
 
     def _process_batch(self, points, im_size, crop_box, store):
         """One EPS batch, entirely asynchronous: decode B prompts, PWD-Net selection, statistics pass, filters +
@@ -279,11 +309,24 @@ class CrowdSAM:
         i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
         sel, category = i32(B), i32(B)
         score = torch.empty(B, dtype=torch.float32, device=dev)
-        hip.select_masks(iou, cls, cls.shape[-1], sel, score, category, None, B)
+        fused4 = torch.empty(B, 4, dtype=torch.float32, device=dev) if self.mask_selection != "max_iou" else None
+        hip.select_masks(iou, cls, cls.shape[-1], sel, score, category, fused4, B)
         inter, uni, box = i32(B), i32(B), i32(B, 4)
         tmp = None
         if tuple(p.input_size) != (H, W):
             tmp = torch.empty(B, p.input_size[0], p.input_size[1], dtype=torch.float32, device=dev)
+        if fused4 is not None:
+            # mask_selection max_area / min_area (crowdsam/model.py:320-323; not the shipped config): pixel counts of
+            # the four thresholded candidates at the output resolution, one statistics pass per candidate
+            areas = torch.empty(4, B, dtype=torch.int32, device=dev)
+            for c in range(4):
+                hip.mask_post_scored(low, torch.full((B,), c, dtype=torch.int32, device=dev), score, 0.0, B, p.input_size,
+                                     (H, W), p.model.mask_threshold, 0.0, inter, areas[c], box, tmp)
+            a = areas.t().contiguous().long()
+            ind = a.max(dim=-1)[1] if self.mask_selection == "max_area" else a.min(dim=-1)[1]
+            sel.copy_(ind)
+            score.copy_(fused4.gather(1, ind[:, None])[:, 0])
+            category.copy_(cls.max(dim=-1)[1].gather(1, ind[:, None])[:, 0])
         # pass 1: statistics of the selected candidates that pass the predicted-IoU filter (the reference filters on
         # it before it computes stability, crowdsam/model.py:371-376 there); no mask bytes yet
         hip.mask_post_scored(low, sel, score, self.pred_iou_thresh, B, p.input_size, (H, W), p.model.mask_threshold,
@@ -292,10 +335,14 @@ class CrowdSAM:
         occ = torch.empty(B, dtype=torch.uint8, device=dev)
         slot = i32(B)
         pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+        edge = None
+        if self.crop_n_layers > 0:      # per batch, before the occupancy flags (crowdsam/model.py:386-389)
+            orig_h, orig_w = self.orig_image.shape[:2]
+            edge = (crop_box, [0, 0, orig_w, orig_h], self.downscale, 20.0)
         hip.post_finalize_compact(score, inter, uni, box, category, pts_dev, self.pred_iou_thresh,
                                   self.stability_score_thresh,
                                   self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
-                                  keep, occ, slot, store["counter"], store, B)
+                                  keep, occ, slot, store["counter"], store, B, edge=edge)
         # pass 2: mask bytes of the survivors, straight into their store slots
         hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, store["masks"], tmp, slot=slot)
         return dict(occ=occ, slot=slot)

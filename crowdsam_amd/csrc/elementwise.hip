@@ -190,6 +190,57 @@ __global__ __launch_bounds__(256) void sigmoid_max_kernel(const float* __restric
   out[i] = m;
 }
 
+// cv2.resize(image, (w, h)) of the reference's frame resize (crowdsam/utils.py:149; INTER_LINEAR, uint8, 3 channels)
+// on the already-uploaded frame: OpenCV's generic fixed-point path restated (11-bit coefficients built by the host
+// exactly as cv::resize builds them; horizontal pass into int32, vertical pass
+// (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; the exact-2x decimation is INTER_AREA's (a+b+c+d+2)>>2).
+// One thread per output pixel; writes the uint8 HWC frame and/or the fp32 CHW tensor the encoders read.
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw,
+                                                               const int* __restrict__ xofs,
+                                                               const short* __restrict__ xcoef,
+                                                               const int* __restrict__ yofs,
+                                                               const short* __restrict__ ycoef, int dh, int dw,
+                                                               int area2x, uint8_t* __restrict__ dst_u8,
+                                                               float* __restrict__ dst_chw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= dh * dw) return;
+  const int y = idx / dw, x = idx - y * dw;
+  int v[3];
+  if (area2x) {
+    const uint8_t* p = src + ((long)(2 * y) * sw + 2 * x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (p[c] + p[3 + c] + p[(long)sw * 3 + c] + p[(long)sw * 3 + 3 + c] + 2) >> 2;
+  } else {
+    const int x0 = xofs[x], x1 = min(x0 + 1, sw - 1);
+    const int a0 = xcoef[2 * x], a1 = xcoef[2 * x + 1];
+    const int r0 = yofs[2 * y], r1 = yofs[2 * y + 1];
+    const int b0 = ycoef[2 * y], b1 = ycoef[2 * y + 1];
+    const uint8_t* p0 = src + (long)r0 * sw * 3;
+    const uint8_t* p1 = src + (long)r1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int s0 = p0[x0 * 3 + c] * a0 + p0[x1 * 3 + c] * a1;
+      const int s1 = p1[x0 * 3 + c] * a0 + p1[x1 * 3 + c] * a1;
+      v[c] = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int u = v[c] & 255;                      // uchar(...) cast of OpenCV (the value is already in 0..255)
+    if (dst_u8) dst_u8[(long)idx * 3 + c] = (uint8_t)u;
+    if (dst_chw) dst_chw[(long)c * dh * dw + idx] = (float)u;
+  }
+}
+
+// uint8 HWC (3 channels) -> fp32 CHW: the layout change + cast of SamPredictor.set_image (predictor.py:52-56) in one pass
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* __restrict__ src, long n,
+                                                              float* __restrict__ dst) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[c * n + idx] = (float)src[idx * 3 + c];
+}
+
 }  // namespace
 
 extern "C" int csam_preprocess_pad(void* stream, const float* img_chw, int h, int w, const float* mean3,
@@ -199,6 +250,27 @@ extern "C" int csam_preprocess_pad(void* stream, const float* img_chw, int h, in
   hipLaunchKernelGGL(preprocess_pad_kernel, dim3(3 * 1024 * 1024 / 256), dim3(256), 0, (hipStream_t)stream, img_chw,
                      h, w, m, sd, out);
   CSAM_LAUNCH_CHECK("csam_preprocess_pad");
+  return CSAM_OK;
+}
+
+extern "C" int csam_resize_linear_u8(void* stream, const uint8_t* src_hwc, int sh, int sw, const int* xofs,
+                                     const short* xcoef, const int* yofs, const short* ycoef, int dh, int dw,
+                                     int area2x, uint8_t* dst_hwc, float* dst_chw_f32) {
+  CSAM_REQUIRE(src_hwc && (dst_hwc || dst_chw_f32) && sh > 0 && sw > 0 && dh > 0 && dw > 0,
+               "csam_resize_linear_u8: bad args");
+  CSAM_REQUIRE(area2x ? (sh == 2 * dh && sw == 2 * dw) : (xofs && xcoef && yofs && ycoef),
+               "csam_resize_linear_u8: tables missing / area2x on a non-2x shape");
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(csam_cdiv((long)dh * dw, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src_hwc, sh, sw, xofs, xcoef, yofs, ycoef, dh, dw, area2x, dst_hwc, dst_chw_f32);
+  CSAM_LAUNCH_CHECK("csam_resize_linear_u8");
+  return CSAM_OK;
+}
+
+extern "C" int csam_u8hwc_to_f32chw(void* stream, const uint8_t* src_hwc, int h, int w, float* dst_chw) {
+  CSAM_REQUIRE(src_hwc && dst_chw && h > 0 && w > 0, "csam_u8hwc_to_f32chw: bad args");
+  hipLaunchKernelGGL(u8hwc_to_f32chw_kernel, dim3(csam_cdiv((long)h * w, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src_hwc, (long)h * w, dst_chw);
+  CSAM_LAUNCH_CHECK("csam_u8hwc_to_f32chw");
   return CSAM_OK;
 }
 

@@ -362,13 +362,20 @@ __global__ __launch_bounds__(256) void post_finalize_kernel(const float* __restr
 // every surviving prompt a slot in the IMAGE-level result store (base = running device counter), scatters
 // its small fields there and bumps the counter.  No host round trip, no gather copies afterwards: the second
 // mask pass writes the bytes straight to store[slot].  One workgroup (B <= 4096).
+// utils.is_box_near_crop_edge (crowdsam/utils.py:213-223): un-crop the box (box / downscale + crop offset, fp32 as torch
+// computes it), drop it when a side lies within atol of the crop box but not of the image box
+struct EdgeFilter {
+  float crop[4], orig[4], downscale, atol;
+  int enabled;
+};
+
 __global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
     const float* __restrict__ score, const int* __restrict__ inter, const int* __restrict__ uni,
     const int* __restrict__ box, const int* __restrict__ category, const int* __restrict__ points,
     float pred_iou_thresh, float stab_thresh, float filter_thresh, uint8_t* __restrict__ keep,
     uint8_t* __restrict__ occ, int* __restrict__ slot, int* __restrict__ counter, float* __restrict__ o_score,
     float* __restrict__ o_stab, int* __restrict__ o_box, int* __restrict__ o_cat, int* __restrict__ o_pts, int B,
-    int cap) {
+    int cap, EdgeFilter edge) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,6 +394,15 @@ __global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) bx[e] = box[b * 4 + e];
       if (bx[2] < bx[0] || bx[3] < bx[1]) bx[0] = bx[1] = bx[2] = bx[3] = 0;
+      if (edge.enabled) {   // the reference applies it inside _process_batch, BEFORE the occupancy mask is built (:386-389)
+        bool near = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (float)bx[e] / edge.downscale + edge.crop[e & 1];
+          near = near || (fabsf(v - edge.crop[e]) <= edge.atol && !(fabsf(v - edge.orig[e]) <= edge.atol));
+        }
+        k = k && !near;
+      }
       keep[b] = k;
       occ[b] = k && (score[b] > filter_thresh);
     }
@@ -577,14 +593,21 @@ extern "C" int csam_post_finalize_compact(void* stream, const float* score, cons
                                           float pred_iou_thresh, float stability_thresh, float filter_thresh,
                                           void* keep_u8, void* occ_u8, int* slot, int* counter, float* out_score,
                                           float* out_stability, int* out_box, int* out_category, int* out_points,
-                                          int B, int capacity) {
+                                          int B, int capacity, const float* edge10_host) {
   CSAM_REQUIRE(score && inter && uni && box && category && points_xy && keep_u8 && occ_u8 && slot && counter &&
                    out_score && out_stability && out_box && out_category && out_points && B > 0 && capacity > 0,
                "csam_post_finalize_compact: bad args");
+  EdgeFilter edge = {};
+  if (edge10_host) {
+    for (int e = 0; e < 4; ++e) edge.crop[e] = edge10_host[e], edge.orig[e] = edge10_host[4 + e];
+    edge.downscale = edge10_host[8];
+    edge.atol = edge10_host[9];
+    edge.enabled = 1;
+  }
   hipLaunchKernelGGL(post_finalize_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, inter, uni, box,
                      category, points_xy, pred_iou_thresh, stability_thresh, filter_thresh, (uint8_t*)keep_u8,
                      (uint8_t*)occ_u8, slot, counter, out_score, out_stability, out_box, out_category, out_points, B,
-                     capacity);
+                     capacity, edge);
   CSAM_LAUNCH_CHECK("csam_post_finalize_compact");
   return CSAM_OK;
 }

@@ -50,7 +50,7 @@ SIGNATURES = {
     "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
     "csam_mask_write": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
-    "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -75,6 +75,8 @@ SIGNATURES = {
     "csam_t2i_merge_launch": [_P, _P, _P, _I, _I],
     "csam_preprocess_pad": [_P, _P, _I, _I, _P, _P, _P],
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
+    "csam_resize_linear_u8": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "csam_u8hwc_to_f32chw": [_P, _P, _I, _I, _P],
 }
 LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
@@ -450,12 +452,17 @@ def occupancy_lookup(points, masks, occ, B, H, W, out, slot=None):
 
 
 def post_finalize_compact(score, inter, uni, box, category, points, pred_iou_thresh, stab_thresh, filter_thresh, keep, occ,
-                          slot, counter, store, B):
-    """Filters + in-kernel compaction of the survivors into ``store`` (dict of image-level device arrays)."""
+                          slot, counter, store, B, edge=None):
+    """Filters + in-kernel compaction of the survivors into ``store`` (dict of image-level device arrays).
+    ``edge`` = (crop_box, orig_box, downscale, atol) enables the crop-edge filter of crowdsam/utils.py:213-223."""
+    e10 = None
+    if edge is not None:
+        e10 = (_F * 10)(*[float(v) for v in edge[0]], *[float(v) for v in edge[1]], float(edge[2]), float(edge[3]))
     call("csam_post_finalize_compact", _stream(), _ptr(score), _ptr(inter), _ptr(uni), _ptr(box), _ptr(category),
          _ptr(points), float(pred_iou_thresh), float(stab_thresh), float(filter_thresh), _ptr(keep), _ptr(occ),
          _ptr(slot), _ptr(counter), _ptr(store["score"]), _ptr(store["stability"]), _ptr(store["boxes"]),
-         _ptr(store["category"]), _ptr(store["points"]), B, store["score"].shape[0])
+         _ptr(store["category"]), _ptr(store["points"]), B, store["score"].shape[0],
+         None if e10 is None else _c.cast(e10, _P))
 
 
 def box_nms(boxes, scores, thr):
@@ -562,6 +569,33 @@ def preprocess_pad(img_chw):
     """Sam.preprocess: raw f32 [3,h,w] -> normalised, zero-padded f32 [3,1024,1024]."""
     out = torch.empty((3, 1024, 1024), dtype=torch.float32, device=img_chw.device)
     call("csam_preprocess_pad", _stream(), _ptr(img_chw), img_chw.shape[1], img_chw.shape[2], _MEAN, _STD, _ptr(out))
+    return out
+
+
+def resize_linear_u8(src_hwc, tables, out_hw, want_u8=True, want_f32chw=True):
+    """cv2.resize INTER_LINEAR of a uint8 [h,w,3] device frame (crowdsam/utils.py:149).  ``tables`` from
+    crowdsam_amd.resize.cv2_linear_tables_device; returns (uint8 [dh,dw,3] | None, fp32 [3,dh,dw] | None)."""
+    sh, sw, c = src_hwc.shape
+    assert c == 3 and src_hwc.dtype == torch.uint8 and src_hwc.is_contiguous()
+    dh, dw = out_hw
+    u8 = torch.empty((dh, dw, 3), dtype=torch.uint8, device=src_hwc.device) if want_u8 else None
+    f32 = torch.empty((3, dh, dw), dtype=torch.float32, device=src_hwc.device) if want_f32chw else None
+    if tables is None:      # exact 2x decimation
+        call("csam_resize_linear_u8", _stream(), _ptr(src_hwc), sh, sw, None, None, None, None, dh, dw, 1, _ptr(u8),
+             _ptr(f32))
+    else:
+        xofs, xcoef, yofs, ycoef = tables
+        call("csam_resize_linear_u8", _stream(), _ptr(src_hwc), sh, sw, _ptr(xofs), _ptr(xcoef), _ptr(yofs),
+             _ptr(ycoef), dh, dw, 0, _ptr(u8), _ptr(f32))
+    return u8, f32
+
+
+def u8hwc_to_f32chw(src_hwc):
+    """uint8 [h,w,3] -> fp32 [3,h,w] (values 0..255)."""
+    h, w, c = src_hwc.shape
+    assert c == 3 and src_hwc.dtype == torch.uint8 and src_hwc.is_contiguous()
+    out = torch.empty((3, h, w), dtype=torch.float32, device=src_hwc.device)
+    call("csam_u8hwc_to_f32chw", _stream(), _ptr(src_hwc), h, w, _ptr(out))
     return out
 
 

@@ -83,6 +83,16 @@ int csam_add_cast(void* stream, const float* a, const float* b, long b_row_strid
 int csam_preprocess_pad(void* stream, const float* img_chw, int h, int w, const float* mean3, const float* std3,
                         float* out_3x1024x1024); /* Sam.preprocess materialised (API path) */
 int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out); /* crowdsam/model.py:203 */
+/* utils.resize_image -> cv2.resize(image, (w, h)) (crowdsam/utils.py:141-149; INTER_LINEAR, uint8 HWC, 3 channels) on
+ * the uploaded frame.  OpenCV's generic fixed-point algorithm restated (third-party, unpinned): xofs int32 [dw],
+ * xcoef int16 [dw][2], yofs int32 [dh][2] (both source rows, clamped), ycoef int16 [dh][2] are the 11-bit tables
+ * cv::resize builds (crowdsam_amd/resize.py); area2x != 0 selects the exact-2x INTER_AREA route (tables unused).
+ * Writes the uint8 HWC frame and / or the fp32 CHW tensor (0..255) the encoder kernels read; either may be NULL. */
+int csam_resize_linear_u8(void* stream, const uint8_t* src_hwc, int sh, int sw, const int* xofs, const short* xcoef,
+                          const int* yofs, const short* ycoef, int dh, int dw, int area2x, uint8_t* dst_hwc,
+                          float* dst_chw_f32);
+/* SamPredictor.set_image's HWC uint8 -> 1x3xHxW layout change + cast (predictor.py:52-56) */
+int csam_u8hwc_to_f32chw(void* stream, const uint8_t* src_hwc, int h, int w, float* dst_chw);
 
 /* ---- attention */
 /* 14x14 windowed attention + decomposed rel-pos; window partition/unpartition folded into the
@@ -209,12 +219,14 @@ int csam_mask_post_scored(void* stream, const float* lowres, const int* sel, con
 int csam_mask_write(void* stream, const float* lowres, const int* sel, const void* keep_u8, const int* slot_or_null,
                     int B, int in_h, int in_w, int out_h, int out_w, float thr, void* out_mask_u8, float* tmp_f32);
 /* finalize + in-kernel compaction of the survivors into an image-level store (MaskData.cat of
- * crowdsam/model.py:247 without host sync or gather copies): slot[b] = store index or -1 */
+ * crowdsam/model.py:247 without host sync or gather copies): slot[b] = store index or -1.
+ * edge10_host (HOST pointer, NULL = off): {crop_box[4], orig_box[4], downscale, atol} of utils.is_box_near_crop_edge
+ * (crowdsam/utils.py:213-223), applied per batch BEFORE the occupancy flags as crowdsam/model.py:386-389 does. */
 int csam_post_finalize_compact(void* stream, const float* score, const int* inter, const int* uni, const int* box,
                                const int* category, const int* points_xy, float pred_iou_thresh,
                                float stability_thresh, float filter_thresh, void* keep_u8, void* occ_u8, int* slot,
                                int* counter, float* out_score, float* out_stability, int* out_box, int* out_category,
-                               int* out_points, int B, int capacity);
+                               int* out_points, int B, int capacity, const float* edge10_host);
 int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W);
 /* crowdsam/model.py:371-389,246: keep / occupancy flags, stability = inter/union, empty box -> 0 */
 int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,

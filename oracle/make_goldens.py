@@ -131,7 +131,16 @@ def _install_shims():
 
     tvb.batched_nms, tvb.box_area = batched_nms, box_area
     tvo.boxes = tvb
-    tvo.box_iou = lambda a, b: None
+    def box_iou(a, b):      # torchvision.ops.box_iou semantics (public): areas (x2-x1)(y2-y1), intersection clamped at 0
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[None, :, :2])
+        rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+    tvo.box_iou = box_iou
     tvo.batched_nms = batched_nms
     tvt.functional = tvf
     for n in ("Compose", "Resize", "ToTensor", "Normalize"):
@@ -144,8 +153,10 @@ def _install_shims():
     cv2 = types.ModuleType("cv2")
 
     def cv_resize(img, wh):
-        assert (img.shape[1], img.shape[0]) == tuple(wh), "goldens use pre-sized images"
-        return img.copy()
+        # same size: identity copy (cv2's behaviour); otherwise OUR restatement of cv2's INTER_LINEAR
+        # (oracle/resize_oracle.py) -- a stand-in, so fixtures pin the reference from the post-resize frame onward
+        from oracle import resize_oracle
+        return resize_oracle.cv2_resize_linear_u8(img, wh)
 
     def cc(working, conn):
         from scipy import ndimage
@@ -335,6 +346,63 @@ def golden_mask_nms():
     res["mask_iou"] = ru.mask_iou(a, b).numpy()
     np.savez_compressed(os.path.join(OUT, "mask_nms.npz"), **res)
     print("mask_nms", {k: (v.shape if hasattr(v, "shape") else v) for k, v in res.items() if k.startswith("keep")})
+
+
+def tools_inputs(seed=3):
+    """Detections / gt boxes for evaluate_boxes (duplicates, score ties, unmatched gt, crowd overlaps) and a per-image
+    result list + GT json for convert_to_coco."""
+    rs = np.random.RandomState(seed)
+    cases = []
+    for n_gt, n_pred in ((6, 9), (0, 4), (5, 0), (12, 30), (3, 3)):
+        gt = rs.uniform(0, 300, (n_gt, 2))
+        gt = np.concatenate([gt, gt + rs.uniform(20, 120, (n_gt, 2))], 1)
+        if n_gt and n_pred:
+            src = gt[rs.randint(0, n_gt, n_pred)] + rs.normal(0, 8, (n_pred, 4))
+            src[::4] = rs.uniform(0, 400, (len(src[::4]), 4))
+            src[::4, 2:] += src[::4, :2]
+        else:
+            src = rs.uniform(0, 300, (n_pred, 4))
+            src[:, 2:] += src[:, :2] + 10
+        scores = np.round(rs.rand(n_pred), 1)             # one decimal: exact ties
+        cases.append((src.astype(np.float32), scores.astype(np.float32), gt))
+    det = [{"image_id": "ignored", "boxes": [[1.5, 2.0, 11.5, 22.0], [5, 5, 6, 9]], "scores": [0.9, 0.25]},
+           {"image_id": "ignored", "boxes": [], "scores": []},
+           {"image_id": "ignored", "boxes": [[0, 0, 100.25, 50]], "scores": [0.5]}]
+    gt_js = {"images": [{"id": 7, "file_name": "273271,c9db000d5146c15.jpg"}, {"id": 8, "file_name": "b.jpg"},
+                        {"id": 9, "file_name": "dir_c.png"}], "categories": [{"id": 1, "name": "person"}],
+             "annotations": []}
+    return cases, det, gt_js
+
+
+def golden_tools():
+    """Tier O2: crowdsam/utils.py::evaluate_boxes (tools/test.py:80) with our box_iou stand-in, and
+    tools/batch_eval.py::convert_to_coco / merge-free parts (pure python).  Fixture: tests/golden/tools.json."""
+    import copy
+    import importlib
+    import json
+    _install_shims()
+    sys.path.insert(0, "/root/reference")
+    ru = importlib.import_module("crowdsam.utils")
+    assert ru.__file__.startswith("/root/reference")
+    spec = importlib.util.spec_from_file_location("ref_batch_eval", "/root/reference/tools/batch_eval.py")
+    be = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(be)
+    sys.path.remove("/root/reference")
+    cases, det, gt_js = tools_inputs()
+    ev = []
+    for pb, ps, gt in cases:
+        for thr in (0.5, 0.3):
+            p, r, fp, fn = ru.evaluate_boxes(pb, ps, gt, thr)
+            ev.append({"precision": float(p), "recall": float(r), "FP": [int(v) for v in fp], "FN": [int(v) for v in fn]})
+    coco = be.convert_to_coco(copy.deepcopy(det), copy.deepcopy(gt_js))
+    cfg = ru.modify_config({"test": {"grid_size": 192}}, ["test.grid_size", "64", "new.section.flag", "TRUE",
+                                                          "test.pos_sim_thresh", "-1.5", "model.sam_model", "vit_b"])
+    conv = [ru.convert_value(v) for v in ("True", "false", "12", "-3.5", "1e-3", "vit_l", "FALSE")]
+    meta = {k: [v[0], v[1], len(v[2])] for k, v in ru.data_meta.items()}
+    with open(os.path.join(OUT, "tools.json"), "w") as f:
+        json.dump({"evaluate_boxes": ev, "convert_to_coco": coco, "modify_config": cfg, "convert_value": conv,
+                   "data_meta": meta}, f)
+    print("tools", ev[:2], len(coco["annotations"]), cfg, conv)
 
 
 def golden_evaluator():

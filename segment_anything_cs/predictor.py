@@ -33,7 +33,22 @@ class SamPredictor:
     # ------------------------------------------------------------------------------------------
     def set_image(self, image, mask=None, image_format="RGB", cal_image=True):
         assert image_format in ["RGB", "BGR"], f"image_format must be in ['RGB', 'BGR'], is {image_format}."
-        if image_format != self.model.image_format:
+        # build extension (the reference takes ndarrays only): a frame that is already resident on the GPU --
+        # uint8 HWC tensor, optionally with its fp32 CHW form from the device resize (crowdsam/utils.py
+        # resize_frame_device) -- skips the host round trip when it needs no further resize
+        f32 = None
+        if isinstance(image, tuple):
+            image, f32 = image
+        if torch.is_tensor(image):
+            if image_format != self.model.image_format:
+                image, f32 = image.flip(-1).contiguous(), None
+            h, w = image.shape[:2]
+            if mask is None and cal_image and max(h, w) == self.model.image_encoder.img_size:
+                if f32 is None:
+                    f32 = hip.u8hwc_to_f32chw(image)
+                return self.set_torch_image(f32[None], (h, w))
+            image = image.cpu().numpy()          # e.g. a 1023-pixel long side (SURVEY.md trap 9): PIL resize on the host
+        elif image_format != self.model.image_format:
             image = image[..., ::-1]
         input_image = self.transform.apply_image(image)
         t = torch.as_tensor(np.ascontiguousarray(input_image)).to(self.device, non_blocking=True)

@@ -1,11 +1,15 @@
 #!/usr/bin/env python
-"""Single-GPU evaluation harness with the reference's argv and result JSON (reference: tools/test.py:13-89).
+"""Single-GPU evaluation harness: the reference's argv, call sequence and result JSON (reference: tools/test.py:13-89).
 
     python tools/test.py -c configs/crowdhuman.yaml [--start_idx A --end_idx B] [-r LOCAL_RANK]
-                         [-s SAVE_PATH] [-v] [key.sub value ...]
+                         [-s SAVE_PATH] [-v] [--mode seg|bbox] [key.sub value ...]
 
-Writes ``[{image_id, num_gt, boxes, scores, categories, rles}, ...]`` to SAVE_PATH.  ``--synthetic N``
-(build extension) runs N synthetic crowd frames with seeded weights when no dataset / checkpoints exist.
+Writes ``[{image_id, num_gt, boxes, scores, categories, rles}, ...]`` to SAVE_PATH (default
+``<environ.output_dir>/result.json``).  It uses only the surface the reference's own script imports
+(``crowdsam.model.CrowdSAM``; ``crowdsam.utils.{load_img_and_annotation, setup_logger, data_meta, load_config,
+modify_config, visualize_result, evaluate_boxes}``), so the reference's unmodified tools/test.py runs against this
+package as well (tests/test_tools_dropin_*.py replay its statements).  ``--synthetic N`` (build extension) runs N
+synthetic crowd frames with seeded weights when no dataset / checkpoints exist.
 """
 import argparse
 import json
@@ -17,60 +21,89 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crowdsam.model import CrowdSAM  # noqa: E402
-from crowdsam.utils import (data_meta, load_config, load_coco_index, load_img_and_annotation, modify_config,  # noqa: E402
-                            setup_logger)
+from crowdsam.utils import (data_meta, evaluate_boxes, load_config, load_img_and_annotation, modify_config,  # noqa: E402
+                            setup_logger, visualize_result)
 
 
-def environ_init(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-c", "--config_file", default="./configs/crowdhuman_mi355x.yaml")
-    ap.add_argument("--start_idx", type=int, default=0)
-    ap.add_argument("--end_idx", type=int, default=-1)
-    ap.add_argument("-r", "--local_rank", type=int, default=0)
-    ap.add_argument("-s", "--save_path", default="result.json")
-    ap.add_argument("-v", "--visualize", action="store_true")
-    ap.add_argument("--synthetic", type=int, default=0, help="run N synthetic frames with seeded weights")
-    ap.add_argument("options", nargs=argparse.REMAINDER)
-    args = ap.parse_args(argv)
-    config = modify_config(load_config(args.config_file), args.options)
-    seed = config["environ"]["seed"]
-    np.random.seed(seed)              # the EPS shuffle draws from the global NumPy RNG (trap 7)
-    torch.manual_seed(seed)
-    logger = setup_logger(config["environ"]["output_dir"])
-    return args, config, logger
+def envrion_init(argv=None):
+    """argparse + YAML + seeds + logger (tools/test.py:13-35; the function name is the reference's spelling)."""
+    parser = argparse.ArgumentParser(description="CrowdSAM argparser")
+    parser.add_argument("--mode", type=str, choices=["seg", "bbox"], default="seg")
+    parser.add_argument("--start_idx", type=int, default=0)
+    parser.add_argument("--end_idx", type=int, default=-1)          # -1: all images
+    parser.add_argument("-c", "--config_file", type=str, default="./configs/crowdhuman.yaml")
+    parser.add_argument("-v", "--visualize", help="visualize the outputs", action="store_true")
+    parser.add_argument("-s", "--save_path", help="the path to dump json result", type=str, default="")
+    parser.add_argument("-r", "--local_rank", type=int, default=0)
+    parser.add_argument("--synthetic", type=int, default=0, help="(build extension) N synthetic frames, seeded weights")
+    parser.add_argument("options", nargs=argparse.REMAINDER)
+    args = parser.parse_args(argv)
+    configs = modify_config(load_config(args.config_file), args.options)
+    np.random.seed(configs["environ"]["seed"])          # the EPS shuffle draws from the global NumPy RNG (trap 7)
+    torch.random.manual_seed(configs["environ"]["seed"])
+    os.makedirs(configs["environ"]["output_dir"], exist_ok=True)
+    os.makedirs(configs["environ"]["output_dir"] + "/log", exist_ok=True)
+    logger = setup_logger(configs["environ"]["output_dir"] + "/log")
+    logger.info(args)
+    return args, configs, logger
+
+
+environ_init = envrion_init
+
+
+def instance_record(image_id, num_gt, result):
+    """One entry of the result JSON (tools/test.py:69-72): only the fields present are copied, so an image without
+    detections (no 'categories' in the reference's MaskData) does not abort the run."""
+    d = {"image_id": image_id, "num_gt": num_gt}
+    d.update({k: v.tolist() for k, v in result.items() if k in ["boxes", "scores", "categories"]})
+    d.update({k: v for k, v in result.items() if k in ["rles"]})
+    return d
 
 
 def run(args, config, logger):
-    torch.cuda.set_device(args.local_rank)
-    config["environ"]["device"] = f"cuda:{args.local_rank}"
-    results = []
+    dataset_path = config["data"]["dataset_root"]
+    n_class, class_names = data_meta[config["data"]["dataset"]][1:]
+    if "cuda" in config["environ"]["device"]:
+        torch.cuda.set_device(args.local_rank)
+        print(f"set device cuda:{args.local_rank}")
+        config["environ"]["device"] = f"cuda:{args.local_rank}"
+    output_content = []
     if args.synthetic:
         from crowdsam_amd import synth
         model = CrowdSAM(config, logger, sam_state_dict=synth.make_sam_state_dict(config["model"]["sam_model"]),
                          dino_state_dict=synth.make_dino_state_dict())
-        ids = list(range(args.synthetic))
-        end = len(ids) if args.end_idx < 0 else args.end_idx
-        for i in ids[args.start_idx:end]:
-            out = model.generate(synth.synthetic_crowd_frame(i))
-            results.append({"image_id": f"synthetic_{i}.jpg", "num_gt": 0, "boxes": out["boxes"].tolist(),
-                            "scores": out["scores"].tolist(), "categories": out["categories"].tolist(),
-                            "rles": out["rles"]})
+        end_idx = args.synthetic if args.end_idx == -1 else min(args.end_idx, args.synthetic)
+        for id_ in range(args.start_idx, end_idx):
+            result = model.generate(synth.synthetic_crowd_frame(id_))
+            output_content.append(instance_record(f"synthetic_{id_}.jpg", 0, result))
     else:
         model = CrowdSAM(config, logger)
-        d = config["data"]
-        coco = load_coco_index(d["json_file"])
-        ids = coco.getImgIds()
-        end = len(ids) if args.end_idx < 0 else args.end_idx
-        for id_ in ids[args.start_idx:end]:
-            image, file_name, gt = load_img_and_annotation(d["dataset_root"], d["dataset"], id_, coco)
-            out = model.generate(image)
-            results.append({"image_id": file_name, "num_gt": int(len(gt)), "boxes": out["boxes"].tolist(),
-                            "scores": out["scores"].tolist(), "categories": out["categories"].tolist(),
-                            "rles": out["rles"]})
-    with open(args.save_path, "w") as f:
-        json.dump(results, f)
-    return results
+        logger.info("load images and annotations from crowdhuman dataset..")
+        annots = json.load(open(config["data"]["json_file"]))
+        end_idx = len(annots["images"]) if args.end_idx == -1 else min(args.end_idx, len(annots["images"]))
+        image_ids = [i for i in range(args.start_idx, end_idx)]
+        logger.info(f"total images  to process { len(image_ids)}")
+        for id_ in image_ids:
+            logger.debug(f"start processing {id_}")
+            image, gt_boxes, image_id = load_img_and_annotation(dataset_path, annots, config["data"]["dataset"], id_)
+            result = model.generate(image)
+            output_content.append(instance_record(image_id, len(gt_boxes) - 1, result))     # "- 1" as tools/test.py:69
+            logger.debug(f"process for image:{id_} is done")
+            if args.visualize:
+                save_path = os.path.join(config["environ"]["output_dir"], f"{id_}.jpg")
+                result["gt_boxes"] = gt_boxes
+                FP_list, FN_list = evaluate_boxes(result["boxes"], result["scores"], gt_boxes, 0.5)[2:]
+                visualize_result(image, result, class_names, save_path, conf_thresh=config["vis"]["vis_thresh"],
+                                 FP_ind=FP_list, FN_ind=FN_list, vis_masks=args.mode == "seg")
+            del result
+    if args.save_path == "":
+        file_path = os.path.join(config["environ"]["output_dir"], "result.json")
+        print(f"dump json file to {file_path}")
+        json.dump(output_content, open(file_path, "w"), ensure_ascii=True)
+    else:
+        json.dump(output_content, open(args.save_path, "w"), ensure_ascii=True)
+    return output_content
 
 
 if __name__ == "__main__":
-    run(*environ_init())
+    run(*envrion_init())
