@@ -47,6 +47,73 @@ def pmc_traffic(kernel_prefix):
         return None, "profiles/r01_pmc_traffic.json not found"
 
 
+def encoder_only(args, rank, world, dev, sam_sd):
+    """BASELINE configs[1]: SAM image-encoder forward only (patch embed + all blocks + neck) on
+    RandomState(0).standard_normal((1,3,1024,1024)) with seeded weights; hipGraph replay, inputs resident in HBM.
+    roofline = the encoder's algorithmic FLOPs (2*M*N*K of every matmul the reference module performs, SURVEY.md 8d:
+    972.1 / 2985.7 / 5961.1 GFLOP for ViT-B / L / H) / measured time vs the dense fp16 MFMA peak."""
+    from crowdsam_amd import hip, synth
+    from segment_anything_cs import sam_model_registry
+    REF_GFLOP = {"vit_b": 972.1, "vit_l": 2985.7, "vit_h": 5961.1}
+    sam = sam_model_registry[args.arch](n_class=1)
+    sam.load_state_dict(sam_sd, strict=False)
+    sam = sam.to(dev)
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+    raw = (x[0] * sam.pixel_std.cpu() + sam.pixel_mean.cpu()).to(dev).contiguous()      # forward_tokens re-normalises
+    enc = sam.image_encoder
+    for _ in range(max(args.warmup, 1)):
+        enc.forward_tokens(raw)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        enc.forward_tokens(raw)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # per-kernel-family split on an instrumented (eager, event-bracketed) repeat
+    names = ["csam_gemm_f16", "csam_win_attn", "csam_flash_attn", "csam_layernorm", "csam_sam_im2col", "csam_im2col3x3",
+             "csam_add_cast", "csam_gemm_f16_batched", "csam_head_gather", "csam_softmax_relpos", "csam_head_scatter",
+             "csam_ln_gemm_f16"]
+    timer = hip.KernelTimer(names)
+    hip.set_timer(timer)
+    for _ in range(min(args.steps, 5)):
+        enc.plan().forward(raw)
+    torch.cuda.synchronize()
+    hip.set_timer(None)
+    n_rep = min(args.steps, 5)
+    fam = {k: {"us_per_image": 1e3 * v["ms"] / n_rep, "launches_per_image": v["calls"] // n_rep,
+               **({"tflops": v["work"] / (v["ms"] * 1e-3) / 1e12} if v["work"] > 0 else {})}
+           for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0:
+        value = args.steps * world / elapsed
+        gf = REF_GFLOP.get(args.arch, enc.plan().flops() / 1e9)
+        ach = gf * 1e9 / (dev_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "images/sec (SAM %s image encoder only, 1024^2 input)" % args.arch, "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SAM %s encoder-only forward (patch embed, %d blocks, neck) on a random "
+                                   "normalised 1024x1024 tensor, seeded weights, hipGraph replay" % (args.arch, enc.depth),
+                       "device_ms_per_image": dev_ms, "kernel_families": fam},
+            "roofline": {"bound": "mfma", "kernel": "whole encoder (GEMMs + windowed / global attention)", "achieved": ach,
+                         "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
+                         "note": "%.1f GFLOP per image (FlopCounter on the reference module: every matmul incl. pad tokens; the "
+                                 "kernels skip the pad-token rows of the windowed QKV / proj GEMMs, required FLOPs %.1f G) / "
+                                 "HIP-event time per image" % (gf, enc.plan().flops() / 1e9)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +130,11 @@ def main():
                     help="stability_score_thresh of the run.  The shipped 0.8 keeps NO mask with random weights "
                          "(median stability 0.25), which would skip mask materialisation, NMS and RLE; 0.25 keeps "
                          "about half of the 4096 prompts, a crowded-scene-like survivor share.")
+    ap.add_argument("--encoder-only", action="store_true",
+                    help="BASELINE configs[1]: SAM image-encoder forward only on a random normalised 1024^2 tensor")
+    ap.add_argument("--crowd-keep", type=int, default=300,
+                    help="second measured leg (dense mode): ~this many masks per image survive NMS into the small-region "
+                         "clean-up + RLE (box NMS off, score cut calibrated on the warm-up frames); 0 disables the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -83,6 +155,8 @@ def main():
 
     D, depth, heads, gidx = synth.SAM_CONFIGS[args.arch]
     sam_sd = synth.make_sam_state_dict(args.arch, seed=0)
+    if args.encoder_only:
+        return encoder_only(args, rank, world, dev, sam_sd)
     dino_sd = synth.make_dino_state_dict(seed=1)
     tcfg = dict(DEFAULT_TEST_CFG)
     n_prompts = args.grid * args.grid
@@ -106,8 +180,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from crowdsam_amd.distributed import detections_to_rows, gather_rows
     n_kept = 0
     n_pre_nms = 0
+    rows = [np.zeros((0, 6), np.float32)]
     for i in range(args.warmup):
         model.generate(frames[i])
     barrier()
@@ -116,8 +192,48 @@ def main():
         out = model.generate(frames[i])
         n_kept += len(out["boxes"])
         n_pre_nms += model.last_candidates
+        rows.append(detections_to_rows(rank * args.steps + i - args.warmup, out["boxes"], out["scores"]))
+    torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_rates = [args.steps / my_elapsed]
+    if world > 1:
+        # the one collective of the design: the variable-length detection gather over RCCL, after
+        # the timed region (it is once per RUN, not per image); rank 0 checks that every rank's rows arrived
+        rows_np = np.concatenate(rows)
+        allrows = gather_rows(rows_np)
+        cnt = torch.tensor([float(len(rows_np)), args.steps / my_elapsed], device=dev, dtype=torch.float64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        assert len(allrows) == int(sum(c[0].item() for c in cnts)), "detection gather lost rows"
+        assert bool(np.all(np.diff(allrows[:, 0]) >= 0)), "gathered rows are not in rank (== image) order"
+        rank_rates = [float(c[1].item()) for c in cnts]
+    # second measured leg: the tail of the path under load.  With random weights the candidate masks are near-identical
+    # blobs and box NMS keeps ~1 per image, so connected components + RLE run on one mask in the headline number; here
+    # box NMS is off and a score cut calibrated on a warm-up frame lets ~crowd_keep candidates through, so
+    # csam_small_regions / csam_rle_* / the COCO string packer are timed on a crowded-frame-sized survivor set.
+    crowd = None
+    if args.crowd_keep > 0 and args.mode == "dense" and rank == 0:
+        saved = (model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh)
+        model.box_nms_thresh = model.crop_nms_thresh = 1.0
+        model.generate(frames[0])
+        sc = np.sort(model._store["score"][:model.last_candidates].float().cpu().numpy())[::-1]
+        model.pred_iou_thresh = float(sc[min(args.crowd_keep, len(sc) - 1)]) if len(sc) else saved[2]
+        model.generate(frames[0])
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        kept_c = 0
+        for i in range(args.warmup, args.warmup + args.steps):
+            kept_c += len(model.generate(frames[i])["boxes"])
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - tc
+        crowd = {"what": "same frames, box NMS off, predicted-IoU cut %.4f (keeps ~%d candidates): every survivor goes "
+                         "through small-region clean-up (device connected components), RLE and COCO string packing"
+                         % (model.pred_iou_thresh, args.crowd_keep),
+                 "ms_per_step": 1e3 * tc / args.steps, "images_per_sec": args.steps / tc,
+                 "kept_masks_per_image": kept_c / args.steps}
+        model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = saved
     # roofline leg: the same K steps once more with HIP events around every launch of the dominant kernel
     # (the timed region above replays hipGraphs, inside which per-launch events cannot be recorded).
     timer = None
@@ -162,8 +278,11 @@ def main():
                                        args.frame, args.frame, args.stability_thresh)),
                        "masks_per_sec": value * n_prompts if args.mode == "dense" else None,
                        "kept_masks_per_image": n_kept / args.steps,
-                       "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}"},
+                       "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}",
+                       "per_rank_images_per_sec": rank_rates},
         }
+        if crowd is not None:
+            res["config"]["crowd_leg"] = crowd
         if timer is not None:
             full = timer.summary()
             summ = {k: v for k, v in full.items() if k in GEMM_NAMES}
@@ -197,7 +316,7 @@ def main():
                 cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), args.arch,
                                      str(n_prompts)], capture_output=True, text=True, timeout=240)
                 cb = json.loads(cp.stdout.strip().splitlines()[-1])
-                res["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+                res["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "stages_s")}
                 res["config"]["speedup_vs_cpu_port"] = value / cb["value"]
             except Exception as exc:   # noqa: BLE001  (never let the baseline leg break the bench line)
                 res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",

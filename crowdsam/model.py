@@ -63,7 +63,8 @@ class CrowdSAM:
             raise NotImplementedError("train-free branch is out of scope (SURVEY.md §2 #11)")
         m = config["model"]
         if dino_model is None:
-            dino_model = DinoV2(depth=dino_depth)
+            # model.dino_depth: build extension for reduced-depth test checkpoints (DINOv2 ViT-L/14 has 24 blocks)
+            dino_model = DinoV2(depth=int(m.get("dino_depth", dino_depth)))
             if dino_state_dict is None:
                 dino_state_dict = torch.load(m["dino_checkpoint"], map_location="cpu")
             dino_model.load_state_dict(dino_state_dict)
@@ -277,7 +278,10 @@ class CrowdSAM:
         del data["masks"]
         data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, self.downscale)
         data["points"] = utils.uncrop_points(data["points"], crop_box, self.downscale)
-        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["boxes"]))])
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["boxes"]))]).reshape(-1, 4)
+        # build extension: the crop box of every mask survives the cross-crop NMS (the reference keeps only the
+        # 2-entries-per-crop ``rles_info`` list, which cannot tell which crop frame an RLE lives in)
+        data["rles_crop"] = data["crop_boxes"].clone()
         data["fboxes"] = data["boxes"]
         return data
 

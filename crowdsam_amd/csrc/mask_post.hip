@@ -284,8 +284,46 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
       }
     }
   };
-  if (a.W == 1024 && a.H == 1024 && i > 0 && i < 63) rows(std::true_type{});
-  else if (x4 < a.W) rows(std::false_type{});
+  if (a.W == 1024 && a.H == 1024 && i > 0 && i < 63) {
+    // Value-uniform strips.  Every output pixel of this thread is a convex combination (two nested fp32 lerps with
+    // weights k/8) of its 18 source logits, so it lies in [min v, max v] up to 2 roundings (< 3e-7 relative): when a
+    // whole wave's strip (16 rows x 256 px) clears both stability thresholds by 1e-6 relative -- the background and
+    // the interior of a mask, i.e. almost all of the frame -- the per-pixel interpolation + compares are skipped and
+    // the outcome they would have produced is written directly.  Decisions are identical to the evaluated path.
+    float vmin = v[0][0], vmax = v[0][0];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vmin = fminf(vmin, v[k][c]);
+        vmax = fmaxf(vmax, v[k][c]);
+      }
+    const bool all_lo = vmax + fabsf(vmax) * 1e-6f < lo_t && a.off >= 0.f;
+    const bool all_hi = vmin - fabsf(vmin) * 1e-6f > hi_t && a.off >= 0.f;
+    if (__all(all_lo)) {
+      if (PASS == 1) {
+        const long o = ((long)(a.slot ? a.slot[b] : b) * 1024 + i * 16) * 1024 + x4;
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) *(uint32_t*)(a.out_mask + o + yy * 1024) = 0u;
+      }
+    } else if (__all(all_hi)) {
+      if (PASS == 0) {
+        cnt_i = 64;
+        cnt_u = 64;
+        colany[0] = colany[1] = colany[2] = colany[3] = 1u;
+        ymin = i * 16;
+        ymax = i * 16 + 15;
+      } else {
+        const long o = ((long)(a.slot ? a.slot[b] : b) * 1024 + i * 16) * 1024 + x4;
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) *(uint32_t*)(a.out_mask + o + yy * 1024) = 0x01010101u;
+      }
+    } else {
+      rows(std::true_type{});
+    }
+  } else if (x4 < a.W) {
+    rows(std::false_type{});
+  }
   if (PASS == 1) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e)

@@ -210,6 +210,7 @@ class DecoderPlan:
         self.taps = _adjoint_taps().to(device)
         self.adj_tables = _adjoint_mfma_tables().to(device)
         self.state = None
+        self._static_in = None
         self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
 
@@ -248,7 +249,7 @@ class DecoderPlan:
         self.state = dict(src16=e(T_IMG, 256), srcpe16=e(T_IMG, 256), src32=e(T_IMG, 256, dt=f), kv0=e(T_IMG, 256),
                           qi0=e(T_IMG, 128), k0=e(T_IMG, 128), v0t=e(128, T_IMG), k0h=e(8, 256, 16, 16), v0h=e(8, 256, 16, 16), G=e(N_DINO, 256, dt=f),
                           GT=e(256, N_DINO_PAD), g16=e(N_DINO, 256), fgh=e(N_DINO, 256, dt=f),
-                          fg=e(N_DINO, self.n_class, dt=f), feat=None, dtok=None)
+                          fg=e(N_DINO, self.n_class, dt=f), feat=e(T_IMG, 256, dt=f), dtok=e(N_DINO_PAD, 1024))
         self.state_graph = hip.GraphCache()
 
     def set_image(self, feat_tok, dino_tok16):
@@ -258,6 +259,17 @@ class DecoderPlan:
             self._alloc_state()
         st = self.state
         L0 = self.layers[0]
+        # the per-image graph reads STATIC operand buffers: inputs living elsewhere (API path: predictor.features
+        # assigned by the caller, a fresh allocation per image) are copied in, so ONE graph serves every image (a
+        # graph keyed by the callers' data_ptr()s would grow without bound and could replay a recycled address)
+        if self._static_in is None:
+            self._static_in = (feat_tok, dino_tok16)            # the encoders' own static outputs: no copy
+        if feat_tok.data_ptr() != self._static_in[0].data_ptr():
+            st["feat"].copy_(feat_tok)
+            feat_tok = st["feat"]
+        if dino_tok16.data_ptr() != self._static_in[1].data_ptr():
+            st["dtok"].copy_(dino_tok16)
+            dino_tok16 = st["dtok"]
 
         def launch():
             hip.add_cast(feat_tok, self.no_mask, 0, out16=st["src16"], out32=st["src32"])
@@ -282,7 +294,7 @@ class DecoderPlan:
             hip.linear_f32(st["fgh"], w2, b2, out=st["fg"])
             return st
 
-        return self.state_graph.run((feat_tok.data_ptr(), dino_tok16.data_ptr()), launch)
+        return self.state_graph.run("image", launch)
 
     def fg_logits(self):
         """[5329, n_class] fp32 FG-prior logits on the 73x73 grid (computed by set_image)."""

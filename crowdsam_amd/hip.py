@@ -173,7 +173,10 @@ GRAPHS_ENABLED = os.environ.get("CSAM_GRAPHS", "1") != "0"
 class GraphCache:
     """hipGraph capture/replay of a launch sequence that only touches static buffers.  The decoder batch is
     ~100 short kernels: replaying one graph removes the per-launch host cost (Python + ctypes + hipLaunch).
-    Disabled while a KernelTimer is active (events cannot be recorded inside a replayed graph)."""
+    Disabled while a KernelTimer is active (events cannot be recorded inside a replayed graph).
+    Invariant: the first call for a key runs ``fn`` eagerly, captures it and then REPLAYS it, i.e. the sequence
+    executes twice on the same buffers -- every captured kernel must therefore be idempotent on its static
+    operands (pure functions of their inputs; no accumulating atomics onto un-reinitialised memory)."""
 
     def __init__(self):
         self.graphs = {}

@@ -80,6 +80,48 @@ def golden_decoder():
     print("decoder", low.shape, iou.flatten()[:4], cls.flatten()[:4])
 
 
+def decoder_big_inputs(n=320):
+    """Production-batch decoder case: the embedding / DINO tokens of decoder_inputs() and n seeded prompts (>= 256 so the
+    persistent stream kernels -- t2i_stream / upscale_stream / i2t_rank -- are the ones that run on the GPU)."""
+    emb, dino, _ = decoder_inputs()
+    pts = np.random.RandomState(12).randint(0, 1024, size=(n, 1, 2)).astype(np.float64)
+    return emb, dino, pts
+
+
+def golden_decoder_big():
+    """>= 320 prompts through the REFERENCE prompt encoder + mask decoder (mask_decoder.py:138-199) in the reference's
+    own batches of 32 (prompts are independent in the decoder: batching only changes fp32 summation order)."""
+    sam, sd, _ = load_ref_sam(TEST_ARCH)
+    emb, dino, pts = decoder_big_inputs()
+    lows, ious, clss = [], [], []
+    with torch.no_grad():
+        pe = sam.prompt_encoder.get_dense_pe()
+        for i in range(0, len(pts), 32):
+            coords = torch.as_tensor(pts[i:i + 32])
+            labels = torch.ones(len(coords), 1, dtype=torch.int)
+            sparse, dense = sam.prompt_encoder(points=(coords, labels), boxes=None, masks=None)
+            low, iou, cls = sam.mask_decoder(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse,
+                                             dense_prompt_embeddings=dense, multimask_output=True, dino_feats=dino)
+            lows.append(low), ious.append(iou), clss.append(cls)
+    low, iou, cls = torch.cat(lows), torch.cat(ious), torch.cat(clss)
+    np.savez_compressed(os.path.join(OUT, "decoder_big_test128.npz"),
+                        low_sample=low[:, :, 5::32, 9::32].numpy(), low_sum=low.double().sum((2, 3)).numpy(),
+                        low_abs_sum=low.double().abs().sum((2, 3)).numpy(), low_max=low.amax((2, 3)).numpy(),
+                        iou=iou.numpy(), cls=cls.numpy())
+    print("decoder_big", low.shape, float(low.abs().mean()), iou[:2], cls[:2, :, 0])
+
+
+def golden_encoder_vitl():
+    """Full-depth (24 blocks) ViT-L reference encoder on the BASELINE configs[1] input."""
+    sam, sd, _ = load_ref_sam("vit_l")
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+    with torch.no_grad():
+        y = sam.image_encoder(x)
+    np.savez_compressed(os.path.join(OUT, "encoder_vit_l.npz"), sample=y[:, ::4, 1::4, 2::4].numpy(),
+                        sum=np.float64(y.double().sum()), abs_sum=np.float64(y.double().abs().sum()))
+    print("encoder_vitl", y.shape, float(y.abs().mean()), float(y.std()))
+
+
 def golden_amg():
     _, _, amg = ref_import.load_modeling()
     rs = np.random.RandomState(5)
@@ -251,6 +293,90 @@ def golden_pipeline(fuse=False):
     name = "pipeline_test128_fuse.npz" if fuse else "pipeline_test128.npz"
     np.savez_compressed(os.path.join(OUT, name), rle_counts=rle_counts, **res)
     print("pipeline", name, {k: v.shape for k, v in res.items()}, out["scores"][:5])
+
+
+VITB_CFG = dict(grid_size=8, pos_sim_thresh=-1.0, points_per_batch=32, max_prompts=500, pred_iou_thresh=-1e9,
+                stability_score_thresh=0.0, min_mask_region_area=0, box_nms_thresh=1.0, crop_nms_thresh=1.0)
+
+
+def vitb_image():
+    return np.random.RandomState(0).randint(0, 256, (512, 512, 3)).astype(np.uint8)
+
+
+def golden_pipeline_vitb():
+    """BASELINE configs[0]: ViT-B via _build_sam(768,12,12,1,[2,5,8,11]) + 8x8 grid on one 512x512 seeded image through
+    the reference's CrowdSAM.generate (tier O2).  The 512 -> 1024 up-scaling goes through OUR cv2 stand-in, so the
+    fixture pins the reference from the post-resize frame onward."""
+    import importlib
+    _install_shims()
+    ref_import.load_modeling()
+    predictor_mod = importlib.import_module("segment_anything_cs.predictor")
+    sys.path.insert(0, ref_import.REF)
+    model_mod = importlib.import_module("crowdsam.model")
+    sys.path.remove(ref_import.REF)
+    sam, sd, _ = load_ref_sam("vit_b")
+    predictor = predictor_mod.SamPredictor(sam, StandInDino())
+    cs = object.__new__(model_mod.CrowdSAM)
+    cfg = dict(po.DEFAULT_TEST_CFG)
+    cfg.update(VITB_CFG)
+    cs.device = torch.device("cpu")
+    cs.train_free = False
+    cs.predictor = predictor
+    for k, v in cfg.items():
+        setattr(cs, k, v)
+    np.random.seed(42)
+    with torch.no_grad():
+        out = cs.generate(vitb_image())
+    res = {k: out[k] for k in ("boxes", "scores", "categories", "points", "stability_score")}
+    # random-weight ViT-B masks are noise-like (1e4+ runs each): keep the run COUNT and the mask area per mask only
+    dec = [po.coco_rle_decode(r["counts"], *r["size"]) for r in out["rles"]]
+    res["mask_area"] = np.array([int(d.sum()) for d in dec], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "pipeline_vit_b_512.npz"), **res)
+    print("pipeline_vitb", {k: v.shape for k, v in res.items()}, out["scores"][:8], out["boxes"][:3])
+
+
+def golden_dino_hf():
+    """Second opinion for the DINOv2 restatement (the reference's dinov2/ submodule is empty and unpinned): the seeded
+    DINOv2 ViT-L/14 state dict mapped into transformers.models.dinov2 (v5.15, present in this image), full depth, on a
+    1022x1022 input.  Fixture = strided x_norm_patchtokens.  Still *unpinned* w.r.t. the un-vendored submodule, but
+    no longer self-referential: an independent implementation of the same published architecture."""
+    from transformers import Dinov2Config, Dinov2Model
+    from oracle import sam_oracle as so
+    depth = 24
+    sd = synth.make_dino_state_dict()
+    cfg = Dinov2Config(hidden_size=1024, num_hidden_layers=depth, num_attention_heads=16, mlp_ratio=4, patch_size=14,
+                       image_size=518, qkv_bias=True, use_swiglu_ffn=False, layer_norm_eps=1e-6, hidden_act="gelu")
+    m = Dinov2Model(cfg).eval()
+    hf = {"embeddings.cls_token": sd["cls_token"], "embeddings.mask_token": sd["mask_token"],
+          "embeddings.position_embeddings": sd["pos_embed"],
+          "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(depth):
+        a, b = f"blocks.{i}.", f"encoder.layer.{i}."
+        qw, kw, vw = sd[a + "attn.qkv.weight"].chunk(3, 0)
+        qb, kb, vb = sd[a + "attn.qkv.bias"].chunk(3, 0)
+        for n, w, bb in (("query", qw, qb), ("key", kw, kb), ("value", vw, vb)):
+            hf[b + f"attention.attention.{n}.weight"], hf[b + f"attention.attention.{n}.bias"] = w, bb
+        for src, dst in (("norm1", "norm1"), ("norm2", "norm2"), ("attn.proj", "attention.output.dense"),
+                         ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            hf[b + dst + ".weight"], hf[b + dst + ".bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+        hf[b + "layer_scale1.lambda1"], hf[b + "layer_scale2.lambda1"] = sd[a + "ls1.gamma"], sd[a + "ls2.gamma"]
+    missing, unexpected = m.load_state_dict(hf, strict=True), None
+    img = synth.synthetic_crowd_frame(5, 1024, 40)[:768]
+    x = so.preprocess(torch.from_numpy(img).permute(2, 0, 1).float().contiguous())[None]
+    xd = torch.nn.functional.interpolate(x, (1022, 1022), mode="bilinear")
+    with torch.no_grad():
+        y = m(pixel_values=xd, interpolate_pos_encoding=True).last_hidden_state[:, 1:]
+        o_size = so.dinov2_forward(sd, xd, depth=depth, pos_offset=None)
+        o_off = so.dinov2_forward(sd, xd, depth=depth, pos_offset=0.1)
+    e_size, e_off = (y - o_size).abs(), (y - o_off).abs()
+    print("dino_hf: HF vs oracle(size= form) max %.3g mean %.3g | vs oracle(+0.1 form) max %.3g mean %.3g | |y| mean %.3g"
+          % (e_size.max(), e_size.mean(), e_off.max(), e_off.mean(), y.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "dino_hf_vitl14.npz"), sample=y[0, ::7, ::8].numpy(),
+                        sum=np.float64(y.double().sum()), abs_sum=np.float64(y.double().abs().sum()),
+                        err_vs_oracle_size=np.array([e_size.max(), e_size.mean()]),
+                        err_vs_oracle_offset=np.array([e_off.max(), e_off.mean()]))
 
 
 def golden_pipeline_fuse():

@@ -7,8 +7,8 @@ Each function cites the reference lines it follows (paths relative to /root/refe
 Third-party arithmetic the reference reaches through un-vendored wheels is restated from the
 published algorithms and is "parity unpinned" (SURVEY.md §8c): torchvision.ops.nms (greedy,
 suppress IoU > thr, stable descending score order), cv2.connectedComponentsWithStats
-(8-connectivity; scipy.ndimage.label here), pycocotools rleToString, cv2/PIL resizes
-(avoided: parity inputs are already 1024 on the long side).
+(8-connectivity; scipy.ndimage.label here), pycocotools rleToString, cv2.resize (oracle/resize_oracle.py;
+the reference-pinned fixtures start at the post-resize frame).  Pillow's bilinear resize IS pinned (against Pillow).
 """
 import math
 from copy import deepcopy
@@ -85,6 +85,34 @@ def coco_rle_string(counts):
                 ch |= 0x20
             s.append(chr(ch + 48))
     return "".join(s)
+
+
+def coco_rle_decode(counts_str, h, w):
+    """pycocotools rleFrString + rleDecode (published algorithm): compressed string -> bool [h, w]."""
+    if isinstance(counts_str, bytes):
+        counts_str = counts_str.decode("ascii")
+    counts, p = [], 0
+    while p < len(counts_str):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(counts_str[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    flat = np.zeros(h * w, dtype=bool)
+    idx, val = 0, False
+    for c in counts:
+        if val:
+            flat[idx:idx + c] = True
+        idx += c
+        val = not val
+    return flat.reshape(w, h).T
 
 
 def coco_encode_rle(rle):
@@ -278,13 +306,16 @@ class OracleCrowdSAM:
         self.record = record  # optional dict collecting intermediates for tests
         self._dense_pe = so.dense_pe(sam_sd)
 
-    # predictor.set_image / set_torch_image (predictor.py:32-112) for an image whose long side is 1024
+    # predictor.set_image / set_torch_image (predictor.py:32-112)
     def set_image(self, image):
+        from . import resize_oracle
         h, w = image.shape[:2]
-        assert max(h, w) == 1024, "oracle parity inputs are pre-sized (SURVEY.md §8c recipe)"
+        nh, nw = get_preprocess_shape(h, w, 1024)            # ResizeLongestSide.apply_image (transforms.py:26-31):
+        if (nh, nw) != (h, w):                               # PIL bilinear; identity unless the long side is 1023
+            image = resize_oracle.pil_resize_bilinear_u8(image, (nh, nw))
         self.original_size = (h, w)
-        self.input_size = (h, w)
-        x = torch.as_tensor(image).permute(2, 0, 1).contiguous()[None].float()
+        self.input_size = (nh, nw)
+        x = torch.as_tensor(np.ascontiguousarray(image)).permute(2, 0, 1).contiguous()[None].float()
         x = so.preprocess(x[0])[None]
         self.features = so.image_encoder(self.sd, x, self.depth, self.heads, self.global_idx)
         xd = F.interpolate(x, (1022, 1022), mode="bilinear")
@@ -354,16 +385,50 @@ class OracleCrowdSAM:
         return d
 
     def generate(self, image):
-        """crowdsam/model.py:133-306 for one crop.  Returns dict of numpy arrays + rles."""
+        """crowdsam/model.py:133-190: crops -> _process_crop -> cross-crop NMS (smaller crops first) -> numpy dict.
+        With more than one crop the reference index-filters its 2-entries-per-crop ``rles_info`` list and raises
+        (SURVEY.md section 8 f4); the sane behaviour restated here keeps per-mask crop boxes (``rles_crop``) and
+        filters those."""
         cfg = self.cfg
         image = np.asarray(image, dtype=np.uint8)
+        crop_boxes, _ = generate_crop_boxes(image.shape[:2], cfg["crop_n_layers"], cfg["crop_overlap_ratio"])
+        data = None
+        self.n_batches = 0
+        for crop_box in crop_boxes:
+            cd = self._process_crop(image, crop_box)
+            if cd is None:
+                continue
+            if data is None:
+                data = cd
+            else:
+                for k in data:
+                    data[k] = data[k] + cd[k] if isinstance(data[k], list) else torch.cat([data[k], cd[k]], dim=0)
+        empty = dict(boxes=np.zeros((0, 4), np.float32), scores=np.zeros((0,), np.float32),
+                     categories=np.zeros((0,), np.int64), rles=[], points=np.zeros((0, 2)))
+        if data is None:
+            return empty
+        if len(crop_boxes) > 1 and len(data["crop_boxes"]) > 0:
+            cb = data["crop_boxes"]
+            scores = 1 / ((cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1]))          # :169 prefer smaller crops
+            keep = nms(data["boxes"].float(), scores, cfg["crop_nms_thresh"])
+            for k in data:
+                data[k] = [data[k][int(i)] for i in keep] if isinstance(data[k], list) else data[k][keep]
+        out = dict(boxes=data["boxes"].numpy(), scores=data["scores"].numpy(), categories=data["categories"].numpy(),
+                   points=data["points"].numpy(), stability_score=data["stability_score"].numpy(),
+                   rles=[coco_encode_rle(r) for r in data["rles"]], rles_uncompressed=data["rles"],
+                   rles_crop=data["crop_boxes"].numpy())
+        if "masks" in data:
+            out["masks"] = data["masks"]
+        return out
+
+    def _process_crop(self, image, crop_box):
+        """crowdsam/model.py:192-306 for one crop."""
+        from . import resize_oracle
+        cfg = self.cfg
         self.orig_image = image
-        H0, W0 = image.shape[:2]
-        self.crop_box = [0, 0, W0, H0]
-        nh, nw, r = resize_shape(H0, W0, cfg["max_size"])
-        assert (nh, nw) == (H0, W0), "oracle parity inputs are pre-sized to the 1024 frame"
-        self.image = image
-        self.downscale = r
+        self.crop_box = list(crop_box)
+        x0, y0, x1, y1 = crop_box
+        self.image, self.downscale = resize_oracle.resize_image(image[y0:y1, x0:x1, :], cfg["max_size"])   # :119-131
         self.set_image(self.image)
         pts = self.sample_points()
         occupy = torch.zeros(self.image.shape[0], self.image.shape[1], dtype=torch.bool)
@@ -372,7 +437,6 @@ class OracleCrowdSAM:
         self.rng.shuffle(points)             # :231 global RNG
         count = 0
         bs = cfg["points_per_batch"]
-        n_batches = 0
         while len(points) > 0 and count < cfg["max_prompts"]:
             bs = min(len(points), bs)
             sel = points[:bs]
@@ -387,12 +451,9 @@ class OracleCrowdSAM:
             keep = (~occupy[points[:, 1], points[:, 0]]).numpy()
             points = points[keep]
             count += bs
-            n_batches += 1
-        self.n_batches = n_batches
-        empty = dict(boxes=np.zeros((0, 4), np.float32), scores=np.zeros((0,), np.float32),
-                     categories=np.zeros((0,), np.int64), rles=[], points=np.zeros((0, 2)))
+            self.n_batches += 1
         if data is None or len(data["masks"]) == 0:
-            return empty
+            return None
         keep = nms(data["boxes"].float(), data["iou_preds"], cfg["box_nms_thresh"])
         for k in data:
             data[k] = data[k][keep]
@@ -403,14 +464,13 @@ class OracleCrowdSAM:
             data["scores"] = fuse_simmap_scores(data["masks"], data["iou_preds"], self._sim, self.image.shape[:2])
         else:
             data["scores"] = data["iou_preds"]
-        rles = mask_to_rle(data["masks"])
-        boxes = data["boxes"] / self.downscale + torch.tensor([[0, 0, 0, 0]])
-        points_out = data["points"] / self.downscale + torch.tensor([[0, 0]])
-        out = dict(boxes=boxes.numpy(), scores=data["scores"].numpy(),
-                   categories=data["categories"].numpy(), points=points_out.numpy(),
-                   stability_score=data["stability_score"].numpy(),
-                   rles=[coco_encode_rle(r) for r in rles], rles_uncompressed=rles,
-                   masks=data["masks"].numpy())
+        n = len(data["boxes"])
+        out = dict(boxes=data["boxes"] / self.downscale + torch.tensor([[x0, y0, x0, y0]]),         # :298-300
+                   points=data["points"] / self.downscale + torch.tensor([[x0, y0]]),
+                   scores=data["scores"], categories=data["categories"], stability_score=data["stability_score"],
+                   crop_boxes=torch.tensor([list(crop_box) for _ in range(n)]).reshape(n, 4),
+                   rles=mask_to_rle(data["masks"]))
+        out["masks"] = [m for m in data["masks"].numpy()]      # per-crop frames differ in size: a list
         return out
 
     @staticmethod

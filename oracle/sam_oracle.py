@@ -226,6 +226,17 @@ def two_way_transformer(sd, src, pos, tokens, prefix="mask_decoder.transformer."
     return queries, keys
 
 
+def upscale_hyper(sd, src, hyper, prefix="mask_decoder."):
+    """mask_decoder.py:172-181: ConvT(256->64,k2,s2) -> LayerNorm2d -> GELU(erf) -> ConvT(64->32,k2,s2) -> GELU(erf), then
+    masks[b,l] = sum_c hyper[b,l,c] * up[b,c].  src [B,256,64,64], hyper [B,4,32] -> [B,4,256,256]."""
+    U = prefix + "output_upscaling."
+    up = F.conv_transpose2d(src, sd[U + "0.weight"], sd[U + "0.bias"], stride=2)
+    up = F.gelu(layer_norm_2d(sd, U + "1", up))
+    up = F.gelu(F.conv_transpose2d(up, sd[U + "3.weight"], sd[U + "3.bias"], stride=2))
+    b, c, h, w = up.shape
+    return (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)
+
+
 def mask_decoder(sd, image_embeddings, image_pe, sparse, dino_feats, prefix="mask_decoder."):
     """mask_decoder.py:138-199 predict_masks (multimask_output=True keeps all 4, :129-135).
 
@@ -243,14 +254,9 @@ def mask_decoder(sd, image_embeddings, image_pe, sparse, dino_feats, prefix="mas
     iou_tok = hs[:, 0, :]
     mask_toks = hs[:, 1:5, :]
     src = keys.transpose(1, 2).view(b, c, h, w)
-    U = prefix + "output_upscaling."
-    up = F.conv_transpose2d(src, sd[U + "0.weight"], sd[U + "0.bias"], stride=2)
-    up = F.gelu(layer_norm_2d(sd, U + "1", up))
-    up = F.gelu(F.conv_transpose2d(up, sd[U + "3.weight"], sd[U + "3.bias"], stride=2))
     hyper = torch.stack([mlp_relu(sd, f"{prefix}output_hypernetworks_mlps.{i}", mask_toks[:, i, :], 3)
                          for i in range(4)], dim=1)
-    b, c, h, w = up.shape
-    masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)
+    masks = upscale_hyper(sd, src, hyper, prefix)
     iou = mlp_relu(sd, prefix + "iou_prediction_head", iou_tok, 3)
     # PWD-Net heads (:186-198)
     d = linear(sd, prefix + "dino_proj", dino_feats)

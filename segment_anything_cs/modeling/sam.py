@@ -44,6 +44,12 @@ class _Planned(_ParamTree):
         self._plan = None
         return super().load_state_dict(*a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        # Sam.load_state_dict recurses through the children with _load_from_state_dict, never through their
+        # load_state_dict override: invalidate here too, or a resident EncoderPlan keeps the old fp16 weight copies
+        self._plan = None
+        return super()._load_from_state_dict(*a, **k)
+
     def _apply(self, fn, *a, **k):
         self._plan = None
         return super()._apply(fn, *a, **k)

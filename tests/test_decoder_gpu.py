@@ -45,12 +45,13 @@ def test_decoder_vs_reference_golden(plan, cuda):
     err = np.abs(low[:, :, ::8, ::8] - ref)
     scale = np.abs(ref).mean()
     print("low-res logits: mean|ref|=%.3f max err=%.4f mean err=%.5f" % (scale, err.max(), err.mean()))
-    assert err.mean() < 0.02 * scale and err.max() < 0.25 * scale
-    np.testing.assert_allclose(low.astype(np.float64).sum((2, 3)), g["low_sum"], rtol=0, atol=0.02 * scale * 65536)
+    # fp16 operands / fp32 accumulate against the fp32 reference: mean < 0.5 %, max < 5 % of the mean |logit|
+    assert err.mean() < 0.005 * scale and err.max() < 0.05 * scale
+    np.testing.assert_allclose(low.astype(np.float64).sum((2, 3)), g["low_sum"], rtol=0, atol=0.005 * scale * 65536)
     e_iou = np.abs(iou.cpu().numpy() - g["iou"]).max()
     e_cls = np.abs(cls.cpu().numpy() - g["cls"]).max()
     print("iou err %.5f  cls err %.5f" % (e_iou, e_cls))
-    assert e_iou < 2e-2 and e_cls < 2e-2
+    assert e_iou < 5e-3 and e_cls < 5e-3
     # dense PE and point tokens are fp32 kernels: tight tolerance
     pe = plan.pe.view(64, 64, 256).permute(2, 0, 1)[None].cpu().numpy()
     np.testing.assert_allclose(pe[:, ::8, ::4, ::4], g["dense_pe_sample"], rtol=0, atol=2e-5)
@@ -98,3 +99,74 @@ def test_large_batch_stream_kernels_match_small_batch_path(cuda):
             (c0, err.max().item(), err.mean().item(), scale)
         assert (iou - iou_big[c0:c0 + 64]).abs().max().item() < 5e-3
         assert (cls - cls_big[c0:c0 + 64]).abs().max().item() < 5e-3
+
+
+def test_decoder_production_batch_vs_reference_golden(cuda):
+    """The kernels the benchmark runs (>= 256 prompts: csam_t2i_stream, csam_upscale_stream, csam_i2t_rank, csam_i2t_stream)
+    against the REFERENCE's own mask decoder on 320 prompts (tests/golden/decoder_big_test128.npz, produced by
+    oracle/make_goldens.py::golden_decoder_big from /root/reference/segment_anything_cs/modeling/mask_decoder.py)."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    g = np.load(os.path.join(G, "decoder_big_test128.npz"))
+    sd = synth.make_sam_state_dict("vit_test128")
+    plan = DecoderPlan(sd, cuda, n_class=1, max_batch=320)
+    assert plan.t2i_stream and plan.up_stream and plan.i2t_stream and plan.i2t_rank
+    _set_image(plan, cuda)
+    pts = np.random.RandomState(12).randint(0, 1024, size=(320, 1, 2)).astype(np.float64)
+    coords = torch.from_numpy(pts[:, 0, :].astype(np.float32)).to(cuda).contiguous()
+    masks, iou, cls = plan.run_batch(coords)
+    torch.cuda.synchronize()
+    low = masks.cpu().numpy()
+    ref = g["low_sample"]
+    err = np.abs(low[:, :, 5::32, 9::32] - ref)
+    scale = np.abs(ref).mean()
+    print("B=320 low-res logits: mean|ref|=%.3f max err=%.4f mean err=%.5f" % (scale, err.max(), err.mean()))
+    assert err.mean() < 0.005 * scale and err.max() < 0.05 * scale
+    np.testing.assert_allclose(low.astype(np.float64).sum((2, 3)), g["low_sum"], rtol=0, atol=0.005 * scale * 65536)
+    np.testing.assert_allclose(np.abs(low.astype(np.float64)).sum((2, 3)), g["low_abs_sum"], rtol=0, atol=0.005 * scale * 65536)
+    np.testing.assert_allclose(low.max((2, 3)), g["low_max"], rtol=0, atol=0.05 * scale)
+    e_iou = np.abs(iou.cpu().numpy() - g["iou"]).max()
+    e_cls = np.abs(cls.cpu().numpy() - g["cls"]).max()
+    print("B=320 iou err %.5f  cls err %.5f" % (e_iou, e_cls))
+    assert e_iou < 5e-3 and e_cls < 5e-3
+    # PWD-Net selection (argmax of clamp(iou,0)*sigmoid(cls), first max wins) must agree wherever the reference's
+    # margin between its best two candidates exceeds the value tolerance
+    s_ref = np.clip(g["iou"], 0, None) / (1 + np.exp(-g["cls"][..., 0]))
+    s_got = np.clip(iou.cpu().numpy(), 0, None) / (1 + np.exp(-cls.cpu().numpy()[..., 0]))
+    top2 = np.sort(s_ref, 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-2
+    assert clear.sum() > 100 and np.array_equal(s_ref.argmax(1)[clear], s_got.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("B", [3, 300])
+def test_upscale_stream_vs_oracle_fp32(cuda, B):
+    """csam_upscale_stream -- the largest kernel of the benchmark -- directly against the oracle's fp32 restatement of
+    mask_decoder.py:172-181 (erf GELU, LayerNorm2d, both transposed convolutions, hyper product), with the plan's own
+    weight permutations; not against another HIP kernel."""
+    from crowdsam_amd import hip, synth
+    from crowdsam_amd.decoder import DecoderPlan
+    from oracle import sam_oracle as so
+    sd = synth.make_sam_state_dict("vit_test128")
+    plan = DecoderPlan(sd, cuda, n_class=1, max_batch=8)
+    gen = torch.Generator().manual_seed(40 + B)
+    nX = min(B, 6)
+    X = (torch.randn(nX, 4096, 256, generator=gen) * 0.9).half()
+    idx = torch.arange(B) % nX
+    hyper = torch.randn(B, 4, 32, generator=gen) * 0.6
+    masks = torch.full((B, 4, 256, 256), float("nan"), device=cuda)
+    stats = torch.full((B * 4, 2), float("nan"), device=cuda)
+    Xd = X[idx].contiguous().view(B * 4096, 256).to(cuda)
+    hip.upscale_stream(Xd, plan.up1_w, plan.up1_b, plan.up_ln_g, plan.up_ln_b, 1e-6, plan.up2_w_perm, plan.up2_b,
+                       hyper.to(cuda).contiguous(), masks, B, stats=stats)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        up_src = X.float().transpose(1, 2).reshape(nX, 256, 64, 64)
+        for b in range(0, B, 50):
+            sl = slice(b, min(b + 50, B))
+            ref = so.upscale_hyper(sd, up_src[idx[sl]], hyper[sl])
+            got = masks[sl].cpu()
+            err = (got - ref).abs()
+            scale = ref.abs().mean().item()
+            assert err.mean().item() < 0.003 * scale and err.max().item() < 0.03 * scale, \
+                (b, err.mean().item(), err.max().item(), scale)
+            assert torch.allclose(stats[sl.start * 4:sl.stop * 4, 0].cpu(), got.reshape(-1, 65536).max(1).values)

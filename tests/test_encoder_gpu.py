@@ -129,3 +129,25 @@ def test_encoder_real_width_vs_oracle(cuda, D, heads):
         ref = so.image_encoder(sd, x, 2, heads, (1,))
     err = (y - ref).abs()
     assert err.max().item() < 6e-2 and err.mean().item() < 6e-3, (err.max().item(), err.mean().item())
+
+
+def test_encoder_vit_l_full_depth_vs_reference_golden(cuda):
+    """All 24 blocks of ViT-L (BASELINE configs[1] input) against the REFERENCE encoder's own output
+    (tests/golden/encoder_vit_l.npz: strided sample + sums, from /root/reference image_encoder.py via make_goldens)."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.encoder import EncoderPlan
+    g = np.load(os.path.join(G, "encoder_vit_l.npz"))
+    D, depth, heads, gidx = synth.SAM_CONFIGS["vit_l"]
+    sd = synth.make_sam_state_dict("vit_l")
+    plan = EncoderPlan(sd, "image_encoder.", D, depth, heads, gidx, cuda)
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(3, 1, 1)
+    feat = plan.forward((x[0] * std + mean).to(cuda).contiguous())
+    y = feat.view(64, 64, 256).permute(2, 0, 1)[None].cpu().numpy()
+    ref = g["sample"]
+    err = np.abs(y[:, ::4, 1::4, 2::4] - ref)
+    scale = np.abs(ref).mean()
+    print("ViT-L x24: mean|ref| %.3f  max err %.4f  mean err %.5f" % (scale, err.max(), err.mean()))
+    assert err.mean() < 0.01 * scale and err.max() < 0.1 * scale, (err.mean(), err.max(), scale)
+    assert abs(np.abs(y.astype(np.float64)).sum() - float(g["abs_sum"])) < 0.005 * float(g["abs_sum"])

@@ -127,6 +127,68 @@ def test_mask_mean_bilinear_matches_oracle(cuda):
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
 
 
+def test_generate_vit_b_512_matches_reference_golden(cuda):
+    """BASELINE configs[0]: ViT-B (_build_sam(768,12,12,1,[2,5,8,11])) + 8x8 grid on one 512x512 frame against the
+    reference's own CrowdSAM.generate (tests/golden/pipeline_vit_b_512.npz).  Exercises the up-scaling frame resize
+    (512 -> 1024, device cv2 restatement; the fixture pins the reference from the post-resize frame on), the ViT-B
+    encoder geometry (12 heads x 64, global blocks 2/5/8/11) and the /downscale un-cropping of boxes and points."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import VITB_CFG, vitb_image
+    cfg = _config(VITB_CFG)
+    cfg["model"]["sam_model"] = "vit_b"
+    m = CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict("vit_b"), dino_model=GpuStandInDino(cuda))
+    g = np.load(os.path.join(G, "pipeline_vit_b_512.npz"), allow_pickle=True)
+    np.random.seed(42)
+    out = m.generate(vitb_image())
+    assert m.downscale == 2.0 and out["boxes"].shape == g["boxes"].shape == (64, 4)
+    # box NMS at threshold 1.0 suppresses nothing but returns the prompts in descending-score order; near-tied
+    # scores may swap under fp16 operands, so the two results are aligned by prompt point (all 64 distinct)
+    ka = np.lexsort((out["points"][:, 1], out["points"][:, 0]))
+    kb = np.lexsort((g["points"][:, 1], g["points"][:, 0]))
+    np.testing.assert_array_equal(out["points"][ka], g["points"][kb])
+    np.testing.assert_array_equal(out["categories"][ka], g["categories"][kb])
+    np.testing.assert_allclose(out["scores"][ka], g["scores"][kb], rtol=0, atol=5e-3)
+    assert np.all(np.diff(out["scores"]) <= 0)
+    assert np.abs(out["boxes"][ka] - g["boxes"][kb]).max() <= 1.5   # 3 px at the 1024 frame / downscale 2
+    np.testing.assert_allclose(out["stability_score"][ka], g["stability_score"][kb], rtol=0.03, atol=2e-3)
+    assert all(r["size"] == [1024, 1024] for r in out["rles"]) and len(out["rles"]) == 64
+    import crowdsam.utils as cu
+    area = np.array([int(cu.coco_decode_rle(r).sum()) for r in out["rles"]])
+    np.testing.assert_allclose(area[ka], g["mask_area"][kb], rtol=5e-3)      # RLE strings decode to the reference's masks
+
+
+@pytest.mark.parametrize("frame", ["768x1024", "700x1366"])
+def test_generate_multi_crop_matches_oracle(cuda, frame):
+    """crop_n_layers = 1: 1 + 4 crops; per-crop resize (cv2 restatement, incl. a 1023-side crop on the
+    second frame -> the PIL 1023 -> 1024 step and the non-identity second interpolate of postprocess_masks), crop-edge
+    filter applied per batch before the occupancy update, per-crop NMS, cross-crop NMS preferring small crops -- the
+    kept prompts, their order and categories must equal the CPU oracle's, values within tolerance."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle import pipeline_oracle as po
+    from oracle.make_goldens import PIPE_CFG, StandInDino, pipeline_image
+    cfg = dict(PIPE_CFG)
+    cfg.update(crop_n_layers=1, crop_nms_thresh=0.7, box_nms_thresh=0.8, max_prompts=16, min_mask_region_area=0)
+    img = pipeline_image() if frame == "768x1024" else synth.synthetic_crowd_frame(9, 1366, 120)[:700]
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    np.random.seed(1)
+    out = m.generate(img)
+    D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
+    np.random.seed(1)
+    o = po.OracleCrowdSAM(synth.make_sam_state_dict(ARCH), (depth, heads, gidx), StandInDino(), cfg, rng=np.random)
+    with torch.no_grad():
+        ref = o.generate(img)
+    print(frame, "kept", out["boxes"].shape, "oracle", ref["boxes"].shape)
+    assert out["boxes"].shape == ref["boxes"].shape and len(ref["boxes"]) > 0
+    np.testing.assert_array_equal(out["points"], ref["points"])              # same prompts survive, same order
+    np.testing.assert_array_equal(out["categories"], ref["categories"])
+    np.testing.assert_allclose(out["scores"], ref["scores"], rtol=0, atol=5e-3)
+    assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / min(1.0, 1024.0 / max(img.shape[:2]))
+    np.testing.assert_array_equal(out["rles_crop"], ref["rles_crop"])        # per-mask crop box (build's sane rles_info)
+    assert "crop_boxes" not in out and len(out["rles"]) == len(ref["rles"])
+
+
 def test_generate_two_crop_layers_runs(cuda):
     """crop_n_layers = 1: 1 + 4 crops, cross-crop NMS preferring small crops, per-crop rles_info
     kept as a per-crop record (the reference index-filters that list and raises once > 2*n_crops masks survive)."""
