@@ -5,7 +5,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libcsam_hip.so")
+# developer A/B builds: CSAM_BUILD_TAG=alt -> libcsam_hip_alt.so + build_alt/ (select it at run time with CSAM_LIB);
+# CSAM_DEFS_<source stem> = extra hipcc flags for one source, e.g. CSAM_DEFS_decoder_fused="-DFOO -fno-slp-vectorize"
+TAG = os.environ.get("CSAM_BUILD_TAG", "")
+LIB = os.path.join(HERE, "libcsam_hip%s.so" % ("_" + TAG if TAG else ""))
 ARCH = "gfx950"
 
 
@@ -37,7 +40,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -50,7 +53,7 @@ def build(force=False, verbose=True):
             continue
         cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
                "-Wno-unused-result", "-Wno-unused-value"] + EXTRA_FLAGS.get(os.path.basename(src), []) + \
-              ["-c", src, "-o", obj]
+              os.environ.get("CSAM_DEFS_" + os.path.basename(src).split(".")[0], "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -214,19 +214,231 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const half_t* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2 (round 2).  The round-1 kernel above spent most of its time OUTSIDE the matrix pipe: the one-hot key fragments
+// that inject the rel-pos bias through the QK^T MFMA were rebuilt with ~1700 VALU instructions per 16-query tile
+// (a wave64 VALU instruction occupies the SIMD for 4 cycles on gfx950), and its 116 KB of LDS (q + 64 extension
+// columns per query) allowed one workgroup per CU, i.e. two rounds of the 25 x nH grid with four waves per CU.
+// Here:
+//   * q is never staged: a wave loads the fragments of its query tile straight from the qkv GEMM output (or the
+//     bias for pad tokens); only K (row-major) and V^T live in LDS -> 67 KB, two workgroups per CU, the whole
+//     grid (400 workgroups for ViT-L) is resident at once;
+//   * the decomposed bias Th[q][kh] + Tw[q][kw] is computed once per query tile by the same small MFMA
+//     (relcat . q), kept in fp32 in a 2 KB per-wave LDS table and ADDED to the scores after the QK^T product:
+//     a lane's four keys are consecutive, so it needs Th for at most two key rows and four consecutive Tw
+//     entries (the Tw row is stored with its first four entries repeated, so the run never wraps) -- two 8-byte
+//     LDS reads, one select and two adds per score instead of two extra MFMAs per key tile;
+//   * V^T is staged two keys at a time (4-byte transposed writes).
+// Arithmetic: S = scale * (q.k) + Th + Tw with fp32 bias (round 1: hi+lo fp16 through the MFMA), base-2 softmax
+// over the 196 keys INCLUDING the pad tokens of edge windows (SURVEY.md trap 4), P.V with P in fp16.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int T_LD = 30;                             // floats per query row of the bias table: Th[14] | Tw[14 + 2 spare]
+constexpr int TW_OFF = 14;                           //   Tw at 14..27, its first 4 entries repeated at 28.. (see below)
+constexpr int T2_LD = 34;                            // Th 0..13 | Tw 14..27 | Tw[0..3] again 28..31 | pad 2 -> 136 B rows
+constexpr int T_BYTES = 4 * 16 * T2_LD * 4;          // per-wave tables
+constexpr int SMEM2_BYTES = KE_BYTES + VT_BYTES + T_BYTES;
+
+__global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restrict__ qkv,
+                                                           const float* __restrict__ qkv_bias,
+                                                           const half_t* __restrict__ relcat,
+                                                           half_t* __restrict__ out, int D, int nH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ke = (half_t*)smem;
+  half_t* Vt = (half_t*)(smem + KE_BYTES);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* Tt = (float*)(smem + KE_BYTES + VT_BYTES) + wave * 16 * T2_LD;
+  const int head = blockIdx.x % nH, win = blockIdx.x / nH;
+  const int wy = win / 5, wx = win % 5;
+  const long ld = 3L * D;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero
+  for (int it = tid; it < (NPAD / 2) * 2 * 8; it += 256) {
+    const int ip = it >> 4, r = it & 15, which = 1 + (r >> 3), ch = r & 7;     // token pair, k|v, 8-channel chunk
+    half8_t v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = 2 * ip + t;
+      v[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < NTOK) {
+        const int y = wy * WS + i / WS, x = wx * WS + i % WS;
+        const int col = which * D + head * 64 + ch * 8;
+        if (y < 64 && x < 64) {
+          v[t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[t][e] = (half_t)qkv_bias[col + e];
+        }
+      }
+    }
+    if (which == 1) {
+      *(half8_t*)(Ke + (2 * ip) * KE_LD + ch * 8) = v[0];
+      *(half8_t*)(Ke + (2 * ip + 1) * KE_LD + ch * 8) = v[1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[0][e], v[1][e]};
+    }
+  }
+  for (int it = tid; it < 64 * 12; it += 256)       // keys 208..231 of V^T (read by the last, half-empty k-step)
+    *(half2_t*)(Vt + (it / 12) * VT_LD + NPAD + 2 * (it % 12)) = half2_t{0, 0};
+
+  // ---- per-lane constants: rel-pos fragments, and for every key tile where this lane's 4 keys sit in the window
+  half8_t rf[4][2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) rf[nt][ks] = *(const half8_t*)(relcat + (nt * 16 + fr) * 64 + (ks * 4 + fg) * 8);
+  int koff[13];                                      // (kh0 << 8) | kw0 of key0 = 16 kt + 4 fg  (kw0 is even)
+#pragma unroll
+  for (int kt = 0; kt < 13; ++kt) {
+    const int key0 = kt * 16 + fg * 4;
+    koff[kt] = ((key0 / WS) << 8) | (key0 % WS);
+  }
+  __syncthreads();
+
+  const float sl2 = scale * 1.4426950408889634f;     // scores in base-2 units
+  const float l2e = 1.4426950408889634f;
+  for (int rt = wave; rt < 13; rt += 4) {
+    const int qi = rt * 16 + fr;
+    const int qh = qi / WS, qw = qi % WS;
+    const int y = wy * WS + qh, x = wx * WS + qw;
+    const bool inside = qi < NTOK && y < 64 && x < 64;
+    half8_t qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = head * 64 + (ks * 4 + fg) * 8;
+      qf[ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (inside) {
+        qf[ks] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
+      } else if (qi < NTOK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)qkv_bias[col + e];
+      }
+    }
+    // bias table of this query tile: T[j][q] = relcat[j] . q, scattered to Th[kh = qh + 13 - j], Tw[kw = qw + 13 - (j - 27)]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      floatx4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) t = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[nt][ks], qf[ks], t, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = nt * 16 + fg * 4 + r;
+        int col = -1;
+        if (j < 27) {
+          const int kh = qh + 13 - j;
+          if (kh >= 0 && kh < WS) col = kh;
+        } else if (j < 54) {
+          const int kw = qw + 13 - (j - 27);
+          if (kw >= 0 && kw < WS) col = TW_OFF + kw;
+        }
+        if (col >= 0) {
+          const float tv = t[r] * l2e;
+          Tt[fr * T2_LD + col] = tv;
+          if (col >= TW_OFF && col < TW_OFF + 4) Tt[fr * T2_LD + col + WS] = tv;     // Tw[0..3] repeated after Tw[13]
+        }
+      }
+    }
+    // (the table is wave-private: only this wave's own LDS writes must have landed before the reads below)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    floatx4 p[14];
+    float mx = -INFINITY;
+    const float* trow = Tt + fr * T2_LD;
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt) {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      const half_t* kr = Ke + (kt * 16 + fr) * KE_LD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8_t kf = *(const half8_t*)(kr + (ks * 4 + fg) * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], acc, 0, 0, 0);
+      }
+      // lane holds S_raw[key = kt*16 + fg*4 + j][query = rt*16 + fr]; its keys are (kh0, kw0 + j), wrapping to kh0 + 1
+      const int kh0 = koff[kt] >> 8, kw0 = koff[kt] & 255;
+      const float2_t th = *(const float2_t*)(trow + (kh0 & ~1));                  // Th[kh0 & ~1], Th[(kh0 & ~1) + 1]
+      const float th0 = (kh0 & 1) ? th[1] : th[0];
+      const float th1 = (kh0 & 1) ? trow[min(kh0 + 1, WS - 1)] : th[1];
+      const float2_t twa = *(const float2_t*)(trow + TW_OFF + kw0);
+      const float2_t twb = *(const float2_t*)(trow + TW_OFF + kw0 + 2);
+      const float tw[4] = {twa[0], twa[1], twb[0], twb[1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kt * 16 + fg * 4 + j;
+        const float bias = ((kw0 + j >= WS) ? th1 : th0) + tw[j];
+        const float sv = (kk < NTOK) ? fmaf(acc[j], sl2, bias) : -INFINITY;
+        acc[j] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      p[kt] = acc;
+    }
+    p[13] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 14; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = csam_exp2(p[kt][j] - mx);
+        p[kt][j] = e;
+        sum += e;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    half8_t pf[7];
+#pragma unroll
+    for (int s2 = 0; s2 < 7; ++s2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[s2][e] = (half_t)p[2 * s2][e];
+        pf[s2][4 + e] = (half_t)p[2 * s2 + 1][e];
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      floatx4 o = {0.f, 0.f, 0.f, 0.f};
+      const half_t* vr = Vt + (dt * 16 + fr) * VT_LD + fg * 4;
+#pragma unroll
+      for (int s2 = 0; s2 < 7; ++s2) {
+        const half4_t v0 = *(const half4_t*)(vr + 32 * s2);
+        const half4_t v1 = *(const half4_t*)(vr + 32 * s2 + 16);
+        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s2], o, 0, 0, 0);
+      }
+      if (inside) {
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[j] * inv);
+        *(half4_t*)(out + (long)(y * 64 + x) * D + head * 64 + dt * 16 + fg * 4) = h;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias,
                              const void* relcat_f16, void* out_f16, int D, int nH, float scale) {
   CSAM_REQUIRE(qkv_f16 && qkv_bias && relcat_f16 && out_f16, "csam_win_attn: null pointer");
   CSAM_REQUIRE(nH > 0 && D == nH * 64, "csam_win_attn: head_dim must be 64 (D=%d nH=%d)", D, nH);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int version = -1;
+  if (version < 0) {
+    const char* e = getenv("CSAM_WIN_ATTN");          // 1 = the round-1 kernel (A/B and debugging)
+    version = e ? atoi(e) : 2;
     hipFuncSetAttribute((const void*)win_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_set = true;
+    hipFuncSetAttribute((const void*)win_attn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
   }
-  hipLaunchKernelGGL(win_attn_kernel, dim3(25 * nH), dim3(256), SMEM_BYTES, (hipStream_t)stream,
-                     (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
+  if (version == 1)
+    hipLaunchKernelGGL(win_attn_kernel, dim3(25 * nH), dim3(256), SMEM_BYTES, (hipStream_t)stream,
+                       (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
+  else
+    hipLaunchKernelGGL(win_attn2_kernel, dim3(25 * nH), dim3(256), SMEM2_BYTES, (hipStream_t)stream,
+                       (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
   CSAM_LAUNCH_CHECK("csam_win_attn");
   return CSAM_OK;
 }

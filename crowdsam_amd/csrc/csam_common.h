@@ -111,6 +111,30 @@ __device__ __forceinline__ void csam_gelu_poly2_n(float2_t (&x)[N]) {
   for (int p = 0; p < N; ++p) x[p] = x[p] * __builtin_elementwise_fma(xc[p], r[p], (float2_t){0.5f, 0.5f});
 }
 
+// The same polynomial on N independent SCALARS (plain v_fma_f32, coefficient-major).  On gfx950 a v_pk_fma_f32 issues
+// over 4 cycles like two v_fma_f32 and is the slower of the two beside MFMAs (MI355X_MICROARCH.md, "packed f32 VALU ...
+// an anti-lever"); build the kernel's source with -fno-slp-vectorize or hipcc re-packs these.
+template <int N>
+__device__ __forceinline__ void csam_gelu_poly1_n(float (&x)[N]) {
+  const float c = 4.4f;
+  const float k[9] = {4.471991608e-11f, -4.528126140e-09f, 2.016253663e-07f, -5.250151905e-06f, 9.008348436e-05f,
+                      -1.092016766e-03f, 9.773204936e-03f, -6.629599897e-02f, 3.988868129e-01f};
+  float xc[N], u[N], r[N];
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    xc[p] = __builtin_amdgcn_fmed3f(x[p], -c, c);
+    u[p] = xc[p] * xc[p];
+  }
+#pragma unroll
+  for (int p = 0; p < N; ++p) r[p] = __builtin_fmaf(k[0], u[p], k[1]);
+#pragma unroll
+  for (int i = 2; i < 9; ++i)
+#pragma unroll
+    for (int p = 0; p < N; ++p) r[p] = __builtin_fmaf(r[p], u[p], k[i]);
+#pragma unroll
+  for (int p = 0; p < N; ++p) x[p] = x[p] * __builtin_fmaf(xc[p], r[p], 0.5f);
+}
+
 // exp2 for softmax arguments (<= 0, results in (0, 1]): the bare v_exp_f32.  exp2f() wraps it in a denormal-range
 // rescue (compare + 2 selects + ldexp per call) that only matters for results below 2^-126, which a softmax
 // weight may flush to zero.

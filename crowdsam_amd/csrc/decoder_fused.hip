@@ -1232,6 +1232,27 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
 // =====================================================================================================
 namespace {
 
+// GELU of 4 channel pairs: packed (v_pk_fma_f32) or, with -DCSAM_SCALAR_GELU (+ -fno-slp-vectorize), 8 scalar chains
+#if defined(CSAM_UP_NOGELU)      /* developer ablation builds (CSAM_DEFS_decoder_fused, crowdsam_amd/build.py) */
+#define CSAM_UP_GELU4(z) do { } while (0)
+#elif defined(CSAM_SCALAR_GELU)
+#define CSAM_UP_GELU4(z)                                                        \
+  do {                                                                          \
+    float zz__[8];                                                              \
+    _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                       \
+      zz__[2 * q__] = (z)[q__][0];                                              \
+      zz__[2 * q__ + 1] = (z)[q__][1];                                          \
+    }                                                                           \
+    csam_gelu_poly1_n<8>(zz__);                                                 \
+    _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__)(z)[q__] = float2_t{zz__[2 * q__], zz__[2 * q__ + 1]}; \
+  } while (0)
+#else
+#define CSAM_UP_GELU4(z) csam_gelu_poly2_n<4>(z)
+#endif
+
+#ifndef CSAM_UP_XDEPTH
+#define CSAM_UP_XDEPTH 3
+#endif
 constexpr int US_TOK = 32;
 constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
 constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
@@ -1318,113 +1339,127 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
       hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
     }
 
-    // ---- GEMM1: [64 co of this position] x [32 tokens], K = 256; accumulators seeded with b1
-    floatx4 a1[2][4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const floatx4 b1v = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
-      a1[0][ni] = b1v;
-      a1[1][ni] = b1v;
-    }
-    {
-      half8_t xf[2][2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) {
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            a1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks & 1][mi], a1[mi][ni], 0, 0, 0);
-        asm volatile("" ::: "memory");
-      }
-    }
-
-    // ---- phases 2-4 per 16-token tile (same arithmetic as upscale_fused_kernel)
+    // ---- GEMM1 + LayerNorm2d + GELU per 16-token sub-tile: [64 co of this position] x [16 tokens], K = 256.
+    // The ablation (r02) showed the GEMM1 phase at twice its MFMA time: with one fragment set in flight the
+    // ~250-cycle LDS latency of a loaded CU is exposed on each of the 8 k-steps (4 MFMAs = 64 cycles of cover).  One
+    // sub-tile at a time halves the live accumulators (16 instead of 32 registers) and pays for a 4-deep fragment
+    // ring; sub-tile 1's MFMAs are independent of sub-tile 0's LayerNorm / GELU and may issue beneath them.
+    half8_t xf2[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      half8_t xf2[2];
+      floatx4 a1[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
+#ifndef CSAM_UP_NOG1
       {
-        // LayerNorm2d statistics over the 64 channels of this pixel: in-lane partial sums (16 channels, packed),
-        // the four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)
-        float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+        constexpr int XD = CSAM_UP_XDEPTH;              // fragment sets in flight
+        half8_t xf[XD];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const float2_t lo = {a1[mi][ni][0], a1[mi][ni][1]}, hi = {a1[mi][ni][2], a1[mi][ni][3]};
-          s2 += lo;
-          q2 = __builtin_elementwise_fma(lo, lo, q2);
-          s2 += hi;
-          q2 = __builtin_elementwise_fma(hi, hi, q2);
-        }
-        const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const float mean = ssum[0] * (1.f / 64.f);
-        const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + p.eps);
-        const float nmr = -mean * rstd;
+        for (int ks = 0; ks < XD - 1; ++ks) xf[ks] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time: registers
-          float2_t z[4];
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + XD - 1 < 8)
+            xf[(ks + XD - 1) % XD] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + XD - 1) * 4 + fg) ^ fr) << 4));
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) {
-            const int ni = nh * 2 + n2;
-            const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
-            const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-              const float2_t av = {a1[mi][ni][e], a1[mi][ni][e + 1]};
-              const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
-              const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
-              z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
-            }
-          }
-          csam_gelu_poly2_n<4>(z);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
-            xf2[nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
-            xf2[nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
-          }
+          for (int ni = 0; ni < 4; ++ni)
+            a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
+          asm volatile("" ::: "memory");
         }
       }
-      floatx4 a2[8];                                    // seeded with the second conv's bias
+#else
+      asm volatile("" ::"v"(w1[0][0]), "v"(w1[3][7]), "v"(xb));
+#endif
+      // LayerNorm2d statistics over the 64 channels of a pixel: in-lane partial sums (16 channels, packed), the
+      // four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)
+      float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) a2[n2] = *(const floatx4*)(par + n2 * 16 + fg * 4);
+      for (int ni = 0; ni < 4; ++ni) {
+        const float2_t lo = {a1[ni][0], a1[ni][1]}, hi = {a1[ni][2], a1[ni][3]};
+        s2 += lo;
+        q2 = __builtin_elementwise_fma(lo, lo, q2);
+        s2 += hi;
+        q2 = __builtin_elementwise_fma(hi, hi, q2);
+      }
+      const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const float mean = ssum[0] * (1.f / 64.f);
+      const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + p.eps);
+      const float nmr = -mean * rstd;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time
+        float2_t z[4];
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = nh * 2 + n2;
+          const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
+          const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float2_t av = {a1[ni][e], a1[ni][e + 1]};
+            const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
+            const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
+            z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
+          }
+        }
+        CSAM_UP_GELU4(z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
+          xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
+          xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
+        }
+      }
+    }
+    // second conv + GELU + hyper product in two halves of its 8 N tiles (= output sub-positions 0,1 then 2,3), so that
+    // only 32 accumulator registers are live beside the 128 of the resident W1 slice
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      floatx4 a2[2][4];                                 // seeded with the second conv's bias
+#pragma unroll
+      for (int n2 = 0; n2 < 4; ++n2) {
+        const floatx4 b2v = *(const floatx4*)(par + (ph * 4 + n2) * 16 + fg * 4);
+        a2[0][n2] = b2v;
+        a2[1][n2] = b2v;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) {
-          const int row = n2 * 16 + fr;
+        for (int n2 = 0; n2 < 4; ++n2) {
+          const int row = (ph * 4 + n2) * 16 + fr;
           const half8_t wf = *(const half8_t*)(smem + US_W2S + row * 128 + (((s2 * 4 + fg) ^ (row & 7)) << 4));
-          a2[n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[s2], a2[n2], 0, 0, 0);
+          a2[0][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[0][s2], a2[0][n2], 0, 0, 0);
+          a2[1][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[1][s2], a2[1][n2], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int pos2 = 0; pos2 < 4; ++pos2) {
-        half8_t ub;
-        float2_t z[4];
+      for (int p2 = 0; p2 < 2; ++p2) {
+        const int pos2 = ph * 2 + p2;
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
+        for (int mi = 0; mi < 2; ++mi) {
+          float2_t z[4];
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[pos2 * 2 + h2][e], a2[pos2 * 2 + h2][e + 1]};
-        csam_gelu_poly2_n<4>(z);
+          for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ub[q * 2] = (half_t)z[q][0];
-          ub[q * 2 + 1] = (half_t)z[q][1];
-        }
-        floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
-        if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
-          const int yy = (pos >> 1) * 2 + (pos2 >> 1);
-          const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+            for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[mi][p2 * 2 + h2][e], a2[mi][p2 * 2 + h2][e + 1]};
+          CSAM_UP_GELU4(z);
+          half8_t ub;
 #pragma unroll
-          for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
+          for (int q = 0; q < 4; ++q) {
+            ub[q * 2] = (half_t)z[q][0];
+            ub[q * 2 + 1] = (half_t)z[q][1];
+          }
+#ifndef CSAM_UP_NOHYP
+          floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
+#else
+          floatx4 m4 = {(float)ub[0], (float)ub[2], (float)ub[4], (float)ub[6]};
+#endif
+          if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+            const int yy = (pos >> 1) * 2 + (pos2 >> 1);
+            const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
+          }
         }
       }
     }
@@ -1438,7 +1473,11 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         const int l = rowid >> 2, yy = rowid & 3;
         char* dst = (char*)(p.masks + (((long)b * 4 * 256) + 4 * i0) * 256 + half * 128);     // uniform base
         const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
+#ifndef CSAM_UP_NOSTORE
         asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(dst) : "memory");
+#else
+        asm volatile("" ::"v"(voff), "s"(dst));
+#endif
         const float mxv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
         if (it == 0) pmax0 = fmaxf(pmax0, mxv);
         else pmax1 = fmaxf(pmax1, mxv);
