@@ -32,7 +32,9 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
     needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         d = json.load(open(path))
         rows = [v for k, v in d["kernels"].items() if k.startswith(kernel_prefix)]
@@ -41,10 +43,10 @@ def pmc_traffic(kernel_prefix):
         if launches == 0:
             return None, "no PMC rows for " + kernel_prefix
         return total / launches, ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same bench "
-                                  "command (profiles/r01_pmc_traffic.json); all kernels: %.1f GB/image"
-                                  % (d["hbm_bytes_per_image_total"] / 1e9))
+                                  "command (profiles/%s); all kernels: %.1f GB/image"
+                                  % (os.path.basename(path), d["hbm_bytes_per_image_total"] / 1e9))
     except (OSError, KeyError, ValueError):
-        return None, "profiles/r01_pmc_traffic.json not found"
+        return None, "profiles/r0x_pmc_traffic.json not found"
 
 
 def encoder_only(args, rank, world, dev, sam_sd):
@@ -132,7 +134,7 @@ def main():
                          "about half of the 4096 prompts, a crowded-scene-like survivor share.")
     ap.add_argument("--encoder-only", action="store_true",
                     help="BASELINE configs[1]: SAM image-encoder forward only on a random normalised 1024^2 tensor")
-    ap.add_argument("--crowd-keep", type=int, default=300,
+    ap.add_argument("--crowd-keep", type=int, default=700,
                     help="second measured leg (dense mode): ~this many masks per image survive NMS into the small-region "
                          "clean-up + RLE (box NMS off, score cut calibrated on the warm-up frames); 0 disables the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,13 +304,35 @@ def main():
                             "PMC bytes per launch of the largest of them (i2t)"}
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_note = pmc_traffic("gemm_f16_kernel")
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (csam_gemm_f16*)", "achieved": achieved,
-                               "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                               "traffic": traffic, "traffic_note": traffic_note,
-                               "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
-                               "gemm_ms_per_step": ms / args.steps,
-                               "note": ("algorithmic 2*M*N*K of every GEMM launch / HIP-event time on the launch stream, measured on an "
-                                        "instrumented repeat of the K timed steps (graph replay and the DINOv2 side stream disabled)")}
+            res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm_f16_kernel + gemm256_kernel (csam_gemm_f16*)",
+                                    "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                                    "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
+                                    "gemm_ms_per_step": ms / args.steps,
+                                    "note": ("algorithmic 2*M*N*K of every GEMM launch / HIP-event time on the launch stream, "
+                                             "measured on an instrumented repeat of the K timed steps (graph replay and the "
+                                             "DINOv2 side stream disabled)")}
+            # the dominant single kernel of the timed region (rocprofv3 --stats: profiles/r02_bench_kernel_stats.txt):
+            # the persistent upscaler.  Algorithmic bytes per launch = prompts x (2 MB fp16 key state read + 1 MB fp32
+            # low-res logits written), SURVEY.md 8d passes R4 + the logits term.
+            up = full.get("csam_upscale_stream")
+            if up and up["ms"] > 0 and args.mode == "dense":
+                per_launch = (4096 * 256 * 2 + 4 * 256 * 256 * 4) * min(args.points_per_batch, n_prompts)
+                avg_ms = up["ms"] / up["calls"]
+                gbs = per_launch / (avg_ms * 1e-3) / 1e9
+                tr, tr_note = pmc_traffic("upscale_stream_kernel")
+                res["roofline"] = {
+                    "bound": "hbm", "kernel": "upscale_stream_kernel (csam_upscale_stream)", "achieved": gbs, "peak": 8000.0,
+                    "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_note": tr_note,
+                    "launches": up["calls"], "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch,
+                    "note": ("dominant kernel of the timed region (~16 % of GPU time).  HBM is the roof SURVEY.md 8d assigns to "
+                             "the decoder sweep, but this kernel is ISSUE-bound: its VALU (870 instructions per 32-token tile and "
+                             "wave, 72 % of them the two erf-GELU polynomials, 4 cycles each) and MFMA (112 x 16 cycles) times "
+                             "add up on a SIMD instead of overlapping (in-kernel ablations: no GELU -40 %, no first-conv MFMAs "
+                             "-18 %, no hyper MFMAs -7 %, no stores -3 %); it runs at 0.78 of that additive bound "
+                             "(DESIGN.md section 4, profiles/r02_upscale_ablation.txt)")}
+            else:
+                res["roofline"] = res["roofline_gemm"]
         if not args.no_cpu_baseline and world == 1:
             # CPU port of the path (oracle/) on the host cores, bounded sample, in a subprocess with a hard limit
             import subprocess

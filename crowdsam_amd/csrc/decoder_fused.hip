@@ -1367,7 +1367,14 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         }
       }
 #else
+#ifdef CSAM_UP_NOG1_PIN      /* ablation: no GEMM1, but the 128 registers of the W1 slice stay live */
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        asm volatile("" ::"v"(w1[ni][0]), "v"(w1[ni][1]), "v"(w1[ni][2]), "v"(w1[ni][3]), "v"(w1[ni][4]), "v"(w1[ni][5]),
+                     "v"(w1[ni][6]), "v"(w1[ni][7]));
+#else
       asm volatile("" ::"v"(w1[0][0]), "v"(w1[3][7]), "v"(xb));
+#endif
 #endif
       // LayerNorm2d statistics over the 64 channels of a pixel: in-lane partial sums (16 channels, packed), the
       // four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)

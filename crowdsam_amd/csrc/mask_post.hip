@@ -321,11 +321,11 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
     } else if (PASS == 0) {
       // Interior strip, statistics pass.  The VALU is the bound here (one wave64 VALU instruction = 4 cycles): the
       // vertical lerp runs on pixel PAIRS (v_pk_mul / v_pk_add; fp contraction is off, so the arithmetic is the
-      // generic kernel's mul, mul, add bit for bit) and every compare writes its 64-lane mask to SGPRs, where the
-      // counts (s_bcnt1), the row flags and the column flags (s_or) accumulate on the scalar unit -- 4.5 VALU
-      // instructions per pixel instead of ~13.
+      // generic kernel's mul, mul, add bit for bit); the compares against the mask threshold and the upper stability
+      // threshold write their 64-lane masks to SGPRs, where the count (s_bcnt1), the row flags and the column flags
+      // (s_or) accumulate on the scalar unit -- 5.5 VALU + 4 SALU instructions per pixel instead of ~13 VALU.
       typedef float f2 __attribute__((ext_vector_type(2)));
-      int sc_i = 0, sc_u = 0;                       // wave-uniform counters
+      int sc_i = 0;                                 // wave-uniform counter
       unsigned long long colm[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
       for (int yy = 0; yy < 16; ++yy) {
@@ -341,8 +341,11 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
           const f2 val = t1 + t2;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+            // the scalar unit issues one instruction per cycle per CU, the same rate as the four SIMDs' VALUs together:
+            // the work is split between them -- `inter` counts on the scalar side (compare -> mask -> s_bcnt1), `union`
+            // counts on the vector side (compare -> add-with-carry), the mask bits as SGPR ORs
             sc_i += __popcll(__ballot(val[h] > hi_t));
-            sc_u += __popcll(__ballot(val[h] > lo_t));
+            cnt_u += val[h] > lo_t;
             const unsigned long long m = __ballot(val[h] > a.thr);
             colm[2 * e2 + h] |= m;
             rowm |= m;
@@ -354,8 +357,7 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
         }
       }
       const int lane = tid & 63;
-      cnt_i = lane == 0 ? sc_i : 0;                 // the wave totals enter the block reduction once
-      cnt_u = lane == 0 ? sc_u : 0;
+      cnt_i = lane == 0 ? sc_i : 0;                 // the wave total enters the block reduction once
 #pragma unroll
       for (int e = 0; e < 4; ++e) colany[e] = (colm[e] >> lane) & 1ull ? 1u : 0u;
     } else {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer A/B: time one decoder batch with each alternative build of the library (crowdsam_amd/build.py CSAM_BUILD_TAG)
 B=${1:-2048}
-for lib in "" _sg _noslp _nogelu _nog1 _nohyp _nostore; do
+for lib in "" $(ls crowdsam_amd/libcsam_hip_*.so 2>/dev/null | sed "s/.*libcsam_hip\(_[a-z0-9]*\).so/\1/"); do
   f=crowdsam_amd/libcsam_hip${lib}.so
   [ -f $f ] || continue
   echo "== $f"
