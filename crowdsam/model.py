@@ -226,19 +226,38 @@ class CrowdSAM:
         store["counter"].zero_()
 
         points = points_for_image.astype("int")      # :230 truncation
-        np.random.shuffle(points)                    # :231 global RNG (seeded by the harness)
+        # :231 np.random.shuffle(points) on the global RNG (seeded by the harness).  NumPy shuffles the rows of a 2-D
+        # array one Python-level swap at a time (38 ms for the 36 864 points of the shipped grid_size 192); shuffling an
+        # index vector draws the SAME random_interval sequence (Fisher-Yates over n items either way), so the
+        # permutation and the RNG state afterwards are identical (tests/test_host_logic_cpu.py) at 3 ms
+        perm = np.arange(len(points))
+        np.random.shuffle(perm)
+        points = points[perm]
+        # The shuffled point list goes to the GPU ONCE; the sampler then works on indices into it.  (Uploading the
+        # remaining points every batch -- 36 864 of them at the shipped grid_size 192 -- was a pageable H2D of ~300 KB
+        # per batch, which ROCm pins on the fly: 0.7-14 ms each, several times the 1 ms the batch itself takes.)
+        all_pts_dev = None
+        alive = np.arange(len(points))               # indices of the points still in play, in shuffled order
         count = 0
         n_batches = 0
         batch_size = self.points_per_batch
-        while len(points) > 0 and count < self.max_prompts:
-            batch_size = min(len(points), batch_size)
-            sel_pts, points = points[:batch_size], points[batch_size:]
-            bd = self._process_batch(sel_pts, self.predictor.original_size, crop_box, store)
-            if prune and len(points) > 0:
-                rem = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
-                occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
-                hip.occupancy_lookup(rem, store["masks"], bd["occ"], batch_size, H, W, occupy_bits, slot=bd["slot"])
-                points = points[~occupy_bits.cpu().numpy().astype(bool)]      # the per-batch sync
+        while len(alive) > 0 and count < self.max_prompts:
+            batch_size = min(len(alive), batch_size)
+            sel_idx, alive = alive[:batch_size], alive[batch_size:]
+            tb = time.perf_counter()
+            bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
+            tb = self._tick("eps.batch", tb)
+            if prune and len(alive) > 0:
+                if all_pts_dev is None:
+                    all_pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+                    occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
+                    tb = self._tick("eps.upload_points", tb)
+                # occupancy of EVERY point under this batch's masks (the mask is replaced per batch, :246); only the
+                # flags of the live points are looked at -- same pruning as points[~occupy_mask[y, x]] (:238-239)
+                hip.occupancy_lookup(all_pts_dev, store["masks"], bd["occ"], batch_size, H, W, occupy_bits, slot=bd["slot"])
+                occ = occupy_bits.cpu().numpy().astype(bool)                  # the per-batch sync
+                alive = alive[~occ[alive]]
+                self._tick("eps.prune", tb)
             count += batch_size
             n_batches += 1
         self.predictor.reset_image()

@@ -89,7 +89,12 @@ struct PostArgs {
   float score_thr = 0.f;          // the predicted-IoU filter BEFORE stability is looked at, crowdsam/model.py:371-376)
 };
 
-constexpr int POST_ROWS = 16;   // output rows per workgroup
+constexpr int POST_ROWS = 16;   // output rows per row block
+#ifndef CSAM_POST_RB
+#define CSAM_POST_RB 4
+#endif
+constexpr int POST_RB = CSAM_POST_RB;   // row blocks per workgroup of the x4 statistics pass (the byte pass keeps 1:
+                                        // it is store-bound and measured 10 % slower with fewer, longer workgroups)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
@@ -196,7 +201,14 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
   if (a.score && !(a.score[b] > a.score_thr)) return;
   const int x4 = tid * 4;
   const float* p = a.src + (long)b * a.src_bstride + (long)a.sel[b] * a.plane;
-  const int i = blockIdx.x;                      // 16 output rows: y = 16 i .. 16 i + 15
+  // A workgroup walks POST_RB consecutive 16-row blocks: with one block per workgroup (262 144 workgroups per 4096
+  // prompts) the SIMDs were ~50 % busy -- a workgroup's life was mostly dispatch, first-load latency and the
+  // reduction / atomics tail, and 83 VGPRs cap the residency at six of them per CU.
+  int T_ci = 0, T_cu = 0, T_xmin = 1 << 30, T_xmax = -1, T_ymin = 1 << 30, T_ymax = -1;
+  constexpr int RB = PASS == 0 ? POST_RB : 1;
+  for (int ib = 0; ib < RB; ++ib) {
+  const int i = blockIdx.x * RB + ib;            // 16 output rows: y = 16 i .. 16 i + 15
+  if (i * 16 >= a.H) break;
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
   // PASS 0 box: per-pixel work is one OR into a column flag and one into the row flag; the extents are taken from the
   // flags once per row (y) and once per thread (x) instead of four predicated min / max per pixel
@@ -366,13 +378,23 @@ __global__ __launch_bounds__(256) void mask_post_x4_kernel(PostArgs a) {
   } else if (x4 < a.W) {
     rows(std::false_type{});
   }
-  if (PASS == 1) return;
+  if (PASS == 0) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (colany[e]) {
-      xmin = min(xmin, x4 + e);
-      xmax = max(xmax, x4 + e);
-    }
+    for (int e = 0; e < 4; ++e)
+      if (colany[e]) {
+        xmin = min(xmin, x4 + e);
+        xmax = max(xmax, x4 + e);
+      }
+    T_ci += cnt_i;
+    T_cu += cnt_u;
+    T_xmin = min(T_xmin, xmin);
+    T_xmax = max(T_xmax, xmax);
+    T_ymin = min(T_ymin, ymin);
+    T_ymax = max(T_ymax, ymax);
+  }
+  }   // row blocks
+  if (PASS == 1) return;
+  int cnt_i = T_ci, cnt_u = T_cu, xmin = T_xmin, xmax = T_xmax, ymin = T_ymin, ymax = T_ymax;
   __shared__ int red[4][6];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -569,9 +591,9 @@ static int post_launch(hipStream_t s, const float* lowres, const int* sel, const
     a.src = lowres; a.src_bstride = 4L * 65536; a.plane = 65536; a.sel = sel;
     a.sh = 256; a.sw = 256; a.scale_y = 256.0f / 1024.0f; a.scale_x = 256.0f / 1024.0f;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
-    dim3 grid(csam_cdiv(out_h, POST_ROWS), 1, B);
-    if (do_stats) hipLaunchKernelGGL(mask_post_x4_kernel<0>, grid, dim3(256), 0, s, a);
-    if (out_mask_u8) hipLaunchKernelGGL(mask_post_x4_kernel<1>, grid, dim3(256), 0, s, a);
+    dim3 grid0(csam_cdiv(csam_cdiv(out_h, POST_ROWS), POST_RB), 1, B), grid1(csam_cdiv(out_h, POST_ROWS), 1, B);
+    if (do_stats) hipLaunchKernelGGL(mask_post_x4_kernel<0>, grid0, dim3(256), 0, s, a);
+    if (out_mask_u8) hipLaunchKernelGGL(mask_post_x4_kernel<1>, grid1, dim3(256), 0, s, a);
   } else {
     if (!tmp_f32) {
       csam_set_error("csam_mask_post: tmp buffer required when original_size != input_size");

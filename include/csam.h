@@ -30,7 +30,9 @@ extern "C" {
 #define CSAM_ERR_HIP (-2)
 #define CSAM_ERR_WORKSPACE (-3)
 #define CSAM_ACT_NONE 0
-#define CSAM_ACT_GELU 1 /* exact erf GELU (nn.GELU default) */
+#define CSAM_ACT_GELU 1 /* erf GELU (nn.GELU default): fp32 outputs use erf (A&S 7.1.26, |err| <= 1.5e-7); fp16 outputs and
+                          * the fused upscaler use a minimax polynomial of Phi (|err| <= 4.5e-5, below the fp16 rounding of the
+                          * value it produces; csam_common.h csam_gelu_poly2, tools/fit_gelu_poly.py) */
 #define CSAM_ACT_RELU 2
 #define CSAM_DT_F16 0
 #define CSAM_DT_F32 1

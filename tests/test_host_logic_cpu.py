@@ -146,3 +146,19 @@ def test_batch_eval_convert_to_coco_schema():
     assert [x["id"] for x in a] == [0, 1, 2] and [x["image_id"] for x in a] == ["a,1", "b,2", "b,2"]
     assert a[0]["bbox"] == [1.0, 1.0, 4.0, 8.0] and a[0]["area"] == 32.0 and a[1]["bbox"] == [2.0, 3.0, 10.0, 20.0]
     assert coco["categories"] == [{"id": 1}]
+
+
+def test_index_shuffle_equals_row_shuffle():
+    """CrowdSAM._process_crop shuffles an index vector instead of the point rows (crowdsam/model.py:231 of the reference
+    calls np.random.shuffle(points)): same permutation, same global RNG state afterwards, for every length."""
+    for n in (0, 1, 2, 3, 17, 500, 4096):
+        pts = np.random.RandomState(n).randint(0, 1024, (n, 2))
+        a = pts.copy()
+        np.random.seed(1234 + n)
+        np.random.shuffle(a)
+        nxt_a = np.random.randint(0, 1 << 30)
+        np.random.seed(1234 + n)
+        perm = np.arange(n)
+        np.random.shuffle(perm)
+        nxt_b = np.random.randint(0, 1 << 30)
+        assert np.array_equal(a, pts[perm]) and nxt_a == nxt_b, n
