@@ -111,6 +111,9 @@ def resize_frame_device(image, max_size, device):
     from crowdsam_amd.resize import cv2_linear_tables_device
     h, w = image.shape[:2]
     nh, nw, r = resize_shape(h, w, max_size)
+    # (a pinned staging buffer for this upload was measured and rejected: with a torch pin_memory allocation alive
+    # every kernel of the frame ran 1.6-1.75x slower on the box -- 43.0 vs 64.7-75.3 ms/image, A/B in one process pair,
+    # profiles/r02_pinned_upload_ab.txt; the pageable copy stays)
     dev = torch.from_numpy(np.ascontiguousarray(image)).to(device, non_blocking=True)
     if (nh, nw) == (h, w):
         return dev, None, r
