@@ -241,6 +241,38 @@ __global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* __r
   for (int c = 0; c < 3; ++c) dst[c * n + idx] = (float)src[idx * 3 + c];
 }
 
+// Pillow's Image.resize(size, BILINEAR) for uint8 images (ImagingResample, 8 bits per channel), one separable pass:
+// out[o] = clip8((2^21 + sum_j in[xmin[o] + j] * k[o][j]) >> 22) with the 22-bit coefficient tables Pillow's
+// precompute_coeffs / normalize_coeffs_8bpc build (crowdsam_amd/resize.py).  ResizeLongestSide.apply_image
+// (segment_anything_cs/utils/transforms.py:26-31, via torchvision's resize(to_pil_image(.))) runs the horizontal pass,
+// rounds to uint8, then the vertical pass -- two launches of this kernel.  `axis` 0: along x, 1: along y.
+// Optionally also writes the fp32 CHW tensor the encoder kernels read (second pass).
+constexpr int PIL_MAXTAPS = 8;
+__global__ __launch_bounds__(256) void pil_resample_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw,
+                                                              const int* __restrict__ xmin, const int* __restrict__ ntap,
+                                                              const int* __restrict__ coef, int dh, int dw, int axis,
+                                                              uint8_t* __restrict__ dst, float* __restrict__ dst_chw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= dh * dw) return;
+  const int y = idx / dw, x = idx - y * dw;
+  const int o = axis == 0 ? x : y;
+  const int x0 = xmin[o], n = ntap[o];
+  int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+  for (int j = 0; j < n; ++j) {
+    const int k = coef[o * PIL_MAXTAPS + j];
+    const uint8_t* p = axis == 0 ? src + ((long)y * sw + x0 + j) * 3 : src + ((long)(x0 + j) * sw + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += (int)p[c] * k;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int v = acc[c] >> 22;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(long)idx * 3 + c] = (uint8_t)v;
+    if (dst_chw) dst_chw[(long)c * dh * dw + idx] = (float)v;
+  }
+}
+
 }  // namespace
 
 extern "C" int csam_preprocess_pad(void* stream, const float* img_chw, int h, int w, const float* mean3,
@@ -263,6 +295,17 @@ extern "C" int csam_resize_linear_u8(void* stream, const uint8_t* src_hwc, int s
   hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(csam_cdiv((long)dh * dw, 256)), dim3(256), 0, (hipStream_t)stream,
                      src_hwc, sh, sw, xofs, xcoef, yofs, ycoef, dh, dw, area2x, dst_hwc, dst_chw_f32);
   CSAM_LAUNCH_CHECK("csam_resize_linear_u8");
+  return CSAM_OK;
+}
+
+extern "C" int csam_pil_resample_u8(void* stream, const uint8_t* src_hwc, int sh, int sw, const int* xmin, const int* ntap,
+                                    const int* coef, int dh, int dw, int axis, uint8_t* dst_hwc, float* dst_chw_f32) {
+  CSAM_REQUIRE(src_hwc && xmin && ntap && coef && dst_hwc && sh > 0 && sw > 0 && dh > 0 && dw > 0 && (axis == 0 || axis == 1),
+               "csam_pil_resample_u8: bad args");
+  CSAM_REQUIRE(axis == 0 ? dh == sh : dw == sw, "csam_pil_resample_u8: one pass resizes one axis");
+  hipLaunchKernelGGL(pil_resample_u8_kernel, dim3(csam_cdiv((long)dh * dw, 256)), dim3(256), 0, (hipStream_t)stream, src_hwc,
+                     sh, sw, xmin, ntap, coef, dh, dw, axis, dst_hwc, dst_chw_f32);
+  CSAM_LAUNCH_CHECK("csam_pil_resample_u8");
   return CSAM_OK;
 }
 

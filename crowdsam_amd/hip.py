@@ -77,6 +77,7 @@ SIGNATURES = {
     "csam_sigmoid_max": [_P, _P, _I, _I, _P],
     "csam_resize_linear_u8": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "csam_u8hwc_to_f32chw": [_P, _P, _I, _I, _P],
+    "csam_pil_resample_u8": [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P],
 }
 LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
@@ -591,6 +592,30 @@ def resize_linear_u8(src_hwc, tables, out_hw, want_u8=True, want_f32chw=True):
         call("csam_resize_linear_u8", _stream(), _ptr(src_hwc), sh, sw, _ptr(xofs), _ptr(xcoef), _ptr(yofs),
              _ptr(ycoef), dh, dw, 0, _ptr(u8), _ptr(f32))
     return u8, f32
+
+
+def pil_resize_bilinear_u8(src_hwc, out_hw, tables_x, tables_y, want_f32chw=True):
+    """PIL.Image.resize((w, h), BILINEAR) of a uint8 [h,w,3] device frame: horizontal pass, uint8 rounding, vertical pass
+    (a pass whose size does not change is skipped).  tables_* from crowdsam_amd.resize.pil_bilinear_tables_device.
+    Returns (uint8 [dh,dw,3], fp32 [3,dh,dw] | None)."""
+    sh, sw, c = src_hwc.shape
+    assert c == 3 and src_hwc.dtype == torch.uint8 and src_hwc.is_contiguous()
+    dh, dw = out_hw
+    cur, f32 = src_hwc, None
+    passes = ([(0, sh, dw, tables_x)] if dw != sw else []) + ([(1, dh, dw, tables_y)] if dh != sh else [])
+    for i, (axis, oh, ow, tb) in enumerate(passes):
+        out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=src_hwc.device)
+        last = i == len(passes) - 1
+        if last and want_f32chw:
+            f32 = torch.empty((3, oh, ow), dtype=torch.float32, device=src_hwc.device)
+        call("csam_pil_resample_u8", _stream(), _ptr(cur), cur.shape[0], cur.shape[1], _ptr(tb[0]), _ptr(tb[1]), _ptr(tb[2]),
+             oh, ow, axis, _ptr(out), _ptr(f32) if last else None)
+        cur = out
+    if not passes:
+        cur = src_hwc.clone()
+    if want_f32chw and f32 is None:
+        f32 = u8hwc_to_f32chw(cur)
+    return cur, f32
 
 
 def u8hwc_to_f32chw(src_hwc):

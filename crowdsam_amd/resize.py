@@ -43,3 +43,42 @@ def cv2_linear_tables_device(sh, sw, dh, dw, device):
     if t is None:
         return None
     return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in t)
+
+
+# ---- Pillow ImagingResample (BILINEAR, 8 bits per channel): Resample.c precompute_coeffs + normalize_coeffs_8bpc
+PIL_PRECISION_BITS = 32 - 8 - 2
+PIL_MAXTAPS = 8
+
+
+def pil_bilinear_tables(in_size, out_size):
+    """numpy (xmin [out] i32, ntap [out] i32, coef [out, 8] i32).  support = max(in/out, 1): 2-3 taps when enlarging
+    (the 1023 -> 1024 case of SURVEY.md trap 9), up to 2*scale+1 when shrinking (<= 8 taps: scale <= 3.5)."""
+    scale = filterscale = np.float64(in_size) / np.float64(out_size)
+    if filterscale < 1.0:
+        filterscale = np.float64(1.0)
+    support = 1.0 * filterscale
+    ss = 1.0 / filterscale
+    xmin = np.zeros(out_size, np.int32)
+    ntap = np.zeros(out_size, np.int32)
+    coef = np.zeros((out_size, PIL_MAXTAPS), np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), in_size)
+        n = hi - lo
+        if n > PIL_MAXTAPS:
+            raise ValueError("pil_bilinear_tables: more than %d taps (shrink factor %.2f)" % (PIL_MAXTAPS, scale))
+        w = 1.0 - np.abs((np.arange(n, dtype=np.float64) + lo - center + 0.5) * ss)
+        w = np.where(w > 0.0, w, 0.0)
+        tot = w.sum()
+        if tot != 0.0:
+            w = w / tot
+        k = np.where(w < 0, -0.5 + w * (1 << PIL_PRECISION_BITS), 0.5 + w * (1 << PIL_PRECISION_BITS)).astype(np.int32)
+        xmin[xx], ntap[xx] = lo, n
+        coef[xx, :n] = k
+    return xmin, ntap, coef
+
+
+@functools.lru_cache(maxsize=64)
+def pil_bilinear_tables_device(in_size, out_size, device):
+    return tuple(torch.from_numpy(a).to(device) for a in pil_bilinear_tables(in_size, out_size))

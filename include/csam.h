@@ -93,6 +93,13 @@ int csam_sigmoid_max(void* stream, const float* x, int C, int N, float* out); /*
 int csam_resize_linear_u8(void* stream, const uint8_t* src_hwc, int sh, int sw, const int* xofs, const short* xcoef,
                           const int* yofs, const short* ycoef, int dh, int dw, int area2x, uint8_t* dst_hwc,
                           float* dst_chw_f32);
+/* One separable pass of Pillow's Image.resize(size, BILINEAR) for uint8 HWC frames (3 channels): ResizeLongestSide.
+ * apply_image (segment_anything_cs/utils/transforms.py:26-31, reached when the frame's long side is 1023, SURVEY.md
+ * trap 9).  xmin int32 [n_out], ntap int32 [n_out] (<= 8), coef int32 [n_out][8]: Pillow's 22-bit tables
+ * (crowdsam_amd/resize.py, pinned against Pillow itself).  axis 0 resizes x (dh == sh), axis 1 resizes y (dw == sw);
+ * dst_chw_f32 (optional) receives the fp32 CHW copy. */
+int csam_pil_resample_u8(void* stream, const uint8_t* src_hwc, int sh, int sw, const int* xmin, const int* ntap,
+                         const int* coef, int dh, int dw, int axis, uint8_t* dst_hwc, float* dst_chw_f32);
 /* SamPredictor.set_image's HWC uint8 -> 1x3xHxW layout change + cast (predictor.py:52-56) */
 int csam_u8hwc_to_f32chw(void* stream, const uint8_t* src_hwc, int h, int w, float* dst_chw);
 

@@ -43,11 +43,21 @@ class SamPredictor:
             if image_format != self.model.image_format:
                 image, f32 = image.flip(-1).contiguous(), None
             h, w = image.shape[:2]
-            if mask is None and cal_image and max(h, w) == self.model.image_encoder.img_size:
+            size = self.model.image_encoder.img_size
+            if mask is None and cal_image and max(h, w) == size:
                 if f32 is None:
                     f32 = hip.u8hwc_to_f32chw(image)
                 return self.set_torch_image(f32[None], (h, w))
-            image = image.cpu().numpy()          # e.g. a 1023-pixel long side (SURVEY.md trap 9): PIL resize on the host
+            th, tw = self.transform.get_preprocess_shape(h, w, size)
+            if mask is None and cal_image and max(h, w) < size and max(h, w) * 3.5 >= size:
+                # ResizeLongestSide.apply_image (PIL bilinear via torchvision, transforms.py:26-31) on the device: the
+                # 1023-pixel long side of SURVEY.md trap 9 (and any other enlargement) without a host round trip
+                from crowdsam_amd.resize import pil_bilinear_tables_device
+                dev = str(image.device)
+                _, f32 = hip.pil_resize_bilinear_u8(image.contiguous(), (th, tw), pil_bilinear_tables_device(w, tw, dev),
+                                                    pil_bilinear_tables_device(h, th, dev))
+                return self.set_torch_image(f32[None], (h, w))
+            image = image.cpu().numpy()          # anything else: PIL resize on the host
         elif image_format != self.model.image_format:
             image = image[..., ::-1]
         input_image = self.transform.apply_image(image)

@@ -205,3 +205,53 @@ def test_generate_two_crop_layers_runs(cuda):
     assert b.ndim == 2 and b.shape[1] == 4 and len(out["scores"]) == len(b) == len(out["rles"])
     assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= img.shape[1]).all() and (b[:, 3] <= img.shape[0]).all()
     assert "crop_boxes" not in out
+
+
+def test_generate_without_detections_and_area_selection(cuda):
+    """an image on which no prompt survives must still give a well-formed result (the reference's MaskData
+    then holds boxes / scores / rles only; tools/test.py copies the keys present) -- here every per-mask field exists and
+    is empty.  Also: mask_selection max_area / min_area (crowdsam/model.py:320-323) against the oracle's choice."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle import pipeline_oracle as po
+    from oracle import sam_oracle as so
+    from oracle.make_goldens import PIPE_CFG, pipeline_image
+    cfg = dict(PIPE_CFG)
+    cfg.update(stability_score_thresh=0.9999, pred_iou_thresh=0.99)
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    np.random.seed(3)
+    out = m.generate(pipeline_image())
+    assert out["boxes"].shape == (0, 4) and len(out["scores"]) == 0 and out["rles"] == []
+    assert len(out["categories"]) == 0 and out["points"].shape == (0, 2)
+    rec = {k: v.tolist() for k, v in out.items() if k in ["boxes", "scores", "categories"]}      # tools/test.py:71
+    assert rec == {"boxes": [], "scores": [], "categories": []}
+    # area-based selection: same surviving prompts and the same candidate index as picking by thresholded area
+    for mode in ("max_area", "min_area"):
+        cfg2 = dict(PIPE_CFG)
+        cfg2.update(mask_selection=mode, filter_thresh=float("inf"), max_prompts=16, box_nms_thresh=1.0, min_mask_region_area=0,
+                    pred_iou_thresh=0.0, stability_score_thresh=0.0)
+        m2 = CrowdSAM(_config(cfg2), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+        np.random.seed(5)
+        o2 = m2.generate(pipeline_image())
+        assert len(o2["boxes"]) == 16
+        # oracle: decode the same 16 prompts, choose by area of (logit > 0) at full resolution
+        D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
+        np.random.seed(5)
+        orc = po.OracleCrowdSAM(synth.make_sam_state_dict(ARCH), (depth, heads, gidx), __import__("oracle.make_goldens", fromlist=["x"]).StandInDino(),
+                                dict(cfg2, mask_selection="max_iou"), rng=np.random)
+        img = pipeline_image()
+        orc.orig_image, orc.crop_box = img, [0, 0, img.shape[1], img.shape[0]]
+        orc.image, orc.downscale = img, 1.0
+        with torch.no_grad():
+            orc.set_image(img)
+            pts = o2["points"].astype(np.int64)
+            masks, iou, cls, low = orc.predict_torch(torch.as_tensor(po.apply_coords(pts, orc.original_size))[:, None, :],
+                                                     torch.ones(len(pts), 1, dtype=torch.int))
+        area = (masks > 0).sum(dim=[-1, -2])
+        ind = area.max(dim=-1)[1] if mode == "max_area" else area.min(dim=-1)[1]
+        fused = torch.clamp(iou, 0.) * cls.squeeze(2).sigmoid()
+        ref_score = fused[torch.arange(len(pts)), ind].numpy()
+        srt = np.sort(area.numpy(), 1)
+        clear = (srt[:, -1] - srt[:, -2] > 200) if mode == "max_area" else (srt[:, 1] - srt[:, 0] > 200)
+        assert clear.sum() >= 4
+        np.testing.assert_allclose(o2["scores"][clear], ref_score[clear], rtol=0, atol=5e-3)

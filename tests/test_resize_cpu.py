@@ -85,3 +85,10 @@ def test_product_tables_equal_oracle_tables():
         assert np.array_equal(xofs, xs) and np.array_equal(xcoef, xa)
         assert np.array_equal(yofs, np.stack([r0, r1], 1)) and np.array_equal(ycoef, yb)
     assert pr.cv2_linear_tables(2048, 1536, 1024, 768) is None
+
+
+def test_product_pil_tables_equal_oracle_tables():
+    for a, b in [(1023, 1024), (682, 683), (100, 150), (640, 1024), (512, 1024), (900, 1024)]:
+        xm, nt, co = pr.pil_bilinear_tables(a, b)
+        for i, (x0, n, k) in enumerate(ro.pil_bilinear_coeffs(a, b)):
+            assert xm[i] == x0 and nt[i] == n and np.array_equal(co[i, :n], k), (a, b, i)

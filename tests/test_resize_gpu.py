@@ -33,3 +33,23 @@ def test_u8_to_chw():
     from crowdsam_amd import hip
     img = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (37, 53, 3)).astype(np.uint8)).cuda()
     assert torch.equal(hip.u8hwc_to_f32chw(img), img.permute(2, 0, 1).float())
+
+
+@pytest.mark.parametrize("shape", [(682, 1023), (1023, 700), (1023, 1023), (600, 900), (445, 640)])
+def test_pil_bilinear_kernel_bit_exact_vs_pillow(shape):
+    """ResizeLongestSide.apply_image (PIL bilinear through torchvision in the reference, transforms.py:26-31) as the
+    device kernel csam_pil_resample_u8, against Pillow itself (present on the GPU box); incl. the 1023 -> 1024 case of
+    SURVEY.md trap 9.  And the predictor path that uses it."""
+    from PIL import Image
+    from crowdsam_amd import hip
+    from crowdsam_amd.resize import pil_bilinear_tables_device
+    from segment_anything_cs.utils.transforms import ResizeLongestSide
+    h, w = shape
+    img = np.random.RandomState(h * 7 + w).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    th, tw = ResizeLongestSide.get_preprocess_shape(h, w, 1024)
+    ref = np.array(Image.fromarray(img).resize((tw, th), Image.BILINEAR))
+    d = torch.from_numpy(img).cuda()
+    u8, f32 = hip.pil_resize_bilinear_u8(d, (th, tw), pil_bilinear_tables_device(w, tw, "cuda:0"),
+                                         pil_bilinear_tables_device(h, th, "cuda:0"))
+    assert np.array_equal(u8.cpu().numpy(), ref)
+    assert np.array_equal(f32.cpu().numpy(), ref.transpose(2, 0, 1).astype(np.float32))
