@@ -2105,6 +2105,243 @@ extern "C" int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_
   return CSAM_OK;
 }
 
+// =====================================================================================================
+// csam_t2i_rank (round 2): the token->image attention of layers 1 / final in RANK-56 form.  csam_t2i_stream projects
+// every key: K^T = Wk X^T and V = X Wv^T are 64 of its 72 MFMAs per 32-key tile, and that kernel is issue-bound (VALU +
+// MFMA cycles add up on a SIMD).  With only 7 queries per prompt the projections fold into the
+// token side:
+//     scores[(h,j), t] = q_hj . (Wk_h (x_t + pe_t) + bk_h) = (Wk_h^T q_hj) . x_t  +  q_hj . (Wk_h pe_t)  (+ const per row)
+//     out[(h,j), :]    = sum_t p_t (Wv_h x_t + bv_h)       = Wv_h (sum_t p_t x_t) + bv_h
+// i.e. S^T = X Qp^T (+ kpe qblk^T) with Qp = the 56 (padded 64) back-projected queries of the prompt (csam_t2i_rank_prep),
+// and Y^T = X^T P^T, the probability-weighted sum of the RAW key rows; Wv and the out-projection are applied afterwards
+// by one ordinary GEMM over K = 8 heads x 256 (weights folded per model on the host).  Per tile and wave: 18 + 16 MFMAs
+// instead of 72, one softmax over 16 (head, query) rows on the lanes instead of two over 7-of-16 -- and no fp32->fp16
+// casts of K / V.  The row constant q.bk does not move a softmax and is dropped.  X^T fragments come from the row-major
+// LDS tile through ds_read_b64_tr_b16 (lane mapping: profiles/r02_ds_read_tr_probe.txt).
+// Wave w owns heads 2w, 2w+1: softmax rows r = 8*hh + j (j = 7 padding).  Queries arrive pre-multiplied by
+// 0.25 * log2(e), so the scores are already in base-2 units.
+// =====================================================================================================
+namespace {
+
+struct T2rArgs {
+  const half_t* X;        // [B, T, 256] key state
+  const half_t* Qp;       // [B, 64, 256] back-projected queries, row = 16*wave + 8*hh + j  (csam_t2i_rank_prep)
+  const half_t* qs;       // [B, 7, 128] scaled queries (for the key_pe term)
+  const half_t* kpe;      // [T, 128] fp16  pe Wk^T
+  half_t* Y;              // [B, 7, 8, 256] = softmax-weighted mean of the key rows per (query, head)
+  int B; int T;
+};
+
+typedef __fp16 fp16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4_t ds_tr_b64(const char* lds_ptr) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(lptr_t)lds_ptr);
+  return half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+}
+
+// Qp[b][16*w + 8*hh + j][c] = sum_d qs[b][j][(2w+hh)*16 + d] * Wk[(2w+hh)*16 + d][c]   (j = 7: zero row)
+__global__ __launch_bounds__(256) void t2i_rank_prep_kernel(const half_t* __restrict__ qs, const half_t* __restrict__ Wk,
+                                                            half_t* __restrict__ Qp) {
+  __shared__ float q[7 * 128];
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int i = c; i < 7 * 128; i += 256) q[i] = (float)qs[(long)b * 7 * 128 + i];
+  __syncthreads();
+  half_t* dst = Qp + (long)b * 64 * 256 + c;
+#pragma unroll 1
+  for (int head = 0; head < 8; ++head) {
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) w[d] = (float)Wk[(long)(head * 16 + d) * 256 + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.f;
+      if (j < 7) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc = fmaf(w[d], q[j * 128 + head * 16 + d], acc);
+      }
+      dst[(long)(head * 8 + j) * 256] = (half_t)acc;        // head*8 + j == 16*(head>>1) + 8*(head&1) + j
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void t2i_rank_kernel(T2rArgs p, int prompts_per_wg) {
+  constexpr int MI = T2S_MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
+  constexpr int PIECE = 256 * 16;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  const int tpp = p.T / T2S_TOK;
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, p.B);
+  if (b_first >= b_last) return;
+  const int first = b_first * tpp, last = b_last * tpp;
+
+  auto issue_x = [&](int t, int buf) {
+    const char* src = (const char*)(p.X + (long)t * T2S_TOK * 256);
+    const unsigned dst = lds0 + buf * T2S_BUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < T2S_NP; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
+  };
+  // key_pe fragments of the NEXT tile (A operand of the pe term): keys mi*16 + fr, dims wave*32 + fg*8 .. +7
+  floatx4 kpf[MI];
+  auto fetch_kpe = [&](int t) {
+    const int t0 = (t % tpp) * T2S_TOK;
+    const char* base = (const char*)(p.kpe + (long)t0 * 128);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) kpf[mi] = i2s_load16(base + mi * 16 * 128 * 2, (fr * 128 + wave * 32 + fg * 8) * 2);
+  };
+  // transposed-read byte offsets inside a key tile: 16-lane group fg supplies the k-slots of keys {4fg..4fg+3} and
+  // {16+4fg..16+4fg+3}; lane pl of the group points at row kb + (pl >> 2), dims (pl & 3)*4..+3 of a 16-dim block
+  const int pl = lane & 15;
+  unsigned troff[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const int row = kh * 16 + fg * 4 + (pl >> 2);
+    troff[kh] = row * 512 + (pl & 1) * 8;                 // + ((chunk ^ (row & 15)) << 4) per 16-dim block, chunk = 2n + ((pl&3)>>1)
+  }
+  const int trow[2] = {(fg * 4 + (pl >> 2)) & 15, (16 + fg * 4 + (pl >> 2)) & 15};
+  const int tsub = (pl & 3) >> 1;
+
+  half8_t qp[8];              // B operand of S^T = X Qp^T: softmax row 16*wave + fr, dims ks*32 + fg*8 .. +7
+  half8_t qblk;               // B operand of the pe term: dims of head 2*wave + (fg >> 1) for rows of that head, else 0
+  floatx4 y[16];              // Y^T accumulators: dims n*16 + fg*4 + e, softmax row fr
+  float m, l;
+  auto new_prompt = [&](int b) {
+    const half_t* src = p.Qp + ((long)b * 64 + wave * 16 + fr) * 256 + fg * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qp[ks] = *(const half8_t*)(src + ks * 32);
+    qblk = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    const int hh = fr >> 3, j = fr & 7;
+    if (j < 7 && (fg >> 1) == hh)
+      qblk = *(const half8_t*)(p.qs + ((long)b * 7 + j) * 128 + (wave * 2 + hh) * 16 + (fg & 1) * 8);
+    asm volatile("" : "+v"(qblk), "+v"(qp[0]), "+v"(qp[7]));   // tracked loads: the compiler's wait lands here, once per prompt
+#pragma unroll
+    for (int n = 0; n < 16; ++n) y[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    m = -INFINITY;
+    l = 0.f;
+  };
+
+  issue_x(first, 0);
+  fetch_kpe(first);
+  for (int t = first; t < last; ++t) {
+    const int cur = (t - first) & 1;
+    const char* xb = smem + cur * T2S_BUF;
+    const int tp = t % tpp;
+    if (tp == 0) new_prompt(t / tpp);
+    // tile t and its key_pe fragments have landed (issued a tile ago); everyone is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < last) issue_x(t + 1, cur ^ 1);
+
+    // ---- S^T[key][row] = sum_dim X[key][dim] Qp[row][dim]  +  kpe[key][.] . qs[row][.]
+    floatx4 sa[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      half8_t kp8;
+      __builtin_memcpy(&kp8, &kpf[mi], 16);
+      sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kp8, qblk, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    {
+      half8_t xf[2][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((fg ^ fr) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            xf[(ks + 1) & 1][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + 1) * 4 + fg) ^ fr) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks & 1][mi], qp[ks], sa[mi], 0, 0, 0);
+        asm volatile("" ::: "memory");
+      }
+    }
+    if (t + 1 < last) fetch_kpe(t + 1);            // next tile's key_pe fragments fly under the softmax
+
+    // ---- online softmax over this lane's 8 keys of softmax row fr (base-2 scores); P^T as the B operand of Y^T += X^T P^T
+    float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
+                     fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = csam_exp2(m - mnew);
+    m = mnew;
+    float ps = 0.f;
+    half8_t pb;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = csam_exp2(sa[mi][e] - mnew);
+        ps += pe;
+        pb[mi * 4 + e] = (half_t)pe;               // k-slot 4*mi + e of lane group fg <-> key 16*mi + 4*fg + e
+      }
+    l = l * alpha + ps;
+    if (__ballot(alpha != 1.f) != 0ull) {          // exact: alpha == 1 when no row max moved
+#pragma unroll
+      for (int n = 0; n < 16; ++n) y[n] *= alpha;
+    }
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      // X^T fragment: dims n*16 + fr, k-slots = the same 8 keys, by two transposed 4x16 block reads
+      const half4_t a0 = ds_tr_b64(xb + troff[0] + (((2 * n + tsub) ^ trow[0]) << 4));
+      const half4_t a1 = ds_tr_b64(xb + troff[1] + (((2 * n + tsub) ^ trow[1]) << 4));
+      const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
+    }
+
+    if (tp == tpp - 1) {                           // prompt complete: normalise and write Y[b][j][head][256] fp16
+      const int b = t / tpp;
+      float ls = l;
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv = 1.f / ls;
+      const int hh = fr >> 3, j = fr & 7;
+      if (j < 7) {
+        half_t* dst = p.Y + (((long)b * 7 + j) * 8 + wave * 2 + hh) * 256 + fg * 4;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          half4_t r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = (half_t)(y[n][e] * inv);
+          *(half4_t*)(dst + n * 16) = r;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16, const void* kpe_f16, const void* qs_f16,
+                             void* Qp_workspace, long workspace_bytes, void* Y_f16, int B, int T) {
+  CSAM_REQUIRE(X_f16 && Wk_f16 && kpe_f16 && qs_f16 && Qp_workspace && Y_f16, "csam_t2i_rank: null pointer");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % T2S_TOK == 0, "csam_t2i_rank: T must be a multiple of %d", T2S_TOK);
+  if (workspace_bytes < (long)B * 64 * 256 * 2) {
+    csam_set_error("csam_t2i_rank: workspace too small (%ld < %ld)", workspace_bytes, (long)B * 64 * 256 * 2);
+    return CSAM_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(t2i_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)qs_f16,
+                     (const half_t*)Wk_f16, (half_t*)Qp_workspace);
+  T2rArgs a;
+  a.X = (const half_t*)X_f16; a.Qp = (const half_t*)Qp_workspace; a.qs = (const half_t*)qs_f16;
+  a.kpe = (const half_t*)kpe_f16; a.Y = (half_t*)Y_f16; a.B = B; a.T = T;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int per = csam_cdiv(B, 2 * n_cu);           // whole prompts per workgroup, two workgroups per CU
+  hipLaunchKernelGGL(t2i_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
+  CSAM_LAUNCH_CHECK("csam_t2i_rank");
+  return CSAM_OK;
+}
+
 extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);
 
 extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * T2I_PARTS * 56 * T2I_NREC * sizeof(float); }

@@ -114,6 +114,7 @@ class DecoderPlan:
         self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
         self.up_stream = os.environ.get("CSAM_UP_STREAM", "1") != "0"     # persistent upscaler (B >= 256)
         self.i2t_rank = os.environ.get("CSAM_I2T_RANK", "1") != "0"       # rank-56 layer-0 image->token (B >= 256)
+        self.t2i_rank = os.environ.get("CSAM_T2I_RANK", "1") != "0"       # rank-56 token->image, layers 1 / final (B >= 256)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -161,6 +162,7 @@ class DecoderPlan:
             d["i2t_q_pe"] = pe_proj(i2t["q_w"])
             d["i2t_q_peb"] = (d["i2t_q_pe"] + d["i2t_q_b"]).contiguous()
             d["t2i_kpe"] = (pk + d["t2i_kv_b"][:128]).contiguous()        # pe Wk^T + bk, fp32 [4096,128]
+            d.update(self._t2i_rank_consts(t2i, pk))
             d["t2i_bv"] = d["t2i_kv_b"][128:].contiguous()
             d["t2i_v_bias_mat"] = d["t2i_bv"].view(128, 1).expand(128, T_IMG).contiguous()
             d["i2t_o_w_perm"] = f16(i2t["o_w"][:, _kperm(128)])
@@ -176,6 +178,7 @@ class DecoderPlan:
                           kpe=(pk + f32(fa["k_b"])).contiguous(), bv=f32(fa["v_b"]),
                           o_w=f16(fa["o_w"]), o_b=f32(fa["o_b"]),
                           norm_g=f32(sd[T + "norm_final_attn.weight"]), norm_b=f32(sd[T + "norm_final_attn.bias"]))
+        self.final.update({k[4:]: v for k, v in self._t2i_rank_consts(fa, pk).items()})
         # upscaler: ConvTranspose2d(k=2,s=2) as GEMMs; weight [ci, co, di, dj] -> rows n = (di*2+dj)*co_n + co
         w1 = sd[M + "output_upscaling.0.weight"]          # [256, 64, 2, 2]
         self.up1_w = f16(w1.permute(2, 3, 1, 0).reshape(256, 256))
@@ -214,6 +217,22 @@ class DecoderPlan:
         self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
 
+    def _t2i_rank_consts(self, att, pk):
+        """Per-model operands of csam_t2i_rank for one token->image attention (transformer.py:228-254 with 7 queries):
+        q projection pre-multiplied by softmax scale x log2(e); Wk alone (keys are never projected: the queries are
+        projected back through it per prompt); pe Wk^T in fp16 (the per-row constant q.bk does not move a softmax);
+        Wc[:, h*256:(h+1)*256] = Wo[:, h] Wv[h] and the bias Wo bv + bo, so that ONE GEMM over K = 8 x 256 turns the
+        softmax-weighted key sums into the attention output."""
+        dev = self.device
+        f16 = lambda t: t.detach().to(device=dev, dtype=torch.float16).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        sc = 0.25 * 1.4426950408889634
+        wo, wv = att["o_w"].float(), att["v_w"].float()                 # [256,128], [128,256]
+        wc = torch.einsum("ohd,hdk->ohk", wo.view(256, 8, 16), wv.view(8, 16, 256)).reshape(256, 2048)
+        return dict(t2i_q_w_s=f16(att["q_w"].float() * sc), t2i_q_b_s=f32(att["q_b"].float() * sc), t2i_k_w=f16(att["k_w"]),
+                    t2i_kpe16=pk.detach().to(device=dev, dtype=torch.float16).contiguous(), t2i_wc=f16(wc),
+                    t2i_bc=f32(att["o_b"].float() + wo @ att["v_b"].float()))
+
     # ------------------------------------------------------------------------------------------
     def _alloc(self, B):
         dev = self.device
@@ -225,6 +244,8 @@ class DecoderPlan:
             coords=e(B, 2, dt=f), tokens0=e(B * 7, 256, dt=f), queries=e(B * 7, 256, dt=f), tmp32=e(B * 7, 256, dt=f),
             q16=e(B * 7, 256), qpe16=e(B * 7, 256), sa_qk=e(B * 7, 512), sa_v=e(B * 7, 256), sa_o=e(B * 7, 256),
             t2i_q=e(B * 7, 128), t2i_o=e(B * 7, 128), mlp_h=e(B * 7, 2048),
+            # rank-56 token->image: back-projected queries [B,64,256] and weighted key sums [B*7, 8*256] (from 256 prompts)
+            t2i_qp=e((B if B >= 256 else 1) * 64, 256), t2i_y=e((B if B >= 256 else 1) * 7, 2048),
             i2t_kv=e(B * 7, 256), i2t_k=e(B * 7, 128), i2t_v=e(B * 7, 128),
             keysA=e(BT, 256), keysB=e(BT, 256), masks=e(B, 4, 256, 256, dt=f),
             # materialised K|V, Q, attention output and up-scaled feature maps: the unfused (round-1 baseline) path only
@@ -328,6 +349,14 @@ class DecoderPlan:
             hip.add_cast(queries, tokens0, 256, out16=qpe16)
 
         def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None):
+            if fused_args is not None and "rank" in fused_args and self.t2i_rank and self.t2i_stream and B >= 256:
+                # rank-56 form (csam_t2i_rank): no per-key K / V projections; Wv and the out-projection in one GEMM
+                R = fused_args["rank"]
+                hip.gemm_f16(qpe16, R["q_w_s"], out=ws["t2i_q"][:M7], bias=R["q_b_s"])
+                hip.t2i_rank(fused_args["X"], R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_qp"], ws["t2i_y"], B, T_IMG)
+                hip.gemm_f16(ws["t2i_y"][:M7], R["wc"], out=ws["tmp32"][:M7], bias=R["bc"], residual=queries)
+                hip.layernorm(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, out=queries)
+                return
             hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
             if fused_args is not None and "K0" in fused_args:
                 hip.t2i_shared(ws["t2i_q"], st["k0h"], st["v0h"], ws["t2i_o"], B)
@@ -336,7 +365,7 @@ class DecoderPlan:
                 hip.t2i_stream(ws["t2i_q"], ws["t2i_o"], B, fused_args["X"], fused_args["Wkv"], fused_args["kpe"],
                                fused_args["bv"], T_IMG)
             elif fused_args is not None:
-                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **fused_args)
+                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **{k: v for k, v in fused_args.items() if k != "rank"})
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
             hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
@@ -362,7 +391,9 @@ class DecoderPlan:
                     dict(K0=st["k0"], V0T=st["v0t"]) if self.fused else None)
             elif self.fused:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], None, 0, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
-                    dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]))
+                    dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"],
+                         rank=dict(q_w_s=L["t2i_q_w_s"], q_b_s=L["t2i_q_b_s"], k_w=L["t2i_k_w"], kpe16=L["t2i_kpe16"],
+                                   wc=L["t2i_wc"], bc=L["t2i_bc"])))
             else:
                 hip.gemm_f16_resmod(keys_in, L["t2i_kv_w"], ws["kv"][:BT], L["t2i_kv_b"], L["t2i_kv_pe"], T_IMG, M=BT)
                 t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
@@ -412,7 +443,8 @@ class DecoderPlan:
         cast_queries()
         if self.fused:
             t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
-                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"]))
+                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"],
+                     rank=dict(q_w_s=F["q_w_s"], q_b_s=F["q_b_s"], k_w=F["k_w"], kpe16=F["kpe16"], wc=F["wc"], bc=F["bc"])))
         else:
             hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
             t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])

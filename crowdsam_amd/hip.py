@@ -63,6 +63,7 @@ SIGNATURES = {
     "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_i2t_rank": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _L],
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "csam_t2i_rank": [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
@@ -696,6 +697,13 @@ def t2i_stream(q, out, B, X, Wkv, kpe, bv, T=4096):
     """Persistent weight-stationary token->image attention (K/V projections fused, online softmax, no partials)."""
     call("csam_t2i_stream", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(q), _ptr(out), B, T)
     return out
+
+
+def t2i_rank(X, Wk, kpe16, q_scaled, Qp_ws, Y, B, T=4096):
+    """Rank-56 token->image attention: X f16 [B*T,256]; Wk f16 [128,256]; kpe16 f16 [T,128] = pe Wk^T; q_scaled f16 [B*7,128]
+    (already x 0.25 log2 e); Qp_ws f16 >= [B*64,256] scratch; Y f16 [B*7, 8*256] <- softmax-weighted key sums per (query, head)."""
+    call("csam_t2i_rank", _stream(), _ptr(X), _ptr(Wk), _ptr(kpe16), _ptr(q_scaled), _ptr(Qp_ws), Qp_ws.numel() * 2, _ptr(Y), B, T)
+    return Y
 
 
 def head_gather(qkv, qkv_bias, Qs, K, VT, D, nH, hd, Tp, T_valid, window, scale):

@@ -172,6 +172,13 @@ int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_stride, const 
 /* token->image attention with the K/V projections fused in (csam_t2i_fused with keys + weights) as a persistent,
  * weight-stationary flash pass: 4-wave workgroups walk whole prompts, Wk/Wv slices in registers, 32-key tiles LDS-DMA'd a
  * tile ahead, online softmax, out [B,7,128] written once per prompt (no workspace, no merge). transformer.py:173-177,105-112 */
+/* The same attention in rank-56 form (7 queries per prompt: transformer.py:173-177,105-112 with the K / V projections folded
+ * into the token side): scores = X (Wk^T q) + (pe Wk^T) q, output = softmax-weighted sums of the RAW key rows, Y f16
+ * [B,7,8 heads,256]; Wv and out_proj follow as one GEMM over K = 8 x 256 (weights folded by the caller).  q_scaled f16
+ * [B,7,128] = (queries + pe) Wq^T + bq, pre-multiplied by 0.25 log2(e); Wk f16 [128,256]; kpe f16 [T,128];
+ * Qp_workspace >= B*64*256*2 bytes (back-projected queries, built by the prologue kernel). */
+int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16, const void* kpe_f16, const void* q_scaled_f16,
+                  void* Qp_workspace, long workspace_bytes, void* Y_f16, int B, int T);
 int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
                     const void* q_f16, void* out_f16, int B, int T);
 /* same half-block as a persistent, weight-stationary stream (one 8-wave workgroup per CU walks 128-token tiles; the
