@@ -4,17 +4,19 @@
 // the decomposed relative-position bias (:325-361), and (b) every DINOv2 ViT-L/14 block (external
 // dependency; plain softmax(q k^T / sqrt(d)) v over 1 + 73*73 tokens).
 //
-// Workgroup = 4 waves x 32 queries = 128 queries of one head; key tiles of 64 are staged into
-// double-buffered LDS (K row-major, V transposed) through registers (issue-early / write-late),
-// one barrier per tile.  Swapped MFMA orientation: keys on the accumulator rows, so each lane owns
-// ONE query column -> online-softmax max/sum are in-lane + two shuffles, and the fp16 P registers
-// feed P.V directly as the B operand.
+// Workgroup = 4 waves x 32 queries = 128 queries of one head; key tiles of 64 go into a 3-deep LDS ring
+// (K row-major, V transposed) by global_load_lds, one barrier per tile.  Swapped MFMA orientation: keys on the
+// accumulator rows, so each lane owns ONE query column -> softmax state is in-lane, and the fp16 P registers feed
+// P.V directly as the B operand.
+//
+// Scores are in base-2 units from the start (q carries scale * log2(e), folded into the qkv projection by the
+// plans) and relative to a per-query reference exponent that rides in the MFMA accumulator's initial value, so a
+// score costs one v_exp_f32 and half a v_cvt_pk: no running maximum (see the loop comment).
 //
 // Rel-pos bias, SAM global blocks (64x64 grid, key tile t == key row kh = t, kw = key & 63):
-//     S[q, (kh,kw)] = scale * (q.k + Th[q,kh]/scale + Tw[q,kw]/scale)
-// The MFMA accumulator is INITIALISED with Tw[q, kw]/scale (16 registers per query tile, constant
-// over all key tiles) + Th[q, t]/scale (one scalar per lane per tile): the bias costs one v_add per
-// accumulator register and zero extra MFMA/LDS work.  Tables come from csam_relpos_tables.
+//     S2[q, (kh,kw)] = q2.k + log2(e) * (Th[q,kh] + Tw[q,kw])
+// The accumulator is INITIALISED with Tw (16 registers per query tile, constant over all key tiles) + Th[q, t] (one
+// scalar per lane per tile) - reference: one v_add per accumulator register, zero extra MFMA/LDS work.
 #include "csam_common.h"
 
 namespace {
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
                                                          const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ traw,
                                                          half_t* __restrict__ out, long ldo, int T,
-                                                         float scale) {
+                                                         float qmul, float bmul) {
+  // Scores live in BASE-2 units from the start: the caller's q already carries scale * log2(e) (folded into the qkv
+  // projection, qmul == 1) or is multiplied by qmul here; the bias tables are multiplied by bmul.
   // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
   // batched GEMM;  Th[q][kh] = traw[q][qh - kh + 63],  Tw[q][kw] = traw[q][128 + qw - kw + 63]
   // LDS: 3-deep ring x (K tile [64 keys][128 B] + V^T tile [64 dims][128 B]) = 48 KB, filled by global_load_lds;
@@ -97,7 +101,13 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
     qrow[rt] = q0 + rt * 16 + fr;
     const int qc = qrow[rt] < T ? qrow[rt] : T - 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[rt][ks] = *(const half8_t*)(qp + (long)qc * ld + (ks * 4 + fg) * 8);
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[rt][ks] = *(const half8_t*)(qp + (long)qc * ld + (ks * 4 + fg) * 8);
+      if (qmul != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[rt][ks][e] = (half_t)((float)qf[rt][ks][e] * qmul);
+      }
+    }
   }
   // Key permutation inside a 32-key step s: accumulator row (4g + r) of key tile kt holds key
   // 32s + 8g + r + 4*(kt&1), so that a lane's 8 P values of a step are 8 CONSECUTIVE keys and the V^T
@@ -105,7 +115,6 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
   const int krow_in_step = 8 * (fr >> 2) + (fr & 3);
   floatx4 twr[2][4];
   const float* thp[2] = {nullptr, nullptr};
-  const float inv_scale = 1.0f / scale;
   if constexpr (BIAS) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -117,17 +126,17 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
       for (int kt = 0; kt < 4; ++kt) {
         const int kw0 = (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) twr[rt][kt][j] = twq[-(kw0 + j)] * inv_scale;
+        for (int j = 0; j < 4; ++j) twr[rt][kt][j] = twq[-(kw0 + j)] * bmul;
       }
     }
   }
   floatx4 o[2][4];
-  float m[2];
+  float mref[2];              // softmax reference exponent of the query (base-2 units): P = 2^(s - mref)
   floatx4 l[2];
   const half8_t ones8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    m[rt] = -INFINITY;
+    mref[rt] = 0.f;
     l[rt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[rt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -146,10 +155,14 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
       glds16(vtp + (long)row * Tpad + t * KT + ((sl ^ (row & 7)) * 8), smem + buf * 16384 + 8192 + (c & ~63) * 16);
     }
   };
+  float thn[2] = {0.f, 0.f};          // Th[q][t] of the coming tile (raw table units)
+  if constexpr (BIAS) {
+    thn[0] = thp[0][0];
+    thn[1] = thp[1][0];
+  }
   stage(0, 0);
   if (FLASH_NS == 3 && nt > 1) stage(1, 1);
 
-  const float sl2 = scale * 1.4426950408889634f;
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     // vmcnt(0): with the 3-slot ring this retires tile t+1 one iteration before it is read (a counted wait
@@ -169,87 +182,126 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
     floatx4 s[2][4];
     float thv[2] = {0.f, 0.f};
     if constexpr (BIAS) {
-      thv[0] = thp[0][-t] * inv_scale;
-      thv[1] = thp[1][-t] * inv_scale;
+      // fetched an iteration ahead, i.e. BEFORE this iteration's tile loads in program order: the counted wait the
+      // compiler puts in front of the first use then leaves the just-issued tile loads in flight
+      thv[0] = thn[0] * bmul;
+      thv[1] = thn[1] * bmul;
+      if (t + 1 < nt) {
+        thn[0] = thp[0][-(t + 1)];
+        thn[1] = thp[1][-(t + 1)];
+      }
     }
+    // S^T - mref = K Q^T with the accumulator INITIALISED to (bias - mref): the reference exponent costs no VALU op
+    auto scores = [&]() {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt) {
+        const float c0 = thv[rt] - mref[rt];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        if constexpr (BIAS) {
-          s[rt][kt] = twr[rt][kt] + thv[rt];
-        } else {
-          s[rt][kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 4; ++kt) {
+          if constexpr (BIAS) {
+            s[rt][kt] = twr[rt][kt] + c0;
+          } else {
+            s[rt][kt] = floatx4{c0, c0, c0, c0};
+          }
         }
       }
+      if constexpr (BIAS) {
+        // All eight initial quads exist, in registers of their own, BEFORE the first MFMA issues.  Left to the
+        // scheduler, hipcc (ROCm 7.2) computes them between the MFMAs and recycles a quad for the next initial value
+        // right after the MFMA that reads it as SrcC; the first-tile code built that way produced scores with one bias
+        // term missing in lanes 48..63 of one register (run-to-run varying rows; DESIGN.md section 4.1,
+        // tests/test_encoder_gpu.py::test_flash_attn_constant_bias_is_a_no_op).
+        asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]),
+                          "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]));
+      }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const int krow = (kt >> 1) * 32 + krow_in_step + 4 * (kt & 1);
-        const half8_t kf = *(const half8_t*)(Kc + krow * 128 + (((ks * 4 + fg) ^ kswz(krow)) << 4));
+        for (int kt = 0; kt < 4; ++kt) {
+          const int krow = (kt >> 1) * 32 + krow_in_step + 4 * (kt & 1);
+          const half8_t kf = *(const half8_t*)(Kc + krow * 128 + (((ks * 4 + fg) ^ kswz(krow)) << 4));
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            s[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][ks], s[rt][kt], 0, 0, 0);
+        }
+      }
+      // lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr; out-of-range keys only on the last tile
+      if ((t + 1) * KT > T) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
-          s[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][ks], s[rt][kt], 0, 0, 0);
-      }
-    }
-    // ---- online softmax (base 2); lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr.
-    // VALU-bound part of the kernel (PMC: VALU 72 % busy, MFMA 14 %), so it is kept to max3 / fma / exp / add per
-    // score: the softmax scale lives in the exponent's fma (the running max is tracked on the raw scores, scale > 0),
-    // out-of-range keys are masked on the last tile only, and O is rescaled only when some row's max moved.
-    if ((t + 1) * KT > T) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) s[rt][kt][j] = -INFINITY;
+      }
+    };
+    // P = 2^(s - mref) in fp16 (the B operand of both P.V and the row sums) and this tile's row sums on the matrix
+    // pipe: lt^T = 1 . P^T, every lane of a query receives the sum of the fp16 probabilities the PV product uses
+    half8_t pf[2][2];
+    floatx4 lt[2];
+    auto probs = [&]() {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) s[rt][kt][j] = -INFINITY;
-    }
-    half8_t pf[2][2];
-    float alpha[2];
+          for (int j = 0; j < 4; ++j) s[rt][kt][j] = csam_exp2(s[rt][kt][j]);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      float mx = fmaxf(fmaxf(s[rt][0][0], s[rt][0][1]), s[rt][0][2]);
-      mx = fmaxf(fmaxf(mx, s[rt][0][3]), s[rt][1][0]);
-      mx = fmaxf(fmaxf(mx, s[rt][1][1]), s[rt][1][2]);
-      mx = fmaxf(fmaxf(mx, s[rt][1][3]), s[rt][2][0]);
-      mx = fmaxf(fmaxf(mx, s[rt][2][1]), s[rt][2][2]);
-      mx = fmaxf(fmaxf(mx, s[rt][2][3]), s[rt][3][0]);
-      mx = fmaxf(fmaxf(mx, s[rt][3][1]), s[rt][3][2]);
-      mx = fmaxf(mx, s[rt][3][3]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(m[rt], mx);          // raw-score units
-      alpha[rt] = csam_exp2((m[rt] - mnew) * sl2);
-      m[rt] = mnew;
-      const float nm = -mnew * sl2;
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[rt][kt][j] = csam_exp2(fmaf(s[rt][kt][j], sl2, nm));
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pf[rt][st][e] = (half_t)s[rt][2 * st][e];
-          pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
-        }
-    }
-    if (__ballot(alpha[0] != 1.f || alpha[1] != 1.f) != 0ull) {     // exact: alpha == 1 when no max moved
+          for (int e = 0; e < 4; ++e) {
+            pf[rt][st][e] = (half_t)s[rt][2 * st][e];
+            pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
+          }
+      }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        l[rt] *= alpha[rt];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= alpha[rt];
+        lt[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        lt[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][1], lt[rt], 0, 0, 0);
       }
+    };
+    // ---- softmax.  The loop is issue-bound (VALU and MFMA times of a SIMD add up), so the per-score work is ONE
+    // v_exp_f32 and half a v_cvt_pk: no running maximum is tracked.  mref is set from the first tile's maximum and
+    // stays until some probability of the wave leaves fp16's range (> 65504, i.e. a row maximum 16 octaves above its
+    // reference), which shows as a non-finite row sum; only then (and on tile 0) the classic online-softmax update
+    // runs: scores recomputed, row maximum, mref += delta, O and l rescaled by 2^-delta.  Exact up to rounding: the
+    // softmax is shift-invariant, and a reference BELOW the true maximum only adds headroom at the small end.
+    scores();
+    bool renorm = t == 0;
+    if (!renorm) {
+      probs();
+      renorm = __ballot(!(lt[0][0] < 1e30f) || !(lt[1][0] < 1e30f)) != 0ull;
+      if (renorm) scores();                       // rare: s was consumed by the exponentials
     }
-    // row sums on the matrix pipe (the loop is VALU-bound): l^T += 1 . P^T, every lane of a query receives the sum of
-    // the fp16 probabilities the PV product uses
+    if (renorm) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+      for (int rt = 0; rt < 2; ++rt) {
+        float mx = fmaxf(fmaxf(s[rt][0][0], s[rt][0][1]), s[rt][0][2]);
+        mx = fmaxf(fmaxf(mx, s[rt][0][3]), s[rt][1][0]);
+        mx = fmaxf(fmaxf(mx, s[rt][1][1]), s[rt][1][2]);
+        mx = fmaxf(fmaxf(mx, s[rt][1][3]), s[rt][2][0]);
+        mx = fmaxf(fmaxf(mx, s[rt][2][1]), s[rt][2][2]);
+        mx = fmaxf(fmaxf(mx, s[rt][2][3]), s[rt][3][0]);
+        mx = fmaxf(fmaxf(mx, s[rt][3][1]), s[rt][3][2]);
+        mx = fmaxf(mx, s[rt][3][3]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = t == 0 ? mx : fmaxf(mx, 0.f);      // s is relative to the old reference
+        mref[rt] += delta;
+        if (t > 0) {
+          const float a = csam_exp2(-delta);
+          l[rt] *= a;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) l[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][st], l[rt], 0, 0, 0);
+          for (int dt = 0; dt < 4; ++dt) o[rt][dt] *= a;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[rt][kt] -= delta;
+      }
+      probs();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) l[rt] += lt[rt];
     // ---- O^T += V^T P^T: V^T fragment = dims row dt*16+fr, keys 32 st + 8 fg .. +7 (one 16-B read)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -288,7 +340,7 @@ extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
 
 extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
                                const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
-                               void* vt_workspace, long vt_workspace_bytes) {
+                               void* vt_workspace, long vt_workspace_bytes, int q_prescaled) {
   CSAM_REQUIRE(qkv_f16 && out_f16 && vt_workspace && T > 0 && nH > 0, "csam_flash_attn: bad args");
   if (vt_workspace_bytes < csam_flash_attn_workspace_bytes(T, nH)) {
     csam_set_error("csam_flash_attn: V^T workspace too small (must also be zero-initialised once)");
@@ -301,12 +353,17 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)qkv_f16, ld, v_off, (half_t*)vt_workspace, T, Tpad);
   dim3 grid(csam_cdiv(T, QPB), nH), block(256);
+  // q_prescaled: the caller folded scale * log2(e) into the q rows of the qkv projection (and relpos_raw was
+  // computed from that q, so the bias tables carry the same factor and only 1/scale brings them to base-2 units)
+  const float log2e = 1.4426950408889634f;
+  const float qmul = q_prescaled ? 1.f : scale * log2e;
+  const float bmul = q_prescaled ? 1.f / scale : log2e;
   if (relpos_raw)
     hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul);
   else
     hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
   return CSAM_OK;
 }

@@ -48,11 +48,15 @@ class DinoPlan:
         self.pos = f32(pos)
         self.cls_row = f32(sd["cls_token"].reshape(1, D).float().cpu() + pos[:1])
         self.blocks = []
+        # softmax scale and the base-2 conversion live in the q rows of the qkv projection (csam_flash_attn q_prescaled)
+        qfold = torch.ones(3 * D, 1)
+        qfold[:D] = (64 ** -0.5) * hip.FLASH_QMUL
         for i in range(depth):
             B = f"blocks.{i}."
             self.blocks.append(dict(
                 ln1_g=f32(sd[B + "norm1.weight"]), ln1_b=f32(sd[B + "norm1.bias"]),
-                qkv_w=f16(sd[B + "attn.qkv.weight"]), qkv_b=f32(sd[B + "attn.qkv.bias"]),
+                qkv_w=f16(sd[B + "attn.qkv.weight"].detach().float().cpu() * qfold),
+                qkv_b=f32(sd[B + "attn.qkv.bias"].detach().float().cpu() * qfold[:, 0]),
                 proj_w=f16(sd[B + "attn.proj.weight"]), proj_b=f32(sd[B + "attn.proj.bias"]),
                 ls1=f32(sd[B + "ls1.gamma"]),
                 ln2_g=f32(sd[B + "norm2.weight"]), ln2_b=f32(sd[B + "norm2.bias"]),
@@ -85,7 +89,7 @@ class DinoPlan:
         for b in self.blocks:
             hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"], M=T)
             hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"], M=T)
-            hip.flash_attn(ws["qkv"], ws["attn"], T, nH, scale, D)
+            hip.flash_attn(ws["qkv"], ws["attn"], T, nH, scale, D, q_prescaled=True)
             hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T)
             hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"], M=T)
             hip.gemm_f16(ws["h"], b["fc1_w"], out=ws["mlp"], bias=b["fc1_b"], act=hip.ACT_GELU, M=T)

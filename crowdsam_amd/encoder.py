@@ -33,9 +33,16 @@ class EncoderPlan:
         self.blocks = []
         for i in range(depth):
             B = f"{P}blocks.{i}."
+            qkv_w, qkv_b = sd[B + "attn.qkv.weight"].detach().float().cpu(), sd[B + "attn.qkv.bias"].detach().float().cpu()
+            if self.fused_attn and i in self.global_idx:
+                # global blocks run csam_flash_attn with q_prescaled: softmax scale and the base-2 conversion live in
+                # the q rows of the projection (the rel-pos tables, computed from that q, are rescaled in the kernel)
+                qkv_w, qkv_b = qkv_w.clone(), qkv_b.clone()
+                qkv_w[:D] *= (hd ** -0.5) * hip.FLASH_QMUL
+                qkv_b[:D] *= (hd ** -0.5) * hip.FLASH_QMUL
             self.blocks.append(dict(
                 ln1_g=f32(sd[B + "norm1.weight"]), ln1_b=f32(sd[B + "norm1.bias"]),
-                qkv_w=f16(sd[B + "attn.qkv.weight"]), qkv_b=f32(sd[B + "attn.qkv.bias"]),
+                qkv_w=f16(qkv_w), qkv_b=f32(qkv_b),
                 rel_h=f32(sd[B + "attn.rel_pos_h"]), rel_w=f32(sd[B + "attn.rel_pos_w"]),
                 proj_w=f16(sd[B + "attn.proj.weight"]), proj_b=f32(sd[B + "attn.proj.bias"]),
                 ln2_g=f32(sd[B + "norm2.weight"]), ln2_b=f32(sd[B + "norm2.bias"]),
@@ -95,7 +102,7 @@ class EncoderPlan:
                 self._attn_generic(b)
             elif b["is_global"]:
                 hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)
-                hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"])
+                hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"], q_prescaled=True)
             else:
                 hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
             hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)

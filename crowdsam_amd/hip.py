@@ -29,7 +29,7 @@ SIGNATURES = {
     "csam_im2col3x3": [_P, _P, _P, _I],
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
     "csam_win_attn": [_P, _P, _P, _P, _P, _I, _I, _F],
-    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L],
+    "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L, _I],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
     "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
@@ -338,12 +338,16 @@ def flash_vt_workspace(T, nH, device):
     return _vt_ws[key]
 
 
-def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None):
-    """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]; relpos = relpos_raw(...) or None."""
+FLASH_QMUL = 1.4426950408889634     # x scale: what a plan folds into the q rows of its qkv projection (q_prescaled)
+
+
+def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None, q_prescaled=False):
+    """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]; relpos = relpos_raw(...) or None.
+    q_prescaled: the q columns (and relpos) already carry scale * log2(e)."""
     if vt is None:
         vt = flash_vt_workspace(T, nH, qkv.device)
     call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out),
-         out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2)
+         out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2, int(bool(q_prescaled)))
     return out
 
 

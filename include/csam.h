@@ -123,11 +123,13 @@ int csam_head_scatter(void* stream, const void* O_f16, void* out_f16, int D, int
                       int window);
 /* flash-style global attention, head_dim 64: every DINOv2 block (relpos_raw == NULL, ragged T) and SAM's
  * global blocks: relpos_raw fp32 [nH][4096][256] = q . [rel_pos_h(127) | 0 | rel_pos_w(127) | 0]^T, produced by
- * one csam_gemm_f16_batched over the heads (image_encoder.py:349-350). */
+ * one csam_gemm_f16_batched over the heads (image_encoder.py:349-350).
+ * q_prescaled != 0: the q columns of qkv_f16 (and therefore relpos_raw) already carry scale * log2(e), folded into the
+ * qkv projection's weights by the caller -- the scores then need no per-element scaling; 0: plain q, scaled in-kernel. */
 long csam_flash_attn_workspace_bytes(int T, int nH); /* per-head V^T scratch; zero-initialise it once */
 int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
                     const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
-                    long vt_workspace_bytes);
+                    long vt_workspace_bytes, int q_prescaled);
 
 /* ---- prompt encoder + two-way decoder (all prompts of a batch at once) */
 /* prompt_encoder.py:75-93,189-218 + mask_decoder.py:153-155: tokens f32 [B,7,256] =

@@ -88,6 +88,72 @@ def test_flash_attn(cuda, T, bias):
     assert err < 6e-3, err
 
 
+@pytest.mark.parametrize("T,bias", [(4096, True), (5330, False), (333, False)])
+def test_flash_attn_renormalisation_and_prescaled_q(cuda, T, bias):
+    """The kernel tracks no running maximum: its softmax reference moves only when a probability leaves fp16's range.
+    Keys whose scores climb by ~60 octaves along the sequence (and drop again) force that path several times per query;
+    q carries scale * log2(e) as the plans fold it into the projection (q_prescaled)."""
+    from crowdsam_amd import hip
+    nH, D = 2, 128
+    g = torch.Generator().manual_seed(7 * T)
+    u = torch.randn(1, nH, 64, generator=g)
+    ramp = torch.linspace(0.0, 1.0, T).view(T, 1, 1)
+    ramp = torch.where(ramp < 0.7, ramp / 0.7, (1.0 - ramp) / 0.3) * 5.0          # 0 -> 5 -> 0
+    q = u + 0.3 * torch.randn(T, nH, 64, generator=g)
+    k = u * ramp + 0.3 * torch.randn(T, nH, 64, generator=g)
+    v = torch.randn(T, nH, 64, generator=g)
+    qkv32 = torch.cat([q.reshape(T, D), k.reshape(T, D), v.reshape(T, D)], 1)
+    qkv = qkv32.to(cuda).half()
+    qkv_pre = qkv32.clone()
+    qkv_pre[:, :D] *= 0.125 * hip.FLASH_QMUL
+    qkv_pre = qkv_pre.to(cuda).half()
+    qf = qkv[:, :D].float().view(T, nH, 64).transpose(0, 1)
+    kf = qkv[:, D:2 * D].float().view(T, nH, 64).transpose(0, 1)
+    vf = qkv[:, 2 * D:].float().view(T, nH, 64).transpose(0, 1)
+    s = (qf * 0.125) @ kf.transpose(-1, -2)
+    assert (s.max(-1)[0] - s[..., :64].max(-1)[0]).min().item() > 16 * 0.6931 * 2   # > 32 octaves above tile 0, every query
+    out, out_pre = (torch.zeros(T, D, device=cuda, dtype=torch.float16) for _ in range(2))
+    if bias:
+        rel_h = (torch.randn(127, 64, generator=g) * 0.25).to(cuda)
+        rel_w = (torch.randn(127, 64, generator=g) * 0.25).to(cuda)
+        traw, traw_pre = torch.empty(nH, 4096, 256, device=cuda), torch.empty(nH, 4096, 256, device=cuda)
+        rc = hip.relcat_global(rel_h, rel_w)
+        hip.relpos_raw(qkv, rc, traw, nH)
+        hip.relpos_raw(qkv_pre, rc, traw_pre, nH)
+        hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=traw)
+        hip.flash_attn(qkv_pre, out_pre, T, nH, 0.125, D, relpos=traw_pre, q_prescaled=True)
+        s = s + _rel_bias(qf, rel_h.half().float(), rel_w.half().float(), 64)
+    else:
+        hip.flash_attn(qkv, out, T, nH, 0.125, D)
+        hip.flash_attn(qkv_pre, out_pre, T, nH, 0.125, D, q_prescaled=True)
+    ref = (s.softmax(-1) @ vf).transpose(0, 1).reshape(T, D)
+    # scores of ~40 nats: an fp16 rounding of q (2^-11 relative) moves a score by ~0.02 and a probability by ~2 %
+    for o in (out, out_pre):
+        assert torch.isfinite(o).all()
+        err = (o.float() - ref).abs()
+        assert err.max().item() < 8e-2 and err.mean().item() < 6e-3, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("c", [-3.0, 2.0])
+def test_flash_attn_constant_bias_is_a_no_op(cuda, c):
+    """A constant rel-pos table shifts every score of a query by the same amount: the output must not move.  Catches an
+    accumulator-initialisation slip in a single register / lane group (one key in 64 weighted e^c times too much), which
+    a random-bias comparison with fp16 tolerances can miss."""
+    from crowdsam_amd import hip
+    T, nH, D = 4096, 2, 128
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(T, 3 * D, generator=g).to(cuda).half()
+    outs = []
+    for val in (0.0, c):
+        traw = torch.full((nH, T, 256), val, device=cuda)
+        out = torch.zeros(T, D, device=cuda, dtype=torch.float16)
+        for _ in range(3):                                  # the slip moved between launches
+            hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=traw)
+            outs.append(out.float().clone())
+    for o in outs[1:]:
+        assert (o - outs[0]).abs().max().item() < 2e-3, (o - outs[0]).abs().max().item()
+
+
 def test_encoder_vs_reference_golden(cuda):
     """Narrow encoder with the real token geometry vs the reference's own output (fp16 tolerance)."""
     from crowdsam_amd import synth

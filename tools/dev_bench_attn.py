@@ -9,11 +9,11 @@ def bench(T, nH, bias=False, iters=20):
     rp = None
     if bias:
         rp = torch.randn(nH, T, 256, device="cuda")
-    for _ in range(3): hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=rp)
+    for _ in range(3): hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=rp, q_prescaled=True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=rp)
+    for _ in range(iters): hip.flash_attn(qkv, out, T, nH, 0.125, D, relpos=rp, q_prescaled=True)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"flash T={T} nH={nH} bias={bias}: {ms*1e3:.1f} us  {4*T*T*64*nH/ms/1e9:.1f} TFLOP/s")
