@@ -85,6 +85,9 @@ class CrowdSAM:
         self.stability_score_offset = t["stability_score_offset"]
         self.box_nms_thresh = t["box_nms_thresh"]
         self.points_per_batch = t["points_per_batch"]
+        # Efficient Prompt Sampler state on the device (no host round trip per batch); CSAM_EPS_DEVICE=0 keeps the point
+        # list on the host and synchronises after every batch, as the reference does
+        self.eps_on_device = os.environ.get("CSAM_EPS_DEVICE", "1") != "0"
         self.crop_n_layers = t["crop_n_layers"]
         self.crop_nms_thresh = t["crop_nms_thresh"]
         self.crop_overlap_ratio = t["crop_overlap_ratio"]
@@ -179,7 +182,7 @@ class CrowdSAM:
         return data
 
     # ------------------------------------------------------------------------------------------
-    def sample_prompts(self):
+    def sample_prompts(self, on_device=False):
         """FG prior -> grid -> threshold -> pixel coordinates (crowdsam/model.py:196-223)."""
         h, w = self.image_hw
         g = self.grid_size
@@ -190,9 +193,18 @@ class CrowdSAM:
         sim = hip.sigmoid_max(sim.view(sim.shape[0], g * g)).view(g, g)
         self.sim_map = sim
         self.sim_feat_size = (int(feat_size[0]), int(feat_size[1]))
-        sim_c = sim[: int(feat_size[0]), : int(feat_size[1])].cpu()      # one small D2H
-        coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
+        sim_c = sim[: int(feat_size[0]), : int(feat_size[1])]
         inv_factor = torch.tensor([feat_size[1] / w, feat_size[0] / h])
+        if on_device:
+            # same arithmetic where the map already is: nonzero() in row-major order, fp32 division, truncation
+            # (:230's astype("int")) -- the map never goes D2H and only the point COUNT reaches the host
+            coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
+            # fp32 quotient via float64 (exactly the correctly rounded fp32 division of the host path, whatever the
+            # device's fp32 divide does: 53 >= 2 * 24 + 2 bits make the double rounding innocuous)
+            q = (coords.to(torch.float64) / inv_factor.to(coords.device, torch.float64)).to(torch.float32)
+            return q.to(torch.int32).contiguous()
+        sim_c = sim_c.cpu()                                              # one small D2H
+        coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
         return (coords / inv_factor).numpy()
 
     def _result_store(self, H, W):
@@ -218,48 +230,86 @@ class CrowdSAM:
         t0 = self._tick("set_image", t0)
         H, W = self.image_hw
         orig_h, orig_w = self.orig_image.shape[:2]
-        points_for_image = self.sample_prompts()
-        t0 = self._tick("sample_prompts", t0)
         dev = self.device
         prune = math.isfinite(self.filter_thresh)
+        dev_sampler = prune and self.eps_on_device
+        points_for_image = self.sample_prompts(on_device=dev_sampler)
+        t0 = self._tick("sample_prompts", t0)
         store = self._result_store(*self.predictor.original_size)
         store["counter"].zero_()
 
-        points = points_for_image.astype("int")      # :230 truncation
+        # :230 truncation (already done, on the device, for the device-resident sampler)
+        points = points_for_image if dev_sampler else points_for_image.astype("int")
         # :231 np.random.shuffle(points) on the global RNG (seeded by the harness).  NumPy shuffles the rows of a 2-D
         # array one Python-level swap at a time (38 ms for the 36 864 points of the shipped grid_size 192); shuffling an
         # index vector draws the SAME random_interval sequence (Fisher-Yates over n items either way), so the
         # permutation and the RNG state afterwards are identical (tests/test_host_logic_cpu.py) at 3 ms
         perm = np.arange(len(points))
         np.random.shuffle(perm)
-        points = points[perm]
+        if dev_sampler:
+            # the list stays where it was computed; only the permutation (4 bytes per point) goes up
+            points = points[torch.as_tensor(perm.astype(np.int32)).to(dev).long()] if len(perm) else points
+        else:
+            points = points[perm]
         # The shuffled point list goes to the GPU ONCE; the sampler then works on indices into it.  (Uploading the
         # remaining points every batch -- 36 864 of them at the shipped grid_size 192 -- was a pageable H2D of ~300 KB
         # per batch, which ROCm pins on the fly: 0.7-14 ms each, several times the 1 ms the batch itself takes.)
-        all_pts_dev = None
-        alive = np.arange(len(points))               # indices of the points still in play, in shuffled order
         count = 0
         n_batches = 0
         batch_size = self.points_per_batch
-        while len(alive) > 0 and count < self.max_prompts:
-            batch_size = min(len(alive), batch_size)
-            sel_idx, alive = alive[:batch_size], alive[batch_size:]
-            tb = time.perf_counter()
-            bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
-            tb = self._tick("eps.batch", tb)
-            if prune and len(alive) > 0:
-                if all_pts_dev is None:
-                    all_pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
-                    occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
-                    tb = self._tick("eps.upload_points", tb)
-                # occupancy of EVERY point under this batch's masks (the mask is replaced per batch, :246); only the
-                # flags of the live points are looked at -- same pruning as points[~occupy_mask[y, x]] (:238-239)
-                hip.occupancy_lookup(all_pts_dev, store["masks"], bd["occ"], batch_size, H, W, occupy_bits, slot=bd["slot"])
-                occ = occupy_bits.cpu().numpy().astype(bool)                  # the per-batch sync
-                alive = alive[~occ[alive]]
-                self._tick("eps.prune", tb)
-            count += batch_size
-            n_batches += 1
+        if dev_sampler and len(points) > 0:
+            # Device-resident sampler (csam_eps_select / csam_occupancy_prune): the list and one alive flag per point stay
+            # on the GPU; a round takes the first batch_size alive points in list order -- the reference's
+            # points[:batch_size] -- and the pruning clears flags, so the sweep is a queue of kernels without a host round
+            # trip per batch.  The host does not see len(points): it runs the rounds count < max_prompts allows (a round
+            # whose list has run dry has zero valid slots and leaves no trace) and looks at the device's alive count every
+            # 4th round to stop early.  The reference's last round shrinks to the points that are left; here it keeps its
+            # width and reports how many slots are real (n_valid).
+            P = len(points)
+            all_pts_dev = points.contiguous()
+            alive_dev = torch.ones(P, dtype=torch.uint8, device=dev)
+            B = min(batch_size, P)
+            pts_b = torch.empty(B, 2, dtype=torch.int32, device=dev)
+            coords_b = torch.empty(B, 2, dtype=torch.float32, device=dev)
+            counts = torch.zeros(2, dtype=torch.int32, device=dev)
+            old_h, old_w = self.predictor.original_size
+            new_h, new_w = self.predictor.transform.get_preprocess_shape(old_h, old_w, self.predictor.transform.target_length)
+            max_rounds = -(-P // B)
+            while count < self.max_prompts and n_batches < max_rounds:
+                tb = time.perf_counter()
+                hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
+                bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
+                                         device_batch=(pts_b, coords_b, counts[:1]))
+                hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
+                count += B
+                n_batches += 1
+                self._tick("eps.batch", tb)
+                if n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
+                    if int(counts[1].item()) == 0:        # nothing was left behind this round's selection
+                        break
+        else:
+            all_pts_dev = None
+            alive = np.arange(len(points))               # indices of the points still in play, in shuffled order
+            while len(alive) > 0 and count < self.max_prompts:
+                batch_size = min(len(alive), batch_size)
+                sel_idx, alive = alive[:batch_size], alive[batch_size:]
+                tb = time.perf_counter()
+                bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
+                tb = self._tick("eps.batch", tb)
+                if prune and len(alive) > 0:
+                    if all_pts_dev is None:
+                        all_pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+                        occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
+                        tb = self._tick("eps.upload_points", tb)
+                    # occupancy of EVERY point under this batch's masks (the mask is replaced per batch, :246); only the
+                    # flags of the live points are looked at -- same pruning as points[~occupy_mask[y, x]] (:238-239)
+                    hip.occupancy_lookup(all_pts_dev, store["masks"], bd["occ"], batch_size, H, W, occupy_bits,
+                                         slot=bd["slot"])
+                    occ = occupy_bits.cpu().numpy().astype(bool)                  # the per-batch sync
+                    alive = alive[~occ[alive]]
+                    self._tick("eps.prune", tb)
+                count += batch_size
+                n_batches += 1
         self.predictor.reset_image()
         t0 = self._tick("eps_sweep", t0)
         if n_batches == 0:
@@ -318,17 +368,25 @@ class CrowdSAM:
             raise NotImplementedError
         return torch.arange(len(masks)), ind
 
-    def _process_batch(self, points, im_size, crop_box, store):
+    def _process_batch(self, points, im_size, crop_box, store, device_batch=None):
         """One EPS batch, entirely asynchronous: decode B prompts, PWD-Net selection, statistics pass, filters +
         in-kernel compaction of the survivors into ``store``, mask bytes of the survivors.
-        Returns the per-batch occupancy flags and store slots (device) for the pruning lookup."""
+        Returns the per-batch occupancy flags and store slots (device) for the pruning lookup.
+        ``device_batch`` = (points i32 [B,2], coords f32 [B,2], n_valid i32 [1]) on the device, from csam_eps_select
+        (``points`` is then ignored): nothing of the batch touches the host."""
         p = self.predictor
         dev = self.device
-        B = len(points)
         H, W = p.original_size
-        tp = p.transform.apply_coords(points, im_size)                       # float64 on the host (trap 6)
-        in_points = torch.as_tensor(tp)[:, None, :]
-        low, iou, cls = p.decode_points(in_points, None)
+        if device_batch is None:
+            B = len(points)
+            tp = p.transform.apply_coords(points, im_size)                       # float64 on the host (trap 6)
+            in_points = torch.as_tensor(tp)[:, None, :]
+            low, iou, cls = p.decode_points(in_points, None)
+            pts_dev, n_valid = None, None
+        else:
+            pts_dev, coords_dev, n_valid = device_batch
+            B = pts_dev.shape[0]
+            low, iou, cls = p.decode_coords_device(coords_dev)
         i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
         sel, category = i32(B), i32(B)
         score = torch.empty(B, dtype=torch.float32, device=dev)
@@ -357,7 +415,8 @@ class CrowdSAM:
         keep = torch.empty(B, dtype=torch.uint8, device=dev)
         occ = torch.empty(B, dtype=torch.uint8, device=dev)
         slot = i32(B)
-        pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+        if pts_dev is None:
+            pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
         edge = None
         if self.crop_n_layers > 0:      # per batch, before the occupancy flags (crowdsam/model.py:386-389)
             orig_h, orig_w = self.orig_image.shape[:2]
@@ -365,7 +424,7 @@ class CrowdSAM:
         hip.post_finalize_compact(score, inter, uni, box, category, pts_dev, self.pred_iou_thresh,
                                   self.stability_score_thresh,
                                   self.filter_thresh if math.isfinite(self.filter_thresh) else 3.0e38,
-                                  keep, occ, slot, store["counter"], store, B, edge=edge)
+                                  keep, occ, slot, store["counter"], store, B, edge=edge, n_valid=n_valid)
         # pass 2: mask bytes of the survivors, straight into their store slots
         hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, store["masks"], tmp, slot=slot)
         return dict(occ=occ, slot=slot)

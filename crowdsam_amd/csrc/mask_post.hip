@@ -477,11 +477,12 @@ __global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
     float pred_iou_thresh, float stab_thresh, float filter_thresh, uint8_t* __restrict__ keep,
     uint8_t* __restrict__ occ, int* __restrict__ slot, int* __restrict__ counter, float* __restrict__ o_score,
     float* __restrict__ o_stab, int* __restrict__ o_box, int* __restrict__ o_cat, int* __restrict__ o_pts, int B,
-    int cap, EdgeFilter edge) {
+    int cap, EdgeFilter edge, const int* __restrict__ n_valid) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) base_s = *counter;
+  const int nv = n_valid ? *n_valid : B;          // device-resident sampler: slots >= *n_valid hold no prompt
   __syncthreads();
   for (int b0 = 0; b0 < B; b0 += 1024) {
     const int b = b0 + tid;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
     int bx[4] = {0, 0, 0, 0};
     if (b < B) {
       st = (float)inter[b] / (float)uni[b];
-      k = true;
+      k = b < nv;
       if (pred_iou_thresh > 0.f) k = k && (score[b] > pred_iou_thresh);
       if (stab_thresh > 0.f) k = k && (st >= stab_thresh);
 #pragma unroll
@@ -564,7 +565,97 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const int* __restrict__ 
   out[p] = r;
 }
 
+// ---- Efficient Prompt Sampler, device-resident (crowdsam/model.py:233-249).  The reference keeps the shuffled point list on
+// the host, takes points[:batch_size] each round and drops the points that fall under the round's masks.  Here the list
+// stays on the device with one alive flag per point: a round's batch = the first B points still alive, in list order (the
+// same points, in the same order), and the pruning clears flags.  No host round trip per batch.
+//
+// eps_select: out_pts / out_coords [B] <- the first min(B, #alive) alive points (flags cleared: they are consumed), the rest
+// of the B slots are filled with (0, 0) and reported through counts[0] = n_valid; counts[1] = points left alive afterwards.
+// Coordinates go through ResizeLongestSide.apply_coords in float64 as the reference does on the host (transforms.py:33-41,
+// trap 6): x * (new_w / old_w), y * (new_h / old_h), then the fp32 cast of torch.as_tensor(..., dtype=float).
+__global__ __launch_bounds__(1024) void eps_select_kernel(const int* __restrict__ pts, uint8_t* __restrict__ alive, int P,
+                                                          int B, double sx, double sy, int* __restrict__ out_pts,
+                                                          float* __restrict__ out_coords, int* __restrict__ counts) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (P + 1023) / 1024;
+  const int p0 = min(tid * chunk, P), p1 = min(p0 + chunk, P);
+  int cnt = 0;
+  for (int p = p0; p < p1; ++p) cnt += alive[p] != 0;
+  int incl = cnt;                                  // inclusive scan inside the wave, then over the 16 wave totals
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) woff += wsum[w];
+    total += wsum[w];
+  }
+  int rank = woff + incl - cnt;                    // alive points in front of this thread's chunk
+  for (int p = p0; p < p1 && rank < B; ++p) {
+    if (alive[p]) {
+      const int x = pts[p * 2], y = pts[p * 2 + 1];
+      out_pts[rank * 2] = x;
+      out_pts[rank * 2 + 1] = y;
+      out_coords[rank * 2] = (float)((double)x * sx);
+      out_coords[rank * 2 + 1] = (float)((double)y * sy);
+      alive[p] = 0;
+      ++rank;
+    }
+  }
+  const int nv = min(total, B);
+  for (int i = nv + tid; i < B; i += 1024) {
+    out_pts[i * 2] = out_pts[i * 2 + 1] = 0;
+    out_coords[i * 2] = out_coords[i * 2 + 1] = 0.f;
+  }
+  if (tid == 0) {
+    counts[0] = nv;
+    counts[1] = total - nv;
+  }
+}
+
+// alive[p] &= !(OR_b occ[b] & mask[b, y_p, x_p])   (crowdsam/model.py:238-239,246)
+__global__ __launch_bounds__(256) void occupancy_prune_kernel(const int* __restrict__ pts, int P,
+                                                              const uint8_t* __restrict__ masks,
+                                                              const uint8_t* __restrict__ occ,
+                                                              const int* __restrict__ slot, int B, int H, int W,
+                                                              uint8_t* __restrict__ alive) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P || !alive[p]) return;
+  const int x = pts[p * 2], y = pts[p * 2 + 1];
+  if (x < 0 || x >= W || y < 0 || y >= H) return;
+  uint8_t r = 0;
+  for (int b = 0; b < B; ++b)
+    if (occ[b]) r |= masks[((long)(slot ? slot[b] : b) * H + y) * W + x];
+  if (r) alive[p] = 0;
+}
+
 }  // namespace
+
+extern "C" int csam_eps_select(void* stream, const int* points_xy, void* alive_u8, int P, int B, double scale_x,
+                               double scale_y, int* out_points_xy, float* out_coords, int* counts2) {
+  CSAM_REQUIRE(points_xy && alive_u8 && out_points_xy && out_coords && counts2 && P > 0 && B > 0,
+               "csam_eps_select: bad args");
+  hipLaunchKernelGGL(eps_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, points_xy, (uint8_t*)alive_u8, P, B,
+                     scale_x, scale_y, out_points_xy, out_coords, counts2);
+  CSAM_LAUNCH_CHECK("csam_eps_select");
+  return CSAM_OK;
+}
+
+extern "C" int csam_occupancy_prune(void* stream, const int* points_xy, int P, const void* masks_u8, const void* occ_u8,
+                                    const int* slot_or_null, int B, int H, int W, void* alive_u8) {
+  CSAM_REQUIRE(points_xy && masks_u8 && occ_u8 && alive_u8 && P > 0 && B > 0, "csam_occupancy_prune: bad args");
+  hipLaunchKernelGGL(occupancy_prune_kernel, dim3(csam_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, points_xy, P,
+                     (const uint8_t*)masks_u8, (const uint8_t*)occ_u8, slot_or_null, B, H, W, (uint8_t*)alive_u8);
+  CSAM_LAUNCH_CHECK("csam_occupancy_prune");
+  return CSAM_OK;
+}
 
 extern "C" int csam_select_masks(void* stream, const float* iou, const float* cls, int n_class, int* sel,
                                  float* score, int* category, float* fused_or_null, int B) {
@@ -695,7 +786,8 @@ extern "C" int csam_post_finalize_compact(void* stream, const float* score, cons
                                           float pred_iou_thresh, float stability_thresh, float filter_thresh,
                                           void* keep_u8, void* occ_u8, int* slot, int* counter, float* out_score,
                                           float* out_stability, int* out_box, int* out_category, int* out_points,
-                                          int B, int capacity, const float* edge10_host) {
+                                          int B, int capacity, const float* edge10_host,
+                                          const int* n_valid_or_null) {
   CSAM_REQUIRE(score && inter && uni && box && category && points_xy && keep_u8 && occ_u8 && slot && counter &&
                    out_score && out_stability && out_box && out_category && out_points && B > 0 && capacity > 0,
                "csam_post_finalize_compact: bad args");
@@ -709,7 +801,7 @@ extern "C" int csam_post_finalize_compact(void* stream, const float* score, cons
   hipLaunchKernelGGL(post_finalize_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, inter, uni, box,
                      category, points_xy, pred_iou_thresh, stability_thresh, filter_thresh, (uint8_t*)keep_u8,
                      (uint8_t*)occ_u8, slot, counter, out_score, out_stability, out_box, out_category, out_points, B,
-                     capacity, edge);
+                     capacity, edge, n_valid_or_null);
   CSAM_LAUNCH_CHECK("csam_post_finalize_compact");
   return CSAM_OK;
 }

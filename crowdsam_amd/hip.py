@@ -18,7 +18,7 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DT_F16, DT_F32 = 0, 1
 
 _c = ctypes
-_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
+_P, _I, _L, _F, _D = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_double
 
 # name -> argtypes (all return int).  Must match include/csam.h line by line.
 SIGNATURES = {
@@ -50,7 +50,9 @@ SIGNATURES = {
     "csam_post_finalize": [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _I],
     "csam_mask_write": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "csam_occupancy_lookup": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
-    "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "csam_eps_select": [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P],
+    "csam_occupancy_prune": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -460,10 +462,23 @@ def occupancy_lookup(points, masks, occ, B, H, W, out, slot=None):
          _ptr(out))
 
 
+def eps_select(points, alive, B, scale_x, scale_y, out_points, out_coords, counts):
+    """Device-resident sampler step: the first min(B, #alive) alive points (list order) -> out_points i32 [B,2] and, scaled
+    in float64 like ResizeLongestSide.apply_coords, out_coords f32 [B,2]; flags cleared; counts i32 [2] = (valid, left)."""
+    call("csam_eps_select", _stream(), _ptr(points), _ptr(alive), points.shape[0], B, float(scale_x), float(scale_y),
+         _ptr(out_points), _ptr(out_coords), _ptr(counts))
+
+
+def occupancy_prune(points, masks, occ, B, H, W, alive, slot=None):
+    call("csam_occupancy_prune", _stream(), _ptr(points), points.shape[0], _ptr(masks), _ptr(occ), _ptr(slot), B, H, W,
+         _ptr(alive))
+
+
 def post_finalize_compact(score, inter, uni, box, category, points, pred_iou_thresh, stab_thresh, filter_thresh, keep, occ,
-                          slot, counter, store, B, edge=None):
+                          slot, counter, store, B, edge=None, n_valid=None):
     """Filters + in-kernel compaction of the survivors into ``store`` (dict of image-level device arrays).
-    ``edge`` = (crop_box, orig_box, downscale, atol) enables the crop-edge filter of crowdsam/utils.py:213-223."""
+    ``edge`` = (crop_box, orig_box, downscale, atol) enables the crop-edge filter of crowdsam/utils.py:213-223;
+    ``n_valid`` (device i32) = number of slots of the batch that hold a prompt (device-resident sampler)."""
     e10 = None
     if edge is not None:
         e10 = (_F * 10)(*[float(v) for v in edge[0]], *[float(v) for v in edge[1]], float(edge[2]), float(edge[3]))
@@ -471,7 +486,7 @@ def post_finalize_compact(score, inter, uni, box, category, points, pred_iou_thr
          _ptr(points), float(pred_iou_thresh), float(stab_thresh), float(filter_thresh), _ptr(keep), _ptr(occ),
          _ptr(slot), _ptr(counter), _ptr(store["score"]), _ptr(store["stability"]), _ptr(store["boxes"]),
          _ptr(store["category"]), _ptr(store["points"]), B, store["score"].shape[0],
-         None if e10 is None else _c.cast(e10, _P))
+         None if e10 is None else _c.cast(e10, _P), _ptr(n_valid))
 
 
 def box_nms(boxes, scores, thr):

@@ -239,12 +239,15 @@ int csam_mask_write(void* stream, const float* lowres, const int* sel, const voi
 /* finalize + in-kernel compaction of the survivors into an image-level store (MaskData.cat of
  * crowdsam/model.py:247 without host sync or gather copies): slot[b] = store index or -1.
  * edge10_host (HOST pointer, NULL = off): {crop_box[4], orig_box[4], downscale, atol} of utils.is_box_near_crop_edge
- * (crowdsam/utils.py:213-223), applied per batch BEFORE the occupancy flags as crowdsam/model.py:386-389 does. */
+ * (crowdsam/utils.py:213-223), applied per batch BEFORE the occupancy flags as crowdsam/model.py:386-389 does.
+ * n_valid_or_null (DEVICE pointer): with the device-resident sampler only the first *n_valid slots of the batch hold a
+ * prompt (csam_eps_select); the others are dropped here. */
 int csam_post_finalize_compact(void* stream, const float* score, const int* inter, const int* uni, const int* box,
                                const int* category, const int* points_xy, float pred_iou_thresh,
                                float stability_thresh, float filter_thresh, void* keep_u8, void* occ_u8, int* slot,
                                int* counter, float* out_score, float* out_stability, int* out_box, int* out_category,
-                               int* out_points, int B, int capacity, const float* edge10_host);
+                               int* out_points, int B, int capacity, const float* edge10_host,
+                               const int* n_valid_or_null);
 int csam_bilinear_f32(void* stream, const float* src, int n, int sh, int sw, float* dst, int H, int W);
 /* crowdsam/model.py:371-389,246: keep / occupancy flags, stability = inter/union, empty box -> 0 */
 int csam_post_finalize(void* stream, const float* score, const int* inter, const int* uni, int* box,
@@ -253,6 +256,17 @@ int csam_post_finalize(void* stream, const float* score, const int* inter, const
 /* crowdsam/model.py:238: occupancy bits of the remaining points (never the mask itself goes D2H) */
 int csam_occupancy_lookup(void* stream, const int* points_xy, int P, const void* masks_u8, const void* occ_u8,
                           const int* slot_or_null, int B, int H, int W, void* out_u8);
+/* Efficient Prompt Sampler without a host round trip per batch (crowdsam/model.py:233-249): the shuffled point list and
+ * one alive flag per point live on the device.  csam_eps_select: the next batch = the first min(B, #alive) alive points in
+ * list order -- what points[:batch_size] is on the host -- written to out_points_xy [B,2] and, through
+ * ResizeLongestSide.apply_coords in float64 (transforms.py:33-41: x * scale_x, y * scale_y, then the fp32 cast), to
+ * out_coords [B,2]; their flags are cleared; counts2[0] = number of valid slots, counts2[1] = points still alive.
+ * csam_occupancy_prune: alive[p] &= !(point p lies under a mask of this batch with its occupancy flag set), the
+ * points[~occupy_mask[y, x]] of :238-239. */
+int csam_eps_select(void* stream, const int* points_xy, void* alive_u8, int P, int B, double scale_x, double scale_y,
+                    int* out_points_xy, float* out_coords, int* counts2);
+int csam_occupancy_prune(void* stream, const int* points_xy, int P, const void* masks_u8, const void* occ_u8,
+                         const int* slot_or_null, int B, int H, int W, void* alive_u8);
 
 /* ---- NMS + RLE */
 long csam_box_nms_workspace_bytes(int N);

@@ -180,6 +180,14 @@ class SamPredictor:
         c = torch.as_tensor(point_coords)[:, 0, :].to(device=self.device, dtype=torch.float32).contiguous()
         return self._plan.run_batch(c)
 
+    @torch.no_grad()
+    def decode_coords_device(self, coords_f32):
+        """decode_points for coordinates that are already on the device: f32 [B,2] (x, y) in the input frame, e.g. from
+        csam_eps_select (which applies ResizeLongestSide.apply_coords in float64 like the host path)."""
+        self._require_image()
+        assert coords_f32.is_cuda and coords_f32.dtype == torch.float32 and coords_f32.dim() == 2
+        return self._plan.run_batch(coords_f32)
+
     def get_image_embedding(self):
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) to generate an embedding.")
