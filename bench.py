@@ -246,7 +246,7 @@ def main():
         two = _pred._TWO_STREAMS
         _pred._TWO_STREAMS = False
         GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
-        SWEEP_NAMES = ["csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_shared",
+        SWEEP_NAMES = ["csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_i2t_rank_proj", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_shared",
                        "csam_upscale_fused", "csam_upscale_stream",
                        "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_post_scored", "csam_mask_write"]
         timer = hip.KernelTimer(GEMM_NAMES + SWEEP_NAMES)

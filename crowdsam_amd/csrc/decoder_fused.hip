@@ -709,14 +709,21 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
 namespace {
 
 constexpr int IR_M_BYTES = 256 * 64 * 2;            // M_b^T [256 channels][64 k-slots] fp16
+constexpr int IR_KP_BYTES = 64 * 256 * 2;           // Kp_b [64 (head, key) rows][256 channels] fp16 (projected form)
 constexpr int IR_SLICE = 16 * 512;                  // per-wave output staging, 16 tokens x 256 ch fp16
-constexpr int IR_PAR = IR_M_BYTES + 4 * IR_SLICE;   // bo | gamma | beta fp32
-constexpr int IR_SMEM = IR_PAR + 3 * 256 * 4;
+template <bool PROJ, int NW>
+struct IR {
+  static constexpr int KP = IR_M_BYTES;                                  // Kp region (PROJ only)
+  static constexpr int SLICES = IR_M_BYTES + (PROJ ? IR_KP_BYTES : 0);
+  static constexpr int PAR = SLICES + NW * IR_SLICE;                     // bo | gamma | beta fp32
+  static constexpr int SMEM = PAR + 3 * 256 * 4;
+};
 
 struct IrArgs {
   const half_t* X; long x_bstride; const half_t* Q; long q_bstride;
   const half_t* ks;          // [B,7,128] token-side k, pre-multiplied by 0.25 log2(e)
   const half_t* M;           // [B][256][64] from i2t_rank_prep_kernel
+  const half_t* Kp;          // [B][64][256] from i2t_rank_kp_kernel (projected form) or null
   const float* bo; const float* gamma; const float* beta; float eps;
   half_t* out; int B; int T;
 };
@@ -754,17 +761,49 @@ __global__ __launch_bounds__(256) void i2t_rank_prep_kernel(const half_t* __rest
   }
 }
 
-__global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_per_wg) {
+// Projected form (layer 1: q = (X + pe) Wq^T + bq differs per prompt): the X-dependent part of the scores is
+//     (X Wq_h^T) . k_b[j,h] = X . Kp_b[(h, j), :],    Kp_b[8 h + j][c] = sum_d ks[b][j][16 h + d] Wq[16 h + d][c]   (j = 7: zero)
+// so the q projection of the 4096 image tokens is never formed: 56 back-projected token keys per prompt instead.
+__global__ __launch_bounds__(256) void i2t_rank_kp_kernel(const half_t* __restrict__ ks, const half_t* __restrict__ Wq,
+                                                          half_t* __restrict__ Kp) {
+  __shared__ float kk[7 * 128];
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int i = c; i < 7 * 128; i += 256) kk[i] = (float)ks[(long)b * 7 * 128 + i];
+  __syncthreads();
+  half_t* dst = Kp + (long)b * 64 * 256 + c;
+#pragma unroll 1
+  for (int head = 0; head < 8; ++head) {
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) w[d] = (float)Wq[(long)(head * 16 + d) * 256 + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.f;
+      if (j < 7) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc = fmaf(w[d], kk[j * 128 + head * 16 + d], acc);
+      }
+      dst[(long)(head * 8 + j) * 256] = (half_t)acc;
+    }
+  }
+}
+
+template <bool PROJ, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_rank_kernel(IrArgs p, int prompts_per_wg) {
+  typedef IR<PROJ, NW> G;
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
-  char* slice = smem + IR_M_BYTES + wave * IR_SLICE;
-  float* par = (float*)(smem + IR_PAR);
-  par[tid] = p.bo[tid];
-  par[256 + tid] = p.gamma[tid];
-  par[512 + tid] = p.beta[tid];
+  char* slice = smem + G::SLICES + wave * IR_SLICE;
+  float* par = (float*)(smem + G::PAR);
+  for (int i = tid; i < 256; i += NT) {
+    par[i] = p.bo[i];
+    par[256 + i] = p.gamma[i];
+    par[512 + i] = p.beta[i];
+  }
   const int tpp = p.T / 16;
   const int b_first = blockIdx.x * prompts_per_wg;
   const int b_last = min(b_first + prompts_per_wg, p.B);
@@ -780,13 +819,22 @@ __global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_
   floatx4 qraw[4];                                   // 4 x half8: 32 q dims of head pair pr for token fr
   floatx4 xres[8];                                   // 8 x half8 residual fragments: channels nj*32 + fg*8 .. +7 of token fr
   for (int b = b_first; b < b_last; ++b) {
-    __syncthreads();                                 // every wave is done with the previous prompt's M
+    __syncthreads();                                 // every wave is done with the previous prompt's M (and Kp)
     {
       const char* src = (const char*)(p.M + (long)b * 256 * 64);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                  // 256 rows x 8 slots of 16 B, slot ^= row & 7
-        const int c = tid + i * 256, row = c >> 3, sl = c & 7;
-        i2s_glds16(src, (unsigned)(row * 128 + ((sl ^ (row & 7)) << 4)), lds0 + (unsigned)(wave * 1024 + i * 4096));
+      for (int i = 0; i < 2048 / NT; ++i) {          // 256 rows x 8 slots of 16 B, slot ^= row & 7
+        const int c = tid + i * NT, row = c >> 3, sl = c & 7;
+        i2s_glds16(src, (unsigned)(row * 128 + ((sl ^ (row & 7)) << 4)), lds0 + (unsigned)(wave * 1024 + i * NT * 16));
+      }
+      if constexpr (PROJ) {
+        const char* ksrc = (const char*)(p.Kp + (long)b * 64 * 256);
+#pragma unroll
+        for (int i = 0; i < 2048 / NT; ++i) {        // 64 rows x 32 slots of 16 B, slot ^= row & 15
+          const int c = tid + i * NT, row = c >> 5, sl = c & 31;
+          i2s_glds16(ksrc, (unsigned)(row * 512 + ((sl ^ (row & 15)) << 4)),
+                     lds0 + (unsigned)(G::KP + wave * 1024 + i * NT * 16));
+        }
       }
     }
     // paired-head key fragments: rows 0-7 = K_h0 (dims in k 0..15), rows 8-15 = K_h1 (dims in k 16..31)
@@ -815,15 +863,34 @@ __global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_
     prefetch(wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (int tile = wave; tile < tpp; tile += 4) {
+    for (int tile = wave; tile < tpp; tile += NW) {
       const int t0 = tile * 16;
       // ---- scores of the 8 heads (two per MFMA) and their softmax over the 7 keys
-      half8_t pf[2];
+      floatx4 sc[4];
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
         half8_t qf;
         __builtin_memcpy(&qf, &qraw[pr], 16);
-        const floatx4 s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[pr], qf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        sc[pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[pr], qf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+      if constexpr (PROJ) {
+        // + X . Kp^T: A = Kp rows 16 pr + fr (head pair pr, same row order as kfr), channels nj*32 + fg*8 .. +7
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) {
+          half8_t xf;
+          __builtin_memcpy(&xf, &xres[nj], 16);
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            const int row = pr * 16 + fr;
+            const half8_t kp = *(const half8_t*)(smem + G::KP + row * 512 + (((nj * 4 + fg) ^ fr) << 4));
+            sc[pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kp, xf, sc[pr], 0, 0, 0);
+          }
+        }
+      }
+      half8_t pf[2];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const floatx4 s4 = sc[pr];
         const float s3 = key7 ? -INFINITY : s4[3];
         float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -850,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_
         acc[2 * nj + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_hi, xf, b1, 0, 0, 0);
       }
       asm volatile("" ::: "memory");
-      if (tile + 4 < tpp) prefetch(tile + 4);          // the q / residual registers are free: next tile's operands
+      if (tile + NW < tpp) prefetch(tile + NW);        // the q / residual registers are free: next tile's operands
       // ---- P . M_b : [256 channels] x [16 tokens], K = 64 slots
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -908,6 +975,22 @@ __global__ __launch_bounds__(256, 2) void i2t_rank_kernel(IrArgs p, int prompts_
 }  // namespace
 
 extern "C" long csam_i2t_rank_workspace_bytes(int B) { return (long)B * 256 * 64 * 2; }
+extern "C" long csam_i2t_rank_proj_workspace_bytes(int B) { return (long)B * (IR_M_BYTES + IR_KP_BYTES); }
+
+static int ir_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    constexpr int s0 = IR<false, 4>::SMEM, s1 = IR<true, 8>::SMEM, s2 = IR<false, 8>::SMEM;
+    (void)hipFuncSetAttribute((const void*)i2t_rank_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, s0);
+    (void)hipFuncSetAttribute((const void*)i2t_rank_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, s2);
+    (void)hipFuncSetAttribute((const void*)i2t_rank_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, s1);
+  }
+  return n_cu;
+}
 
 extern "C" int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
                              const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
@@ -920,23 +1003,59 @@ extern "C" int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stri
     csam_set_error("csam_i2t_rank: workspace too small");
     return CSAM_ERR_WORKSPACE;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute((const void*)i2t_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IR_SMEM);
-  }
+  const int n_cu = ir_cus();
   hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)v_f16,
                      (const half_t*)Wo_f16, (half_t*)workspace);
   IrArgs a;
   a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
-  a.ks = (const half_t*)k_scaled_f16; a.M = (const half_t*)workspace; a.bo = bo; a.gamma = gamma; a.beta = beta;
-  a.eps = eps; a.out = (half_t*)out_f16; a.B = B; a.T = T;
-  const int per = csam_cdiv(B, 2 * n_cu);
-  hipLaunchKernelGGL(i2t_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), IR_SMEM, (hipStream_t)stream, a, per);
+  a.ks = (const half_t*)k_scaled_f16; a.M = (const half_t*)workspace; a.Kp = nullptr; a.bo = bo; a.gamma = gamma;
+  a.beta = beta; a.eps = eps; a.out = (half_t*)out_f16; a.B = B; a.T = T;
+  static const int nw = [] {                          // developer A/B: 8 = one 8-wave workgroup per CU
+    const char* e = getenv("CSAM_I2T_RANK_NW");
+    return e && e[0] == '8' ? 8 : 4;
+  }();
+  if (nw == 8) {
+    const int per = csam_cdiv(B, n_cu);
+    constexpr int smem = IR<false, 8>::SMEM;
+    hipLaunchKernelGGL((i2t_rank_kernel<false, 8>), dim3(csam_cdiv(B, per)), dim3(512), smem, (hipStream_t)stream, a, per);
+  } else {
+    const int per = csam_cdiv(B, 2 * n_cu);
+    constexpr int smem = IR<false, 4>::SMEM;
+    hipLaunchKernelGGL((i2t_rank_kernel<false, 4>), dim3(csam_cdiv(B, per)), dim3(256), smem, (hipStream_t)stream, a, per);
+  }
   CSAM_LAUNCH_CHECK("csam_i2t_rank");
+  return CSAM_OK;
+}
+
+// Layer-1 form: the keys differ per prompt (x_prompt_stride = T * 256) and q = (X + pe) Wq^T + bq is never formed:
+// qpe_f16 [T,128] = pe Wq^T + bq is the shared part (plays the hoisted Q of csam_i2t_rank), X . Kp_b^T the per-prompt part.
+extern "C" int csam_i2t_rank_proj(void* stream, const void* X_f16, long x_prompt_stride, const void* qpe_f16,
+                                  const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
+                                  const float* bo, const float* gamma, const float* beta, float eps, void* out_f16, int B,
+                                  int T, void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(X_f16 && qpe_f16 && Wq_f16 && k_scaled_f16 && v_f16 && Wo_f16 && bo && gamma && beta && out_f16 &&
+                   workspace,
+               "csam_i2t_rank_proj: null pointer");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % 128 == 0, "csam_i2t_rank_proj: T must be a multiple of 128");
+  if (workspace_bytes < csam_i2t_rank_proj_workspace_bytes(B)) {
+    csam_set_error("csam_i2t_rank_proj: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  const int n_cu = ir_cus();
+  half_t* Mws = (half_t*)workspace;
+  half_t* Kpws = Mws + (long)B * 256 * 64;
+  hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)v_f16,
+                     (const half_t*)Wo_f16, Mws);
+  hipLaunchKernelGGL(i2t_rank_kp_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)k_scaled_f16,
+                     (const half_t*)Wq_f16, Kpws);
+  IrArgs a;
+  a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)qpe_f16; a.q_bstride = 0;
+  a.ks = (const half_t*)k_scaled_f16; a.M = Mws; a.Kp = Kpws; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.out = (half_t*)out_f16; a.B = B; a.T = T;
+  const int per = csam_cdiv(B, n_cu);               // whole prompts per workgroup, one 8-wave workgroup per CU
+  constexpr int smem = IR<true, 8>::SMEM;
+  hipLaunchKernelGGL((i2t_rank_kernel<true, 8>), dim3(csam_cdiv(B, per)), dim3(512), smem, (hipStream_t)stream, a, per);
+  CSAM_LAUNCH_CHECK("csam_i2t_rank_proj");
   return CSAM_OK;
 }
 

@@ -114,6 +114,7 @@ class DecoderPlan:
         self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
         self.up_stream = os.environ.get("CSAM_UP_STREAM", "1") != "0"     # persistent upscaler (B >= 256)
         self.i2t_rank = os.environ.get("CSAM_I2T_RANK", "1") != "0"       # rank-56 layer-0 image->token (B >= 256)
+        self.i2t_rank_l1 = os.environ.get("CSAM_I2T_RANK_L1", "1") != "0"  # ... and layer 1 (csam_i2t_rank_proj)
         self.t2i_rank = os.environ.get("CSAM_T2I_RANK", "1") != "0"       # rank-56 token->image, layers 1 / final (B >= 256)
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -161,6 +162,7 @@ class DecoderPlan:
             d["t2i_kv_pe"] = torch.cat([pk, torch.zeros_like(pk)], 1).contiguous()
             d["i2t_q_pe"] = pe_proj(i2t["q_w"])
             d["i2t_q_peb"] = (d["i2t_q_pe"] + d["i2t_q_b"]).contiguous()
+            d["i2t_q_peb16"] = d["i2t_q_peb"].to(torch.float16).contiguous()     # shared part of the rank-form scores
             d["t2i_kpe"] = (pk + d["t2i_kv_b"][:128]).contiguous()        # pe Wk^T + bk, fp32 [4096,128]
             d.update(self._t2i_rank_consts(t2i, pk))
             d["t2i_bv"] = d["t2i_kv_b"][128:].contiguous()
@@ -258,7 +260,7 @@ class DecoderPlan:
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
             t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev),
             # per-prompt M_b^T of the rank-56 layer-0 image->token kernel (32 KB / prompt; only used from 256 prompts)
-            i2t_rank_ws=e(hip.i2t_rank_workspace_bytes(B if B >= 256 else 1) // 2))
+            i2t_rank_ws=e(hip.i2t_rank_proj_workspace_bytes(B if B >= 256 else 1) // 2))
         self.allocB = B
         self.batch_graphs.clear()
 
@@ -416,6 +418,11 @@ class DecoderPlan:
                 elif li == 0:
                     hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
                                    L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
+                elif self.i2t_rank and self.i2t_rank_l1 and B >= 256:
+                    # per-prompt keys: the image-side q projection folded onto the 7 token keys (56 back-projected rows)
+                    hip.i2t_rank_proj(keys_in, T_IMG * 256, L["i2t_q_peb16"], L["i2t_q_w"], ws["i2t_k"], ws["i2t_v"],
+                                      L["i2t_o_w"], L["i2t_o_b"], L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG,
+                                      ws["i2t_rank_ws"])
                 else:
                     hip.i2t_stream(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
                                    L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],

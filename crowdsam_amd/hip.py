@@ -64,6 +64,7 @@ SIGNATURES = {
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_i2t_rank": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _L],
+    "csam_i2t_rank_proj": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _L],
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_t2i_rank": [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
@@ -91,6 +92,7 @@ LONG_RETURNS = {
     "csam_t2i_fused_workspace_bytes": [_I],
     "csam_flash_attn_workspace_bytes": [_I, _I],
     "csam_i2t_rank_workspace_bytes": [_I],
+    "csam_i2t_rank_proj_workspace_bytes": [_I],
 }
 
 _lib = None
@@ -701,6 +703,19 @@ def i2t_rank(X, x_bstride, Q, q_bstride, k_scaled, v, Wo, bo, gamma, beta, eps, 
     """Hoisted-Q image->token half-block in its rank-56 form (wave-local, barrier-free inside a prompt)."""
     call("csam_i2t_rank", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(k_scaled), _ptr(v), _ptr(Wo), _ptr(bo),
          _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T, _ptr(workspace),
+         workspace.numel() * workspace.element_size())
+    return out
+
+
+def i2t_rank_proj_workspace_bytes(B):
+    return lib().csam_i2t_rank_proj_workspace_bytes(B)
+
+
+def i2t_rank_proj(X, x_bstride, qpe16, Wq, k_scaled, v, Wo, bo, gamma, beta, eps, out, B, T, workspace):
+    """csam_i2t_rank for per-prompt keys (layer 1): qpe16 f16 [T,128] = pe Wq^T + bq, Wq f16 [128,256]; the q projection of
+    the image tokens is replaced by 56 back-projected token keys per prompt."""
+    call("csam_i2t_rank_proj", _stream(), _ptr(X), x_bstride, _ptr(qpe16), _ptr(Wq), _ptr(k_scaled), _ptr(v), _ptr(Wo),
+         _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), B, T, _ptr(workspace),
          workspace.numel() * workspace.element_size())
     return out
 

@@ -198,6 +198,15 @@ long csam_i2t_rank_workspace_bytes(int B);
 int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
                   const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo, const float* gamma,
                   const float* beta, float eps, void* out_f16, int B, int T, void* workspace, long workspace_bytes);
+/* csam_i2t_rank for a layer whose keys differ per prompt (layer 1, transformer.py:186-190 with q = (keys + pe) Wq^T + bq):
+ * the image-side q projection is never formed -- qpe_f16 [T,128] = pe Wq^T + bq is the shared part of the scores and
+ * X . Kp_b^T with Kp_b[8 h + j] = Wq_h^T k_b[j, h] (56 back-projected token keys per prompt, a prologue kernel) the
+ * per-prompt part.  workspace: csam_i2t_rank_proj_workspace_bytes(B). */
+long csam_i2t_rank_proj_workspace_bytes(int B);
+int csam_i2t_rank_proj(void* stream, const void* X_f16, long x_prompt_stride, const void* qpe_f16, const void* Wq_f16,
+                       const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
+                       const float* gamma, const float* beta, float eps, void* out_f16, int B, int T, void* workspace,
+                       long workspace_bytes);
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,

@@ -100,3 +100,39 @@ def test_i2t_rank_hoisted_q(cuda, B):
     out3 = torch.zeros_like(out)
     hip.i2t_rank(X, 0, Q, 0, k_s, v, Wo, bo, g, be, 1e-5, out3, B, T, ws)
     assert torch.equal(out.view(torch.int16), out3.view(torch.int16))
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 530])
+def test_i2t_rank_projected(cuda, B):
+    """csam_i2t_rank_proj (layer-1 form: per-prompt keys, the q projection folded onto 56 back-projected token keys) against
+    the fp32 statement and against csam_i2t_stream's projected form; bitwise repeatable."""
+    from crowdsam_amd import hip
+    T = 4096
+    gen = torch.Generator().manual_seed(300 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(cuda)
+    nX = min(B, 5)
+    Xs = r(nX * T, 256, sc=0.7).half()
+    idx = torch.arange(B, device=cuda) % nX
+    X = Xs.view(nX, T * 256)[idx].contiguous().view(B * T, 256) if B > nX else Xs
+    k, v = r(B * 7, 128, sc=0.8), r(B * 7, 128, sc=0.8).half()
+    Wq, qpe = r(128, 256, sc=0.06).half(), r(T, 128, sc=0.5)
+    Wo, bo = r(256, 128, sc=0.08).half(), r(256, sc=0.2)
+    g, be = (torch.rand(256, generator=gen) + 0.5).to(cuda), r(256, sc=0.2)
+    k_s = (k * SC).half()
+    qpe16 = qpe.half()
+    ws = torch.empty(hip.i2t_rank_proj_workspace_bytes(B) // 2, dtype=torch.float16, device=cuda)
+    out = torch.zeros(B * T, 256, dtype=torch.float16, device=cuda)
+    hip.i2t_rank_proj(X, T * 256, qpe16, Wq, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, ws)
+    sel = torch.tensor(sorted(set(list(range(min(B, 4))) + [B - 1])), device=cuda)
+    Xf = X.float().view(B, T, 256)[sel]
+    q = Xf @ Wq.float().t() + qpe16.float()
+    ref = _ref(Xf, q, (k_s.float() / SC).view(B, 7, 128)[sel], v.float().view(B, 7, 128)[sel], Wo.float(), bo, g, be, 1e-5)
+    err = (out.float().view(B, T, 256)[sel] - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())
+    out2 = torch.zeros_like(out)
+    hip.i2t_stream(X, T * 256, k_s, v, Wo, bo, g, be, 1e-5, out2, B, T, Wq=Wq, qpe=qpe)
+    d = (out.float() - out2.float()).abs()
+    assert d.max().item() < 2.5e-2 and d.mean().item() < 1e-3, (d.max().item(), d.mean().item())
+    out3 = torch.zeros_like(out)
+    hip.i2t_rank_proj(X, T * 256, qpe16, Wq, k_s, v, Wo, bo, g, be, 1e-5, out3, B, T, ws)
+    assert torch.equal(out.view(torch.int16), out3.view(torch.int16))
