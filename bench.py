@@ -299,7 +299,7 @@ def main():
                 res["roofline_decoder_sweep"] = {
                     "bound": "hbm", "kernel": "persistent decoder kernels (i2t / t2i / upscale streams, pool, mask post)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                    "traffic": pmc_traffic("i2t_stream_kernel")[0], "ms_per_step": sweep_ms / args.steps,
+                    "traffic": pmc_traffic("i2t_rank_kernel")[0], "ms_per_step": sweep_ms / args.steps,
                     "note": "algorithmic 14.94 MB/prompt x prompts / HIP-event time of the sweep kernels; traffic = "
                             "PMC bytes per launch of the largest of them (i2t)"}
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -73,6 +73,71 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   }
 }
 
+// LayerNorm of the decoder's token rows with the casts its consumers need folded in: y (fp32, the residual stream),
+// y16 = fp16(y) (value / MLP operand) and ype16 = fp16(y + pe) (query / key operand: tokens + their positional
+// embedding, transformer.py:164-190) -- one launch instead of LayerNorm + two add_cast.  fp32 rows, D <= 1280.
+__global__ __launch_bounds__(256) void layernorm_cast_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int M, int D, float eps,
+                                                             float* __restrict__ y, half_t* __restrict__ y16,
+                                                             const float* __restrict__ pe, half_t* __restrict__ ype16) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nchunk = D >> 2;
+  constexpr int MAXC = 5;
+  floatx4 v[MAXC];
+  const float* xr = x + (long)row * D;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      v[j] = *(const floatx4*)(xr + c * 4);
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  const float mean = csam_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(csam_wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      const floatx4 g = *(const floatx4*)(gamma + c * 4);
+      const floatx4 b = *(const floatx4*)(beta + c * 4);
+      floatx4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];   // same expression as layernorm_kernel
+      const long off = (long)row * D + c * 4;
+      *(floatx4*)(y + off) = o;
+      if (y16) {
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)o[e];
+        *(half4_t*)(y16 + off) = h;
+      }
+      if (ype16) {
+        const floatx4 pv = o + *(const floatx4*)(pe + off);                     // fp32 add, then the cast: add_cast's order
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)pv[e];
+        *(half4_t*)(ype16 + off) = h;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SAM patch-embed im2col with fused Sam.preprocess (sam.py:163-173): normalise with mean/std in
 // fp32, zero-pad bottom/right to 1024^2, emit A[4096, 768] f16 with k = c*256 + dy*16 + dx so the
@@ -345,6 +410,17 @@ extern "C" int csam_layernorm(void* stream, const void* x, long ldx, int x_dtype
     return CSAM_ERR_ARG;
   }
   CSAM_LAUNCH_CHECK("csam_layernorm");
+  return CSAM_OK;
+}
+
+extern "C" int csam_layernorm_cast(void* stream, const float* x, const float* gamma, const float* beta, int M, int D,
+                                   float eps, float* y_f32, void* y_f16_or_null, const float* pe_or_null,
+                                   void* ype_f16_or_null) {
+  CSAM_REQUIRE(x && gamma && beta && y_f32 && M > 0 && D % 4 == 0 && D <= 1280, "csam_layernorm_cast: bad args");
+  CSAM_REQUIRE(!ype_f16_or_null || pe_or_null, "csam_layernorm_cast: ype needs pe");
+  hipLaunchKernelGGL(layernorm_cast_kernel, dim3(csam_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, M, D,
+                     eps, y_f32, (half_t*)y_f16_or_null, pe_or_null, (half_t*)ype_f16_or_null);
+  CSAM_LAUNCH_CHECK("csam_layernorm_cast");
   return CSAM_OK;
 }
 

@@ -346,18 +346,20 @@ class DecoderPlan:
         hip.point_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed1, self.not_a_point, tokens0)
         keys_in, keys_out = None, ws["keysA"]
 
-        def cast_queries():
-            hip.add_cast(queries, out16=q16)
-            hip.add_cast(queries, tokens0, 256, out16=qpe16)
+        def ln_queries(g, b):
+            """queries <- LN(tmp32) together with the operand copies of its consumers: q16 = fp16(queries) and
+            qpe16 = fp16(queries + tokens0) (csam_layernorm_cast: LayerNorm + two add_cast in one launch)"""
+            hip.layernorm_cast(ws["tmp32"][:M7], g, b, 1e-5, queries, out16=q16, pe=tokens0, outpe16=qpe16)
 
-        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None):
+        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None, cast16=None):
+            """queries <- LN(queries + out_proj(attention)); cast16 receives fp16(queries) for the next consumer"""
             if fused_args is not None and "rank" in fused_args and self.t2i_rank and self.t2i_stream and B >= 256:
                 # rank-56 form (csam_t2i_rank): no per-key K / V projections; Wv and the out-projection in one GEMM
                 R = fused_args["rank"]
                 hip.gemm_f16(qpe16, R["q_w_s"], out=ws["t2i_q"][:M7], bias=R["q_b_s"])
                 hip.t2i_rank(fused_args["X"], R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_qp"], ws["t2i_y"], B, T_IMG)
                 hip.gemm_f16(ws["t2i_y"][:M7], R["wc"], out=ws["tmp32"][:M7], bias=R["bc"], residual=queries)
-                hip.layernorm(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, out=queries)
+                hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
                 return
             hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
             if fused_args is not None and "K0" in fused_args:
@@ -371,41 +373,38 @@ class DecoderPlan:
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
             hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
-            hip.layernorm(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, out=queries)
+            hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
 
         for li, L in enumerate(self.layers):
             # ---- token self-attention (transformer.py:164-170)
             if li == 0:
                 hip.add_cast(tokens0, out16=q16)
                 hip.gemm_f16(q16, L["sa_qk_w"], out=ws["sa_qk"][:M7], bias=L["sa_qk_b"])
-            else:
-                cast_queries()
+            else:                                   # q16 / qpe16 still hold the previous layer's norm3 output
                 hip.gemm_f16(qpe16, L["sa_qk_w"], out=ws["sa_qk"][:M7], bias=L["sa_qk_b"])
             hip.gemm_f16(q16, L["sa_v_w"], out=ws["sa_v"][:M7], bias=L["sa_v_b"])
             hip.token_self_attn(ws["sa_qk"], ws["sa_v"], ws["sa_o"], B)
             hip.gemm_f16(ws["sa_o"][:M7], L["sa_o_w"], out=ws["tmp32"][:M7], bias=L["sa_o_b"],
                          residual=None if li == 0 else queries)
-            hip.layernorm(ws["tmp32"][:M7], L["norm1_g"], L["norm1_b"], 1e-5, out=queries)
+            ln_queries(L["norm1_g"], L["norm1_b"])
             # ---- token -> image cross attention (:173-177)
-            cast_queries()
             if li == 0:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
-                    dict(K0=st["k0"], V0T=st["v0t"]) if self.fused else None)
+                    dict(K0=st["k0"], V0T=st["v0t"]) if self.fused else None, cast16=q16)
             elif self.fused:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], None, 0, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
                     dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"],
                          rank=dict(q_w_s=L["t2i_q_w_s"], q_b_s=L["t2i_q_b_s"], k_w=L["t2i_k_w"], kpe16=L["t2i_kpe16"],
-                                   wc=L["t2i_wc"], bc=L["t2i_bc"])))
+                                   wc=L["t2i_wc"], bc=L["t2i_bc"])), cast16=q16)
             else:
                 hip.gemm_f16_resmod(keys_in, L["t2i_kv_w"], ws["kv"][:BT], L["t2i_kv_b"], L["t2i_kv_pe"], T_IMG, M=BT)
-                t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"])
+                t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                    cast16=q16)
             # ---- MLP (:180-183)
-            hip.add_cast(queries, out16=q16)
             hip.gemm_f16(q16, L["mlp1_w"], out=ws["mlp_h"][:M7], bias=L["mlp1_b"], act=hip.ACT_RELU)
             hip.gemm_f16(ws["mlp_h"][:M7], L["mlp2_w"], out=ws["tmp32"][:M7], bias=L["mlp2_b"], residual=queries)
-            hip.layernorm(ws["tmp32"][:M7], L["norm3_g"], L["norm3_b"], 1e-5, out=queries)
+            ln_queries(L["norm3_g"], L["norm3_b"])
             # ---- image -> token cross attention (:186-190): keys = LN4(keys + out_proj(attn))
-            cast_queries()
             stream = self.fused and self.i2t_stream
             kw, kb = (L["i2t_k_w_s"], L["i2t_k_b_s"]) if stream else (L["i2t_k_w"], L["i2t_k_b"])
             hip.gemm_f16(qpe16, kw, out=ws["i2t_k"][:M7], bias=kb)
@@ -446,24 +445,22 @@ class DecoderPlan:
                 hip.layernorm(keys_out[:BT], L["norm4_g"], L["norm4_b"], 1e-5, out=keys_out[:BT])
             keys_in, keys_out = keys_out, ws["keysB"]
         # ---- final token -> image attention (transformer.py:105-112)
-        F = self.final
-        cast_queries()
+        F = self.final                                   # qpe16 still holds fp16(queries + tokens0) from the last norm3
+        hs16 = ws["hs16"][:M7]
         if self.fused:
             t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
                 dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"],
-                     rank=dict(q_w_s=F["q_w_s"], q_b_s=F["q_b_s"], k_w=F["k_w"], kpe16=F["kpe16"], wc=F["wc"], bc=F["bc"])))
+                     rank=dict(q_w_s=F["q_w_s"], q_b_s=F["q_b_s"], k_w=F["k_w"], kpe16=F["kpe16"], wc=F["wc"], bc=F["bc"])),
+                cast16=hs16)
         else:
             hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
-            t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"])
+            t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], cast16=hs16)
         # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
         if not self.fused:
             up1 = ws["kv"]                                   # reuse [BT,256] f16
             hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
             hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
             hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
-        hs = queries.view(B, 7, 256)
-        hs16 = ws["hs16"][:M7]
-        hip.add_cast(queries, out16=hs16)
         tok16 = hs16.view(B, 7, 256)
         # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
         hh1, hh2 = ws["hh1"], ws["hh2"]

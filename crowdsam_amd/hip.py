@@ -24,6 +24,7 @@ _P, _I, _L, _F, _D = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_double
 SIGNATURES = {
     "csam_gemm_f16": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I],
     "csam_layernorm": [_P, _P, _L, _I, _P, _L, _I, _P, _P, _I, _I, _F],
+    "csam_layernorm_cast": [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P],
     "csam_sam_im2col": [_P, _P, _I, _I, _P, _P, _P],
     "csam_dino_im2col": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_im2col3x3": [_P, _P, _P, _I],
@@ -259,6 +260,18 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, M=None):
         out = torch.empty((M, D), dtype=out_dtype, device=x.device)
     call("csam_layernorm", _stream(), _ptr(x), x.stride(0), _dt(x.dtype), _ptr(out), out.stride(0),
          _dt(out.dtype), _ptr(gamma), _ptr(beta), M, D, float(eps))
+    return out
+
+
+def layernorm_cast(x, gamma, beta, eps, out, out16=None, pe=None, outpe16=None):
+    """out (fp32) = LayerNorm(x fp32 rows); out16 = fp16(out); outpe16 = fp16(out + pe): LayerNorm + add_cast x 2 in one
+    launch, same arithmetic.  All tensors contiguous [M, D]."""
+    M, D = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and x.dtype == torch.float32 and out.dtype == torch.float32
+    for t in (out16, pe, outpe16):
+        assert t is None or (t.is_contiguous() and tuple(t.shape) == (M, D))
+    call("csam_layernorm_cast", _stream(), _ptr(x), _ptr(gamma), _ptr(beta), M, D, float(eps), _ptr(out), _ptr(out16),
+         _ptr(pe), _ptr(outpe16))
     return out
 
 

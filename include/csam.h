@@ -71,6 +71,11 @@ int csam_linear_f32_batched(void* stream, const float* A, long lda, long strideA
  * transformer.py norm1-4). One wave per row, D % 4 == 0, D <= 1280. */
 int csam_layernorm(void* stream, const void* x, long ldx, int x_dtype, void* y, long ldy, int y_dtype,
                    const float* gamma, const float* beta, int M, int D, float eps);
+/* LayerNorm of contiguous fp32 rows with the casts of its consumers folded in (the decoder's token rows,
+ * transformer.py:164-190): y_f32 = LN(x); y_f16 = fp16(y) and ype_f16 = fp16(y + pe) when the pointers are given
+ * (pe fp32 [M,D]).  Same arithmetic, in the same order, as csam_layernorm followed by csam_add_cast. */
+int csam_layernorm_cast(void* stream, const float* x, const float* gamma, const float* beta, int M, int D, float eps,
+                        float* y_f32, void* y_f16_or_null, const float* pe_or_null, void* ype_f16_or_null);
 /* Sam.preprocess (sam.py:163-173) + PatchEmbed im2col (image_encoder.py:387-395): raw f32 CHW image
  * (h,w <= 1024) -> A f16 [4096,768]. mean3/std3 are HOST pointers to 3 floats. */
 int csam_sam_im2col(void* stream, const float* img_chw, int h, int w, const float* mean3, const float* std3,

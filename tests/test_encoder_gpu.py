@@ -28,6 +28,28 @@ def test_layernorm(cuda):
         assert (y - ref16).abs().max().item() < 2e-5
 
 
+def test_layernorm_cast_equals_layernorm_plus_add_cast(cuda):
+    """csam_layernorm_cast (the decoder's token LayerNorms with the fp16 operand copies of their consumers folded in) is
+    bit-identical to csam_layernorm followed by the two csam_add_cast launches it replaces."""
+    from crowdsam_amd import hip
+    g = torch.Generator().manual_seed(3)
+    for M, D in ((7, 256), (224, 256), (14336, 256), (5, 1024)):
+        x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(cuda)
+        pe = torch.randn(M, D, generator=g).to(cuda)
+        gm, bt = (torch.rand(D, generator=g) + 0.5).to(cuda), torch.randn(D, generator=g).to(cuda)
+        y = hip.layernorm(x, gm, bt, 1e-5, out_dtype=torch.float32)
+        y16 = torch.empty(M, D, dtype=torch.float16, device=cuda)
+        ype16 = torch.empty_like(y16)
+        hip.add_cast(y, out16=y16)
+        hip.add_cast(y, pe, D, out16=ype16)
+        o, o16, ope16 = torch.empty_like(y), torch.empty_like(y16), torch.empty_like(y16)
+        hip.layernorm_cast(x, gm, bt, 1e-5, o, out16=o16, pe=pe, outpe16=ope16)
+        assert torch.equal(o, y) and torch.equal(o16, y16) and torch.equal(ope16, ype16), (M, D)
+        o2 = torch.empty_like(y)
+        hip.layernorm_cast(x, gm, bt, 1e-5, o2)                  # both optional outputs off
+        assert torch.equal(o2, y)
+
+
 def _rel_bias(q, rel_h, rel_w, S):
     # q [nH, S*S, 64] fp32 -> bias [nH, S*S, S*S]   (image_encoder.py:325-361)
     idx = torch.arange(S, device=q.device)[:, None] - torch.arange(S, device=q.device)[None, :] + (S - 1)

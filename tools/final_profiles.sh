@@ -17,5 +17,6 @@ python tools/dev_bench_attn.py > gpurun_out/${TAG}_attn.txt 2>&1
 python bench.py --arch vit_h --grid 128 --frame 1500 --stability-thresh 0.0 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --crowd-keep 0 > gpurun_out/${TAG}_bench_stress_vith.json 2>> gpurun_out/${TAG}_bench.err
 bash tools/prof_bench.sh ${TAG}_bench --steps 10 --warmup 3 --crowd-keep 0
 bash tools/prof_bench.sh ${TAG}_encoder_only --encoder-only --steps 20 --warmup 3
+bash tools/prof_bench.sh ${TAG}_eps_mode --mode eps --grid 192 --points-per-batch 32 --stability-thresh 0.25 --steps 6 --warmup 3 --crowd-keep 0
 bash tools/collect_pmc.sh --crowd-keep 0
 bash tools/pmc_sq.sh 2048
