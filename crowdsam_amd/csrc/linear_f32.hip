@@ -68,12 +68,60 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   }
 }
 
+// N <= 4 (IoU head 256 -> 4, parallel IoU head -> 1, one-class point classifier): a 64-column tile would leave 60+ lanes
+// of every wave idle and spend 8 barrier pairs per 32 rows.  One wave per output row instead: the row's K values spread
+// over the lanes (4 consecutive per lane and step), N running sums per lane, one wave reduction at the end.
+template <int NMAX>
+__global__ __launch_bounds__(256) void linear_f32_rowdot_kernel(const float* __restrict__ A, long lda,
+                                                                const float* __restrict__ W, long ldw,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ R, long ldr,
+                                                                float* __restrict__ C, long ldc, int M, int N, int K,
+                                                                int act) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float acc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+  const float* a = A + (long)m * lda;
+  for (int k = lane * 4; k < K; k += 256) {            // K % 4 == 0, rows 16-B aligned (checked by the launcher)
+    const floatx4 av = *(const floatx4*)(a + k);
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      if (n < N) {
+        const floatx4 wv = *(const floatx4*)(W + (long)n * ldw + k);
+        acc[n] = fmaf(av[0], wv[0], acc[n]);
+        acc[n] = fmaf(av[1], wv[1], acc[n]);
+        acc[n] = fmaf(av[2], wv[2], acc[n]);
+        acc[n] = fmaf(av[3], wv[3], acc[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    if (n < N) {
+      const float sum = csam_wave_sum(acc[n]);
+      if (lane == 0) {
+        float v = csam_apply_act(sum + (bias ? bias[n] : 0.f), act);
+        if (R) v += R[(long)m * ldr + n];
+        C[(long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int csam_linear_f32(void* stream, const float* A, long lda, const float* W, long ldw,
                                const float* bias, const float* residual, long ldr, float* C, long ldc,
                                int M, int N, int K, int act) {
   CSAM_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "csam_linear_f32: bad args");
+  if (N <= 4 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((unsigned long)A & 15) == 0 && ((unsigned long)W & 15) == 0) {
+    hipLaunchKernelGGL(linear_f32_rowdot_kernel<4>, dim3(csam_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, A, lda, W,
+                       ldw, bias, residual, ldr, C, ldc, M, N, K, act);
+    CSAM_LAUNCH_CHECK("csam_linear_f32");
+    return CSAM_OK;
+  }
   dim3 grid(csam_cdiv(N, LBN), csam_cdiv(M, LBM));
   hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, bias, residual,
                      ldr, C, ldc, M, N, K, act, 0L, 0L, 0L, 0L);

@@ -89,3 +89,25 @@ def test_gemm_pingpong_256(cuda, M, N, K, act):
     assert torch.isfinite(out).all()
     err = (out.float() - ref).abs().max().item()
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 1, 256), (128, 4, 256), (16384, 1, 256), (50, 3, 512), (37, 5, 256), (200, 32, 256),
+                                   (9, 70, 96)])
+def test_linear_f32_small_heads(cuda, M, N, K):
+    """csam_linear_f32: the one-wave-per-row form (N <= 4: IoU / parallel-IoU / one-class classifier heads) and the tiled
+    form, with bias, ReLU, residual and a strided A, against fp64 torch."""
+    from crowdsam_amd import hip
+    g = torch.Generator().manual_seed(M * 131 + N)
+    a_full = torch.randn(M, 2 * K, generator=g).to(cuda)
+    a = a_full[:, :K]                                                  # row stride 2K
+    w, b = (torch.randn(N, K, generator=g) * 0.1).to(cuda), torch.randn(N, generator=g).to(cuda)
+    r = torch.randn(M, N, generator=g).to(cuda)
+    for act, res in ((hip.ACT_NONE, None), (hip.ACT_RELU, r)):
+        out = hip.linear_f32(a, w, b, act=act, residual=res, M=M, lda=a.stride(0))
+        ref = a.double() @ w.double().t() + b.double()
+        if act == hip.ACT_RELU:
+            ref = ref.clamp(min=0)
+        if res is not None:
+            ref = ref + res.double()
+        err = (out.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (M, N, K, err)
