@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
                                                          const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ traw,
                                                          half_t* __restrict__ out, long ldo, int T,
-                                                         float qmul, float bmul) {
+                                                         float qmul, float bmul, int xcd_heads) {
   // Scores live in BASE-2 units from the start: the caller's q already carries scale * log2(e) (folded into the qkv
   // projection, qmul == 1) or is multiplied by qmul here; the bias tables are multiplied by bmul.
   // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
@@ -88,8 +88,18 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
   __shared__ __attribute__((aligned(16))) char smem[FLASH_NS * 16384];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fg = lane >> 4;
-  const int head = blockIdx.y;
-  const int q0 = blockIdx.x * QPB + wave * QPW;
+  // XCD-aware order (nH % 8 == 0): workgroup b runs on XCD b % 8, and all query blocks of a head share its K / V^T
+  // (1.4 MB at T = 5330), so head h is served by XCD h % 8 only -- two heads' keys per 4 MB L2 instead of all sixteen
+  int head, qblk;
+  if (xcd_heads) {
+    const int b = blockIdx.x, x = b & 7, i = b >> 3, nqb = gridDim.x / (xcd_heads * 8);
+    head = x + 8 * (i / nqb);
+    qblk = i % nqb;
+  } else {
+    head = blockIdx.y;
+    qblk = blockIdx.x;
+  }
+  const int q0 = qblk * QPB + wave * QPW;
   const half_t* qp = qkv + q_off + head * 64;
   const half_t* kp = qkv + k_off + head * 64;
   const half_t* vtp = vt + (long)head * 64 * Tpad;
@@ -353,6 +363,13 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)qkv_f16, ld, v_off, (half_t*)vt_workspace, T, Tpad);
   dim3 grid(csam_cdiv(T, QPB), nH), block(256);
+  static int use_xcd = -1;
+  if (use_xcd < 0) {
+    const char* e = getenv("CSAM_FLASH_XCD");          // 0: plain (query block, head) grid, for A/B
+    use_xcd = e ? atoi(e) : 1;
+  }
+  const int xcd_heads = (use_xcd && nH % 8 == 0) ? nH / 8 : 0;
+  if (xcd_heads) grid = dim3(csam_cdiv(T, QPB) * nH);
   // q_prescaled: the caller folded scale * log2(e) into the q rows of the qkv projection (and relpos_raw was
   // computed from that q, so the bias tables carry the same factor and only 1/scale brings them to base-2 units)
   const float log2e = 1.4426950408889634f;
@@ -360,10 +377,12 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   const float bmul = q_prescaled ? 1.f / scale : log2e;
   if (relpos_raw)
     hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul,
+                       xcd_heads);
   else
     hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
-                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul);
+                       q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul,
+                       xcd_heads);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
   return CSAM_OK;
 }
