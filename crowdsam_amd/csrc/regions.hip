@@ -10,14 +10,19 @@
 // come out of the last kernel.
 //
 // Labelling is union-find over pixel indices (labels only ever decrease, roots are the raster-first pixel
-// of a component, so "first label on ties" == smallest root):
-//   init     one wave per 64-pixel row segment; a pixel's initial parent is the start of its horizontal
-//            run inside the segment (ballot + bit scan), so horizontal links inside a segment cost nothing;
-//   merge    the remaining links: segment-boundary west link, and north links pruned with the usual
-//            decision tree (a pixel whose west neighbour is set only needs NE when N is clear);
-//   count    path compression + per-root area with wave-aggregated atomics (16 rows per wave);
+// of a component, so "first label on ties" == smallest root), built in two levels (round 2):
+//   tile     a 64 x 64 tile is labelled in LDS: a pixel's initial parent is the start of its horizontal run (ballot +
+//            bit scan), north links come from the row bit masks with the usual decision tree (a pixel whose west
+//            neighbour is set only needs NE when N is clear), LDS union-find, then every pixel is written out pointing at
+//            its TILE root (global index);
+//   border   the links that cross a tile edge, ONE union per contact run (the background of a frame would otherwise send
+//            64 x 3 unions per edge at one root), on the global forest of tile roots;
+//   count    per tile: pixels counted per tile root in LDS (wave-aggregated), then only the tile roots walk the global
+//            forest, add their count to their global root's area and are re-pointed straight at it;
 //   flags    per-root: any small / any big / arg-max area (64-bit atomicMax of area:~root);
-//   apply    rewrites the mask;  extent: box extents of the final masks (block reduction, 4 atomics per block).
+//   apply    rewrites the mask (pixel -> tile root -> global root);  extent: box extents of the final masks.
+// 3 % of the pixels touch global atomics; on the noise-like masks of the benchmark's crowded-tail leg the two passes over 355
+// masks take 9.9 ms instead of 17.1 (CSAM_CC_TILE=0 runs the one-level form: init / merge / count kernels per pixel).
 #include "csam_common.h"
 #include <algorithm>
 
@@ -139,6 +144,230 @@ __global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict
   if (c) uf_union(Lm, p, p - W + 1);
 }
 
+// ---- tile form of init + merge.  A 64 x 64 tile is labelled in LDS (run starts from ballots, north links from the row
+// bit masks, union-find on a 16 KB LDS array), compressed, and written out as "global index of the tile-local root"; the
+// links that cross a tile edge (west at column 0, north at row 0, the two diagonals at columns 0 / 63 and row 0) are made
+// by cc_border_kernel on that forest with the global atomics of cc_merge_kernel.  Same components, same roots (the
+// raster-first pixel: raster order inside a tile is global order), 3 % of the pixels touch global atomics instead of all.
+__device__ __forceinline__ int lds_find(int* P, int i) {
+  int p;
+  while ((p = __atomic_load_n(P + i, __ATOMIC_RELAXED)) != i) i = p;
+  return i;
+}
+// find with path halving (see uf_find_halve for why the racy shortcut stores are safe)
+__device__ __forceinline__ int lds_find_halve(int* P, int i) {
+  int p = __atomic_load_n(P + i, __ATOMIC_RELAXED);
+  while (p != i) {
+    const int g = __atomic_load_n(P + p, __ATOMIC_RELAXED);
+    if (g == p) return p;
+    __atomic_store_n(P + i, g, __ATOMIC_RELAXED);
+    i = g;
+    p = __atomic_load_n(P + i, __ATOMIC_RELAXED);
+  }
+  return i;
+}
+__device__ __forceinline__ void lds_union(int* P, int a, int b) {
+  bool done;
+  do {
+    a = lds_find_halve(P, a);
+    b = lds_find_halve(P, b);
+    if (a < b) {
+      const int old = atomicMin(P + b, a);
+      done = (old == b);
+      b = old;
+    } else if (b < a) {
+      const int old = atomicMin(P + a, b);
+      done = (old == a);
+      a = old;
+    } else {
+      done = true;
+    }
+  } while (!done);
+}
+
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc_tile_kernel(const uint8_t* __restrict__ masks, int* __restrict__ L,
+                                                      int* __restrict__ S, int H, int W) {
+  __shared__ unsigned long long rowbits[64];
+  __shared__ int P[64 * 64];
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int ty = blockIdx.x / sw, tx = blockIdx.x - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = x0 + lane;
+  const uint8_t* m = masks + base;
+  // runs inside the row segment: parent = start of the horizontal run (as cc_init_kernel)
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i, y = y0 + r;
+    const bool wk = y < H && x < W && work_at<HOLES>(m, W, y, x);
+    const unsigned long long bits = __ballot(wk);
+    if (lane == 0) rowbits[r] = bits;
+    int lab = -1;
+    if (wk) {
+      const unsigned long long below = (lane == 0) ? 0ull : (~bits & ((1ull << lane) - 1ull));
+      const int start = below ? (64 - __clzll(below)) : 0;
+      lab = r * 64 + start;
+    }
+    P[r * 64 + lane] = lab;
+  }
+  __syncthreads();
+  // north links inside the tile, cc_merge_kernel's decision tree on the row bit masks
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i;
+    if (r == 0) continue;
+    const unsigned long long cur = rowbits[r], up = rowbits[r - 1];
+    if (!((cur >> lane) & 1ull)) continue;
+    const bool w = lane > 0 && ((cur >> (lane - 1)) & 1ull);
+    const bool b = (up >> lane) & 1ull;
+    const bool c = lane < 63 && ((up >> (lane + 1)) & 1ull);
+    const int p = r * 64 + lane;
+    if (w) {
+      if (c && !b) lds_union(P, p, p - 63);
+      continue;
+    }
+    if (b) {
+      lds_union(P, p, p - 64);
+      continue;
+    }
+    const bool a = lane > 0 && ((up >> (lane - 1)) & 1ull);
+    if (a) lds_union(P, p, p - 65);
+    if (c) lds_union(P, p, p - 63);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i, y = y0 + r;
+    if (y >= H || x >= W) continue;
+    int g = -1;
+    if (P[r * 64 + lane] >= 0) {
+      const int root = lds_find_halve(P, r * 64 + lane);
+      g = (y0 + (root >> 6)) * W + x0 + (root & 63);
+    }
+    const long q = base + (long)y * W + x;
+    L[q] = g;
+    S[q] = 0;
+  }
+}
+
+// Links across tile edges, ONE union per contact run: where a horizontal run of the row below a tile edge touches a run of
+// the row above it over k consecutive columns, the k N-links (and the diagonals next to them) all join the same two tile
+// components -- the background of a frame would otherwise send 64 x 3 unions per edge at one root -- so only the first
+// column of a contact run links; the same along vertical edges (first row of a vertical contact run).  A diagonal links
+// only where no straight contact next to it already does the job.
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc_border_kernel(const uint8_t* __restrict__ masks, int* __restrict__ L, int H,
+                                                        int W) {
+  const long base = (long)blockIdx.y * H * W;
+  const uint8_t* m = masks + base;
+  int* Lm = L + base;
+  auto at = [&](int y, int x) -> bool { return y >= 0 && x >= 0 && x < W && y < H && work_at<HOLES>(m, W, y, x); };
+  // two waves per tile: the first walks the tile's first row (lane = column), the second its first / last column
+  // (lane = row)
+  const int sw = (W + 63) >> 6, tiles = ((H + 63) >> 6) * sw;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= 2 * tiles) return;
+  const int tile = wv < tiles ? wv : wv - tiles;
+  const int ty = tile / sw, tx = tile - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64;
+  if (wv < tiles) {                                     // the row below a horizontal tile edge (or row 0)
+    const int y = y0, x = x0 + lane;
+    const bool in = x < W;
+    const bool cur = in && at(y, x);
+    const bool up = in && at(y - 1, x);
+    const unsigned long long cb = __ballot(cur), ub = __ballot(up);
+    if (!cur) return;
+    const int p = y * W + x;
+    if (lane == 0 && at(y, x - 1)) uf_union(Lm, p, p - 1);                   // W across the vertical edge
+    if (y == 0) return;
+    const unsigned long long cn = cb & ub;                                   // straight (N) contacts of this segment
+    const bool n_here = (cn >> lane) & 1ull;
+    const bool n_left = lane > 0 && ((cn >> (lane - 1)) & 1ull);
+    const bool n_right = lane < 63 && ((cn >> (lane + 1)) & 1ull);
+    if (n_here) {
+      if (!n_left) uf_union(Lm, p, p - W);
+      return;
+    }
+    const bool upl = lane > 0 ? ((ub >> (lane - 1)) & 1ull) : at(y - 1, x0 - 1);
+    const bool upr = lane < 63 ? ((ub >> (lane + 1)) & 1ull) : at(y - 1, x0 + 64);
+    if (upl && !n_left) uf_union(Lm, p, p - W - 1);
+    if (upr && !n_right) uf_union(Lm, p, p - W + 1);
+    return;
+  }
+  // other rows of the tile: only the columns next to a vertical tile edge
+  const int y = y0 + lane;
+  if (lane == 0 || y >= H) return;
+  if (at(y, x0)) {                                      // first column: W / NW into the tile on the left
+    const int p = y * W + x0;
+    const bool n = at(y - 1, x0);                       // same tile: linked locally
+    if (at(y, x0 - 1)) {
+      if (!(n && at(y - 1, x0 - 1))) uf_union(Lm, p, p - 1);                // first row of a vertical W-contact run
+    } else if (!n && at(y - 1, x0 - 1)) {
+      uf_union(Lm, p, p - W - 1);                                           // NW only where neither W nor N carries it
+    }
+  }
+  const int xr = x0 + 63;                               // last column: NE into the tile on the right
+  if (xr + 1 < W && at(y, xr) && !at(y - 1, xr) && !at(y, xr + 1) && at(y - 1, xr + 1)) {
+    const int p = y * W + xr;
+    uf_union(Lm, p, p - W + 1);
+  }
+}
+
+// Areas on the tile forest.  After cc_tile_kernel every pixel points at its TILE root, so a tile's pixels are counted per
+// tile root in LDS (wave-aggregated), and only the tile roots walk the global forest: each adds its count to its global
+// root's area and is re-pointed straight at it.  Pixels keep their tile root; cc_apply_kernel takes the second hop.
+__global__ __launch_bounds__(256) void cc_count_tile_kernel(int* __restrict__ L, int* __restrict__ S, int H, int W) {
+  __shared__ int cnt[64 * 64];
+  const long base = (long)blockIdx.y * H * W;
+  const int sw = (W + 63) >> 6;
+  const int ty = blockIdx.x / sw, tx = blockIdx.x - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64, origin = y0 * W + x0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const float inv_w = 1.0f / (float)W;
+  const int x = x0 + lane;
+  for (int i = 0; i < 16; ++i) {
+    const int y = y0 + wave * 16 + i;
+    int r = -1;
+    if (y < H && x < W) r = L[base + (long)y * W + x];
+    unsigned long long active = __ballot(r >= 0);
+    while (active) {
+      const int leader = __ffsll((long long)active) - 1;
+      const int rl = __shfl(r, leader);
+      const unsigned long long same = __ballot(r == rl);
+      if (lane == leader) {
+        // cc_border_kernel's path halving may have re-pointed an edge pixel at a root in ANOTHER tile: those go to the
+        // global forest directly (a few per tile edge)
+        const int d = rl - origin;
+        int row = -1, col = -1;
+        if (d >= 0 && d < 64 * W) {                     // < 2^24: the float quotient is off by at most one
+          row = (int)((float)d * inv_w);
+          if (row * W > d) --row;
+          if ((row + 1) * W <= d) ++row;
+          col = d - row * W;
+        }
+        if (row >= 0 && row < 64 && col >= 0 && col < 64) {
+          atomicAdd(&cnt[row * 64 + col], (int)__popcll(same));
+        } else {
+          atomicAdd(S + base + uf_find(L + base, rl), (int)__popcll(same));
+        }
+      }
+      active &= ~same;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = cnt[i];
+    if (c == 0) continue;
+    const int q = (y0 + (i >> 6)) * W + x0 + (i & 63);
+    const int g = uf_find(L + base, q);
+    if (g != q) L[base + q] = g;
+    atomicAdd(S + base + g, c);
+  }
+}
+
 // Path compression + per-root area.  A wave walks CC_ROWS vertically consecutive row segments and keeps a running
 // (root, count) pair, so a solid region costs one atomic per 64 x CC_ROWS pixels instead of one per segment.
 constexpr int CC_ROWS = 16;
@@ -239,7 +468,10 @@ __global__ __launch_bounds__(256) void cc_apply_kernel(const uint8_t* in, uint8_
     const int p = s.y * W + s.x;
     v = in[base + p] != 0;
     if (mm.any_small) {
-      const int r = L[base + p];
+      int r = L[base + p];
+      // tile root -> global root: one more hop for almost every pixel (cc_count_tile_kernel points the counted tile roots
+      // straight at their global root); a tile root nobody of its own tile points at any more keeps its chain
+      if (r >= 0) r = uf_find(L + base, r);
       if (HOLES) {
         if (r >= 0 && S[base + r] < thresh) v = true;
       } else if (r >= 0) {
@@ -409,17 +641,38 @@ extern "C" int csam_small_regions(void* stream_, const uint8_t* masks, uint8_t* 
   // chunked reductions (flags, extents): enough blocks to fill the chip whatever n is
   const dim3 rgrid(std::min(std::min(std::max(1024 / n, 16), 256), std::max(1, segs / 8)), n);
   const dim3 cgrid(csam_cdiv(csam_cdiv(H, CC_ROWS) * ((W + 63) >> 6), 4), n);
+  static int tiled = -1;
+  if (tiled < 0) {
+    const char* e = getenv("CSAM_CC_TILE");            // 0: per-pixel global union-find (init + merge kernels), for A/B
+    tiled = e ? atoi(e) : 1;
+  }
+  const dim3 tgrid(csam_cdiv(H, 64) * ((W + 63) >> 6), n);
+  const dim3 bgrid(csam_cdiv(2 * (int)tgrid.x, 4), n);
   hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);
   // pass 1: holes (components of the complement)
-  hipLaunchKernelGGL(cc_init_kernel<1>, grid, block, 0, stream, masks, L, S, H, W);
-  hipLaunchKernelGGL(cc_merge_kernel<1>, grid, block, 0, stream, masks, L, H, W);
-  hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  if (tiled) {
+    hipLaunchKernelGGL(cc_tile_kernel<1>, tgrid, block, 0, stream, masks, L, S, H, W);
+    hipLaunchKernelGGL(cc_border_kernel<1>, bgrid, block, 0, stream, masks, L, H, W);
+    if (tiled == 2) hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+    else hipLaunchKernelGGL(cc_count_tile_kernel, tgrid, block, 0, stream, L, S, H, W);
+  } else {
+    hipLaunchKernelGGL(cc_init_kernel<1>, grid, block, 0, stream, masks, L, S, H, W);
+    hipLaunchKernelGGL(cc_merge_kernel<1>, grid, block, 0, stream, masks, L, H, W);
+    hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  }
   hipLaunchKernelGGL(cc_flags_kernel, rgrid, block, 0, stream, L, S, meta, H, W, min_area);
   hipLaunchKernelGGL(cc_apply_kernel<1>, grid, block, 0, stream, masks, out, L, S, meta, H, W, min_area);
   // pass 2: islands (components of the hole-filled mask)
-  hipLaunchKernelGGL(cc_init_kernel<0>, grid, block, 0, stream, out, L, S, H, W);
-  hipLaunchKernelGGL(cc_merge_kernel<0>, grid, block, 0, stream, out, L, H, W);
-  hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  if (tiled) {
+    hipLaunchKernelGGL(cc_tile_kernel<0>, tgrid, block, 0, stream, out, L, S, H, W);
+    hipLaunchKernelGGL(cc_border_kernel<0>, bgrid, block, 0, stream, out, L, H, W);
+    if (tiled == 2) hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+    else hipLaunchKernelGGL(cc_count_tile_kernel, tgrid, block, 0, stream, L, S, H, W);
+  } else {
+    hipLaunchKernelGGL(cc_init_kernel<0>, grid, block, 0, stream, out, L, S, H, W);
+    hipLaunchKernelGGL(cc_merge_kernel<0>, grid, block, 0, stream, out, L, H, W);
+    hipLaunchKernelGGL(cc_count_kernel, cgrid, block, 0, stream, L, S, H, W);
+  }
   hipLaunchKernelGGL(cc_flags_kernel, rgrid, block, 0, stream, L, S, meta + n, H, W, min_area);
   hipLaunchKernelGGL(cc_apply_kernel<0>, grid, block, 0, stream, out, out, L, S, meta + n, H, W, min_area);
   hipLaunchKernelGGL(cc_extent_kernel, rgrid, block, 0, stream, out, ext, H, W);

@@ -76,3 +76,45 @@ def test_in_place_and_many(cuda):
     assert np.array_equal(out.cpu().numpy().astype(bool), ro)
     assert np.array_equal(changed.cpu().numpy(), rc)
     assert np.array_equal(boxes.cpu().numpy(), rb)
+
+
+def test_tile_edges(cuda):
+    """Patterns aimed at the 64 x 64 tile decomposition of the labelling (tile-local union-find + cross-edge links with one
+    union per contact run): components that live only on tile edges and corners, anti-diagonals through tile corners, thin
+    chains of single-pixel tile components, a frame-spanning background, sizes that are not multiples of 64."""
+    H, W = 200, 330
+    m = []
+    a = np.zeros((H, W), bool)                    # lines ON the tile edges (rows / columns 63, 64, 127, 128 ...)
+    a[63::64, :] = True
+    a[:, 64::64] = True
+    m.append(a)
+    b = np.zeros((H, W), bool)                    # anti-diagonal: crosses tile corners NE <-> SW (8-connectivity only)
+    idx = np.arange(min(H, W))
+    b[idx, W - 1 - idx] = True
+    b[idx[:-1], W - 3 - idx[:-1]] = True
+    m.append(b)
+    c = np.zeros((H, W), bool)                    # isolated pixels in the four corners of every tile + a staircase
+    for dy in (0, 63):
+        for dx in (0, 63):
+            c[dy::64, dx::64] = True
+    for k in range(0, min(H, W) - 1):
+        c[k, k] = True
+        c[k, k + 1] = True
+    m.append(c)
+    d = np.ones((H, W), bool)                     # background-like: everything set except small holes on the edges
+    d[60:68, 60:68] = False
+    d[126:130, 10:300:7] = False
+    d[5:195:9, 127:129] = False
+    m.append(d)
+    rng = np.random.RandomState(3)
+    e = rng.rand(H, W) > 0.45                     # noise with a band of single-pixel-wide vertical strokes over an edge
+    e[:, 62:66] = False
+    e[::2, 63] = True
+    e[1::2, 64] = True
+    m.append(e)
+    masks = np.stack(m)
+    for min_area in (100, 3, 40000):
+        _check(cuda, masks, min_area)
+    big = np.stack([np.kron(rng.rand(16, 16) > 0.5, np.ones((64, 64), bool)),       # whole tiles on / off, 1024 x 1024
+                    rng.rand(1024, 1024) > 0.5])
+    _check(cuda, big, 100)
