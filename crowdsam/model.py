@@ -26,7 +26,8 @@ import torch
 import crowdsam.utils as utils
 from crowdsam_amd import hip
 from crowdsam_amd.dino import DinoV2
-from segment_anything_cs.utils.amg import MaskData, coco_encode_rle, generate_crop_boxes, mask_to_rle_arrays
+from segment_anything_cs.utils.amg import (MaskData, coco_encode_rle, coco_encode_rles, generate_crop_boxes,
+                                           mask_to_rle_arrays)
 
 
 def box_area(b):
@@ -177,7 +178,7 @@ class CrowdSAM:
             data["points"] = torch.zeros(0, 2)
             data["stability_score"] = torch.zeros(0)
             data["fboxes"] = torch.zeros(0, 4)
-        data["rles"] = [coco_encode_rle(r) for r in data["rles"]] if "rles" in data else []
+        data["rles"] = coco_encode_rles(data["rles"]) if "rles" in data else []
         data.to_numpy()
         return data
 

@@ -35,5 +35,19 @@ long csam_coco_rle_string(const long long* counts, long n, char* out, long cap) 
   }
   return p;
 }
+// n strings in one call: counts = the run lengths of all masks back to back, offs[n + 1] their boundaries; the strings
+// go to `out` back to back with their boundaries in out_offs[n + 1].  Returns the total length or -1 (cap too small).
+long csam_coco_rle_strings(const long long* counts, const long long* offs, long n, char* out, long cap,
+                           long long* out_offs) {
+  long p = 0;
+  for (long m = 0; m < n; ++m) {
+    out_offs[m] = p;
+    const long r = csam_coco_rle_string(counts + offs[m], (long)(offs[m + 1] - offs[m]), out + p, cap - p);
+    if (r < 0) return -1;
+    p += r;
+  }
+  out_offs[n] = p;
+  return p;
+}
 const char* csam_last_error(void) { return g_err; }
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
 }
 LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
+    "csam_coco_rle_strings": [_P, _P, _L, _P, _L, _P],
     "csam_attn_t2i_workspace_bytes": [_I, _I],
     "csam_box_nms_workspace_bytes": [_I],
     "csam_mask_nms_workspace_bytes": [_I],
@@ -782,6 +783,29 @@ def mask_write(lowres, sel, keep, B, in_hw, out_hw, thr, out_mask, tmp=None, slo
     """Second pass: mask bytes of the prompts with keep[b] != 0, at out_mask[b] or out_mask[slot[b]]."""
     call("csam_mask_write", _stream(), _ptr(lowres), _ptr(sel), _ptr(keep), _ptr(slot), B, in_hw[0], in_hw[1], out_hw[0],
          out_hw[1], float(thr), _ptr(out_mask), _ptr(tmp))
+
+
+def coco_rle_strings(counts_list):
+    """Host helper: COCO compressed-RLE strings of many masks in ONE C call (run-length arrays -> list of str)."""
+    import numpy as np
+    n = len(counts_list)
+    if n == 0:
+        return []
+    sizes = np.fromiter((len(c) for c in counts_list), dtype=np.int64, count=n)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offs[1:])
+    allc = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.int64) for c in counts_list]), dtype=np.int64) \
+        if offs[-1] else np.zeros(1, np.int64)
+    cap = int(offs[-1]) * 13 + 1
+    buf = ctypes.create_string_buffer(cap)
+    out_offs = np.zeros(n + 1, dtype=np.int64)
+    tot = lib().csam_coco_rle_strings(allc.ctypes.data_as(_P), offs.ctypes.data_as(_P), n, buf, cap,
+                                      out_offs.ctypes.data_as(_P))
+    if tot < 0:
+        raise RuntimeError("csam_coco_rle_strings: buffer too small")
+    raw = buf.raw[:tot].decode("ascii")
+    o = out_offs.tolist()
+    return [raw[o[i]:o[i + 1]] for i in range(n)]
 
 
 def coco_rle_string(counts):

@@ -321,6 +321,10 @@ int csam_mask_mean_bilinear(void* stream, const uint8_t* masks, int n, int H, in
 /* host helper (HOST pointers): COCO compressed-RLE string of run lengths (amg.py:294-300 / pycocotools
  * rleToString); returns the length or -1 when cap is too small (13 chars per run always suffice) */
 long csam_coco_rle_string(const long long* counts, long n, char* out, long cap);
+/* the strings of n masks in one call (a crowded frame keeps hundreds of masks): counts back to back with boundaries
+ * offs[n + 1]; strings back to back in out with boundaries out_offs[n + 1]; returns the total length or -1 */
+long csam_coco_rle_strings(const long long* counts, const long long* offs, long n, char* out, long cap,
+                           long long* out_offs);
 
 #ifdef __cplusplus
 }

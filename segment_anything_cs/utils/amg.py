@@ -152,9 +152,29 @@ def mask_to_rle_arrays(tensor):
         m8 = (tensor.view(torch.uint8) if tensor.dtype == torch.bool else tensor.to(torch.uint8)).contiguous()
         pos, offs = hip.rle_encode(m8)
         pos = pos.cpu().numpy().astype(np.int64)
-        first = m8[:, 0, 0].cpu().numpy()
-        return [{"size": [h, w], "counts": _runs_from_positions(pos[offs[i]:offs[i + 1]], bool(first[i]), h * w)}
-                for i in range(b)]
+        first = m8[:, 0, 0].cpu().numpy().astype(bool)
+        # run lengths of ALL masks in one pass (a crowded frame keeps hundreds of masks: per-mask numpy calls were the
+        # tail's largest host cost): per mask the sequence [0 if the first pixel is set] 0 pos... hw, differenced
+        offs = np.asarray(offs, dtype=np.int64)
+        npos = offs[1:] - offs[:-1]
+        seg = npos + 2 + first                        # entries of mask i in the boundary array
+        so = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(seg, out=so[1:])
+        bounds = np.empty(int(so[-1]), dtype=np.int64)
+        lead = so[:-1] + first                        # index of the "0" that precedes the positions
+        bounds[so[:-1]] = 0                           # (for first-set masks: the extra leading 0 -> a zero-length run)
+        bounds[lead] = 0
+        bounds[so[1:] - 1] = h * w
+        keep = np.ones(int(so[-1]), dtype=bool)
+        keep[so[:-1]] = False
+        keep[lead] = False
+        keep[so[1:] - 1] = False
+        bounds[keep] = pos[: int(offs[-1])]
+        runs = np.diff(bounds)                        # the difference across a mask boundary lands on a dropped slot
+        out = []
+        for i in range(b):
+            out.append({"size": [h, w], "counts": runs[so[i]: so[i + 1] - 1]})
+        return out
     arr = tensor.numpy().astype(bool)
     out = []
     for i in range(b):
@@ -214,6 +234,12 @@ def coco_rle_string(counts):
     offset by 48, runs after the third delta-coded against counts[i-2]).  A crowded frame carries 1e5+ runs, so
     the byte loop is the C host helper csam_coco_rle_string (pycocotools is C in the reference as well)."""
     return hip.coco_rle_string(counts)
+
+
+def coco_encode_rles(uncompressed_rles):
+    """coco_encode_rle for a list of masks with one call into the C string packer."""
+    strings = hip.coco_rle_strings([r["counts"] for r in uncompressed_rles])
+    return [{"size": list(r["size"]), "counts": st} for r, st in zip(uncompressed_rles, strings)]
 
 
 def coco_encode_rle(uncompressed_rle):

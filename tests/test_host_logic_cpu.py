@@ -162,3 +162,19 @@ def test_index_shuffle_equals_row_shuffle():
         np.random.shuffle(perm)
         nxt_b = np.random.randint(0, 1 << 30)
         assert np.array_equal(a, pts[perm]) and nxt_a == nxt_b, n
+
+
+def test_batched_coco_strings_equal_per_mask_strings():
+    """amg.coco_encode_rles (one call into the C packer for all masks of a frame) against coco_encode_rle per mask and the
+    oracle's pure-Python packer; empty list, an all-zero mask (a single run), a first-pixel-set mask (leading zero run)."""
+    rs = np.random.RandomState(11)
+    m = torch.from_numpy(rs.rand(7, 29, 41) > 0.55)
+    m[2] = False
+    m[3] = True
+    m[4, 0, 0] = True
+    rles = amg.mask_to_rle_arrays(m)
+    batch = amg.coco_encode_rles(rles)
+    assert len(batch) == 7 and amg.coco_encode_rles([]) == []
+    for r, b in zip(rles, batch):
+        assert b == amg.coco_encode_rle(r)
+        assert b["counts"] == po.coco_rle_string([int(c) for c in r["counts"]])
