@@ -445,7 +445,10 @@ class CrowdSAM:
         edited = keep[scores[keep] == 0]
         if edited.numel():
             mask_data["boxes"][edited] = boxes[edited].to(mask_data["boxes"].dtype)
-            mask_data["masks"][edited] = new_masks[edited].to(masks.dtype)
+            # the cleaned-up stack as a whole instead of a gather + scatter of the edited masks (hundreds of MB on a crowded
+            # frame): a mask the clean-up did not change is returned unchanged, and only `keep` survives the filter below
+            mask_data["masks"] = new_masks.view(masks.dtype) if new_masks.element_size() == masks.element_size() \
+                else new_masks.to(masks.dtype)
         mask_data.filter(keep)
         return mask_data
 

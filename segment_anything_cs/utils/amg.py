@@ -62,16 +62,24 @@ class MaskData:
             else:
                 raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
 
+    @staticmethod
+    def _copy(v):
+        """deepcopy of amg.py:72-83, except that the per-mask RLE dicts of a list are copied one level deep: their run-length
+        arrays are never modified in place, and deep-copying several hundred of them per crowded frame was 3 ms of host time"""
+        if isinstance(v, list) and v and all(isinstance(r, dict) for r in v):
+            return [dict(r) for r in v]
+        return deepcopy(v)
+
     def cat(self, new_stats):
         for k, v in new_stats.items():
             if k not in self._stats or self._stats[k] is None:
-                self._stats[k] = deepcopy(v)
+                self._stats[k] = self._copy(v)
             elif isinstance(v, torch.Tensor):
                 self._stats[k] = torch.cat([self._stats[k], v], dim=0)
             elif isinstance(v, np.ndarray):
                 self._stats[k] = np.concatenate([self._stats[k], v], axis=0)
             elif isinstance(v, list):
-                self._stats[k] = self._stats[k] + deepcopy(v)
+                self._stats[k] = self._stats[k] + self._copy(v)
             else:
                 raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
 
