@@ -233,7 +233,9 @@ class CrowdSAM:
         orig_h, orig_w = self.orig_image.shape[:2]
         dev = self.device
         prune = math.isfinite(self.filter_thresh)
-        dev_sampler = prune and self.eps_on_device
+        # the device-resident sampler also serves the sweep without pruning (filter_thresh = inf): the point list never
+        # visits the host, the rounds simply skip csam_occupancy_prune
+        dev_sampler = self.eps_on_device
         points_for_image = self.sample_prompts(on_device=dev_sampler)
         t0 = self._tick("sample_prompts", t0)
         store = self._result_store(*self.predictor.original_size)
@@ -281,11 +283,12 @@ class CrowdSAM:
                 hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
                 bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
                                          device_batch=(pts_b, coords_b, counts[:1]))
-                hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
+                if prune:
+                    hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
                 count += B
                 n_batches += 1
                 self._tick("eps.batch", tb)
-                if n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
+                if prune and n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
                     if int(counts[1].item()) == 0:        # nothing was left behind this round's selection
                         break
         else:
