@@ -2282,7 +2282,10 @@ __global__ __launch_bounds__(256) void t2i_rank_prep_kernel(const half_t* __rest
   }
 }
 
-__global__ __launch_bounds__(256, 2) void t2i_rank_kernel(T2rArgs p, int prompts_per_wg) {
+#ifndef T2R_OCC
+#define T2R_OCC 2
+#endif
+__global__ __launch_bounds__(256, T2R_OCC) void t2i_rank_kernel(T2rArgs p, int prompts_per_wg) {
   constexpr int MI = T2S_MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2455,7 +2458,7 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
   }
-  const int per = csam_cdiv(B, 2 * n_cu);           // whole prompts per workgroup, two workgroups per CU
+  const int per = csam_cdiv(B, T2R_OCC * n_cu);     // whole prompts per workgroup, T2R_OCC workgroups per CU
   hipLaunchKernelGGL(t2i_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
   CSAM_LAUNCH_CHECK("csam_t2i_rank");
   return CSAM_OK;
