@@ -307,6 +307,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // the wave's 4 x 4 bias values (columns wc*64 + j*16 + fg*4 ..): fetched now, under the whole main loop, instead of by
+  // 32 loads at the head of the epilogue where nothing covers their latency
+  floatx4 bz[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bz[j] = p.bias ? *(const floatx4*)(p.bias + bn0 + (wave & 3) * 64 + j * 16 + (lane >> 4) * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
   const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
   const int a_base = (wr * 128 + fr) * 64 + coff;                 // + i * 1024 per 16-row tile
   const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
@@ -384,8 +390,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = wc * 64 + j * 16 + fg * 4;
-      floatx4 v = acc[i][j];
-      if (p.bias) v += *(const floatx4*)(p.bias + bn0 + col);
+      floatx4 v = acc[i][j] + bz[j];
       if (p.act == CSAM_ACT_GELU) {
         const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
         v = floatx4{g0[0], g0[1], g1[0], g1[1]};
