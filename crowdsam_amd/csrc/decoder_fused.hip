@@ -765,25 +765,28 @@ __global__ __launch_bounds__(256) void i2t_rank_prep_kernel(const half_t* __rest
 //     (X Wq_h^T) . k_b[j,h] = X . Kp_b[(h, j), :],    Kp_b[8 h + j][c] = sum_d ks[b][j][16 h + d] Wq[16 h + d][c]   (j = 7: zero)
 // so the q projection of the 4096 image tokens is never formed: 56 back-projected token keys per prompt instead.
 __global__ __launch_bounds__(256) void i2t_rank_kp_kernel(const half_t* __restrict__ ks, const half_t* __restrict__ Wq,
-                                                          half_t* __restrict__ Kp) {
+                                                          half_t* __restrict__ Kp, int B) {
   __shared__ float kk[7 * 128];
-  const int b = blockIdx.x, c = threadIdx.x;
-  for (int i = c; i < 7 * 128; i += 256) kk[i] = (float)ks[(long)b * 7 * 128 + i];
-  __syncthreads();
-  half_t* dst = Kp + (long)b * 64 * 256 + c;
-#pragma unroll 1
-  for (int head = 0; head < 8; ++head) {
-    float w[16];
+  const int c = threadIdx.x;
+  float w[128];                                   // column c of Wq, kept over the workgroup's prompts
 #pragma unroll
-    for (int d = 0; d < 16; ++d) w[d] = (float)Wq[(long)(head * 16 + d) * 256 + c];
+  for (int r = 0; r < 128; ++r) w[r] = (float)Wq[(long)r * 256 + c];
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = c; i < 7 * 128; i += 256) kk[i] = (float)ks[(long)b * 7 * 128 + i];
+    __syncthreads();
+    half_t* dst = Kp + (long)b * 64 * 256 + c;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float acc = 0.f;
-      if (j < 7) {
+    for (int head = 0; head < 8; ++head) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) acc = fmaf(w[d], kk[j * 128 + head * 16 + d], acc);
+      for (int j = 0; j < 8; ++j) {
+        float acc = 0.f;
+        if (j < 7) {
+#pragma unroll
+          for (int d = 0; d < 16; ++d) acc = fmaf(w[head * 16 + d], kk[j * 128 + head * 16 + d], acc);
+        }
+        dst[(long)(head * 8 + j) * 256] = (half_t)acc;
       }
-      dst[(long)(head * 8 + j) * 256] = (half_t)acc;
     }
   }
 }
@@ -1044,10 +1047,11 @@ extern "C" int csam_i2t_rank_proj(void* stream, const void* X_f16, long x_prompt
   const int n_cu = ir_cus();
   half_t* Mws = (half_t*)workspace;
   half_t* Kpws = Mws + (long)B * 256 * 64;
+  const dim3 pgrid(B < 2 * n_cu ? B : 2 * n_cu);
   hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)v_f16,
                      (const half_t*)Wo_f16, Mws);
-  hipLaunchKernelGGL(i2t_rank_kp_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)k_scaled_f16,
-                     (const half_t*)Wq_f16, Kpws);
+  hipLaunchKernelGGL(i2t_rank_kp_kernel, pgrid, dim3(256), 0, (hipStream_t)stream, (const half_t*)k_scaled_f16,
+                     (const half_t*)Wq_f16, Kpws, B);
   IrArgs a;
   a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)qpe_f16; a.q_bstride = 0;
   a.ks = (const half_t*)k_scaled_f16; a.M = Mws; a.Kp = Kpws; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
@@ -2259,25 +2263,28 @@ __device__ __forceinline__ half4_t ds_tr_b64(const char* lds_ptr) {
 
 // Qp[b][16*w + 8*hh + j][c] = sum_d qs[b][j][(2w+hh)*16 + d] * Wk[(2w+hh)*16 + d][c]   (j = 7: zero row)
 __global__ __launch_bounds__(256) void t2i_rank_prep_kernel(const half_t* __restrict__ qs, const half_t* __restrict__ Wk,
-                                                            half_t* __restrict__ Qp) {
+                                                            half_t* __restrict__ Qp, int B) {
   __shared__ float q[7 * 128];
-  const int b = blockIdx.x, c = threadIdx.x;
-  for (int i = c; i < 7 * 128; i += 256) q[i] = (float)qs[(long)b * 7 * 128 + i];
-  __syncthreads();
-  half_t* dst = Qp + (long)b * 64 * 256 + c;
-#pragma unroll 1
-  for (int head = 0; head < 8; ++head) {
-    float w[16];
+  const int c = threadIdx.x;
+  float w[128];                                   // column c of Wk, kept over the workgroup's prompts
 #pragma unroll
-    for (int d = 0; d < 16; ++d) w[d] = (float)Wk[(long)(head * 16 + d) * 256 + c];
+  for (int r = 0; r < 128; ++r) w[r] = (float)Wk[(long)r * 256 + c];
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = c; i < 7 * 128; i += 256) q[i] = (float)qs[(long)b * 7 * 128 + i];
+    __syncthreads();
+    half_t* dst = Qp + (long)b * 64 * 256 + c;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float acc = 0.f;
-      if (j < 7) {
+    for (int head = 0; head < 8; ++head) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) acc = fmaf(w[d], q[j * 128 + head * 16 + d], acc);
+      for (int j = 0; j < 8; ++j) {
+        float acc = 0.f;
+        if (j < 7) {
+#pragma unroll
+          for (int d = 0; d < 16; ++d) acc = fmaf(w[head * 16 + d], q[j * 128 + head * 16 + d], acc);
+        }
+        dst[(long)(head * 8 + j) * 256] = (half_t)acc;        // head*8 + j == 16*(head>>1) + 8*(head&1) + j
       }
-      dst[(long)(head * 8 + j) * 256] = (half_t)acc;        // head*8 + j == 16*(head>>1) + 8*(head&1) + j
     }
   }
 }
@@ -2446,11 +2453,6 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
     csam_set_error("csam_t2i_rank: workspace too small (%ld < %ld)", workspace_bytes, (long)B * 64 * 256 * 2);
     return CSAM_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL(t2i_rank_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const half_t*)qs_f16,
-                     (const half_t*)Wk_f16, (half_t*)Qp_workspace);
-  T2rArgs a;
-  a.X = (const half_t*)X_f16; a.Qp = (const half_t*)Qp_workspace; a.qs = (const half_t*)qs_f16;
-  a.kpe = (const half_t*)kpe_f16; a.Y = (half_t*)Y_f16; a.B = B; a.T = T;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -2458,6 +2460,11 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
   }
+  hipLaunchKernelGGL(t2i_rank_prep_kernel, dim3(B < 2 * n_cu ? B : 2 * n_cu), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)qs_f16, (const half_t*)Wk_f16, (half_t*)Qp_workspace, B);
+  T2rArgs a;
+  a.X = (const half_t*)X_f16; a.Qp = (const half_t*)Qp_workspace; a.qs = (const half_t*)qs_f16;
+  a.kpe = (const half_t*)kpe_f16; a.Y = (half_t*)Y_f16; a.B = B; a.T = T;
   const int per = csam_cdiv(B, T2R_OCC * n_cu);     // whole prompts per workgroup, T2R_OCC workgroups per CU
   hipLaunchKernelGGL(t2i_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
   CSAM_LAUNCH_CHECK("csam_t2i_rank");
