@@ -116,6 +116,81 @@ def encoder_only(args, rank, world, dev, sam_sd):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun around it: spawn the N ranks (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1), forward their output, return the worst
+    exit code.  Rank 0 prints the JSON line; a rank that dies takes the others down instead of leaving them in a
+    collective."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if p.returncode != 0:
+                rc = rc or p.returncode
+                for q in alive:          # the exact children we started, never a pattern
+                    q.terminate()
+    if rc:
+        sys.exit(rc)
+
+
+def stub_run(args, rank, world):
+    """The measurement protocol of main() around a host no-op step on gloo ranks (no GPU): exercises the launcher, the
+    barrier / MAX-over-ranks timing and the row gather without the model."""
+    import torch.distributed as dist
+    from crowdsam_amd.distributed import detections_to_rows, gather_rows
+    if os.environ.get("CSAM_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group("gloo")
+    rows = []
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        time.sleep(0.002)
+        rows.append(detections_to_rows(rank * args.steps + i, np.array([[0, 0, 1, 1.0]], np.float32), np.array([0.5], np.float32)))
+    my = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rates = [args.steps / my]
+    if world > 1:
+        allrows = gather_rows(np.concatenate(rows))
+        assert len(allrows) == world * args.steps and bool(np.all(np.diff(allrows[:, 0]) >= 0))
+        t = torch.tensor([elapsed, 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        c = torch.tensor([args.steps / my], dtype=torch.float64)
+        cs = [torch.zeros_like(c) for _ in range(world)]
+        dist.all_gather(cs, c)
+        rates = [float(x) for x in cs]
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (launcher self-test, stub step)", "value": args.steps * world / elapsed,
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "per_rank_images_per_sec": rates}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,13 +213,21 @@ def main():
                     help="second measured leg (dense mode): ~this many masks per image survive NMS into the small-region "
                          "clean-up + RLE (box NMS off, score cut calibrated on the warm-up frames); 0 disables the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="launcher self-test (tests/test_bench_launcher_cpu.py): gloo ranks, a step is a host no-op")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way
+        # tools/batch_eval.py -n N does (reference: tools/batch_eval.py:80-95); rank 0 prints the one JSON line
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.stub_step:
+        return stub_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

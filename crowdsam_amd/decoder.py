@@ -215,7 +215,6 @@ class DecoderPlan:
         self.taps = _adjoint_taps().to(device)
         self.adj_tables = _adjoint_mfma_tables().to(device)
         self.state = None
-        self._static_in = None
         self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
 
@@ -282,17 +281,14 @@ class DecoderPlan:
             self._alloc_state()
         st = self.state
         L0 = self.layers[0]
-        # the per-image graph reads STATIC operand buffers: inputs living elsewhere (API path: predictor.features
-        # assigned by the caller, a fresh allocation per image) are copied in, so ONE graph serves every image (a
-        # graph keyed by the callers' data_ptr()s would grow without bound and could replay a recycled address)
-        if self._static_in is None:
-            self._static_in = (feat_tok, dino_tok16)            # the encoders' own static outputs: no copy
-        if feat_tok.data_ptr() != self._static_in[0].data_ptr():
+        # the per-image graph reads the plan's OWN operand buffers, and every call copies its inputs into them (4 MB +
+        # 11 MB device-to-device, a few microseconds) before the replay: a graph that captured the first caller's
+        # pointers would silently serve that caller's data to every later image / predictor.
+        if feat_tok.data_ptr() != st["feat"].data_ptr():
             st["feat"].copy_(feat_tok)
-            feat_tok = st["feat"]
-        if dino_tok16.data_ptr() != self._static_in[1].data_ptr():
+        if dino_tok16.data_ptr() != st["dtok"].data_ptr():
             st["dtok"].copy_(dino_tok16)
-            dino_tok16 = st["dtok"]
+        feat_tok, dino_tok16 = st["feat"], st["dtok"]
 
         def launch():
             hip.add_cast(feat_tok, self.no_mask, 0, out16=st["src16"], out32=st["src32"])

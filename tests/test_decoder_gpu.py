@@ -170,3 +170,28 @@ def test_upscale_stream_vs_oracle_fp32(cuda, B):
             assert err.mean().item() < 0.003 * scale and err.max().item() < 0.03 * scale, \
                 (b, err.mean().item(), err.max().item(), scale)
             assert torch.allclose(stats[sl.start * 4:sl.stop * 4, 0].cpu(), got.reshape(-1, 65536).max(1).values)
+
+
+def test_set_image_twice_with_fresh_tensors_is_not_stale(plan, cuda):
+    """the per-image hipGraph must read the plan's own operand buffers.  Two images in FRESH tensors (new
+    addresses, different contents): the second call's state must equal what a plan that never saw the first computes."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    rs = np.random.RandomState(5)
+    imgs = []
+    for _ in range(2):
+        feat = torch.from_numpy(rs.standard_normal((4096, 256)).astype(np.float32)).to(cuda)
+        dtok = torch.zeros(5376, 1024, dtype=torch.float16, device=cuda)
+        dtok[:5329] = torch.from_numpy(rs.standard_normal((5329, 1024)).astype(np.float32)).to(cuda).half()
+        imgs.append((feat, dtok))
+    coords = torch.tensor([[100.0, 200.0], [900.5, 31.0], [512.0, 512.0]], device=cuda)
+    plan.set_image(*imgs[0])
+    first = [t.clone() for t in plan.run_batch(coords)] + [plan.fg_logits().clone()]
+    plan.set_image(imgs[1][0].clone(), imgs[1][1].clone())                       # second image, fresh addresses
+    second = [t.clone() for t in plan.run_batch(coords)] + [plan.fg_logits().clone()]
+    fresh = DecoderPlan(synth.make_sam_state_dict("vit_test128"), cuda, n_class=1, max_batch=8)
+    fresh.set_image(*imgs[1])
+    want = list(fresh.run_batch(coords)) + [fresh.fg_logits()]
+    for a, b, c in zip(second, want, first):
+        assert torch.equal(a, b)
+        assert not torch.equal(a, c)
