@@ -65,7 +65,11 @@ class CrowdSAM:
         m = config["model"]
         if dino_model is None:
             # model.dino_depth: build extension for reduced-depth test checkpoints (DINOv2 ViT-L/14 has 24 blocks)
-            dino_model = DinoV2(depth=int(m.get("dino_depth", dino_depth)))
+            # model.dino_pos_offset: how the 37x37 learned position embedding reaches 73x73.  0.1 = the hub models'
+            # `interpolate_offset` form (F.interpolate(scale_factor=(73.1/37)), what torch.hub.load(dino_repo,
+            # 'dinov2_vitl14') of the reference's era builds -- the shipped default); null = the `size=(73,73)` form of
+            # newer upstream commits / transformers.  The submodule commit is not recorded: unpinned.
+            dino_model = DinoV2(depth=int(m.get("dino_depth", dino_depth)), pos_offset=m.get("dino_pos_offset", 0.1))
             if dino_state_dict is None:
                 dino_state_dict = torch.load(m["dino_checkpoint"], map_location="cpu")
             dino_model.load_state_dict(dino_state_dict)
@@ -102,9 +106,9 @@ class CrowdSAM:
             raise NotImplementedError("mask_selection='all' is broken in the reference (float tensor used as an index)")
         if self.mask_selection not in ("max_iou", "max_area", "min_area"):
             raise NotImplementedError(f"unknown mask_selection '{self.mask_selection}'")
-        if self.max_size > 1024:
-            # the mask post-processing kernels keep a 1024-pixel output row in registers (256 lanes x 4 pixels)
-            raise NotImplementedError("test.max_size > 1024 is not supported by the fused mask post-processing kernels")
+        if self.max_size > 4096:
+            # free knob as in the reference (crowdsam/utils.py:141-156) up to the RLE column scan's 4096-pixel row
+            raise NotImplementedError("test.max_size > 4096 is not supported (csam_rle_count scans rows of <= 4096 pixels)")
         if self.apply_box_offsets:
             raise NotImplementedError("apply_box_offsets is off in the shipped config (the decoder has no offset head)")
         self.timings = {}

@@ -98,12 +98,13 @@ constexpr int POST_RB = CSAM_POST_RB;   // row blocks per workgroup of the x4 st
 
 template <int MODE>
 __global__ __launch_bounds__(256) void mask_post_kernel(PostArgs a) {
-  // grid: (row chunks of POST_ROWS, 1, B); 256 threads x 4 pixels cover a row of up to 1024 pixels.
+  // grid: (row chunks of POST_ROWS, 1024-pixel column strips, B); 256 threads x 4 pixels cover one strip of a row, so
+  // the output width is free (test.max_size > 1024: crowdsam/utils.py:141-156 makes it a knob)
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   if (a.keep && !a.keep[b]) return;
   if (a.score && !(a.score[b] > a.score_thr)) return;
-  const int x4 = tid * 4;
+  const int x4 = (blockIdx.y * 256 + tid) * 4;
   const float* p = a.src + (long)b * a.src_bstride + (a.sel ? (long)a.sel[b] * a.plane : 0);
   int cnt_i = 0, cnt_u = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
   int x0[4], x1[4];
@@ -698,7 +699,7 @@ static int post_launch(hipStream_t s, const float* lowres, const int* sel, const
     a.src = tmp_f32; a.src_bstride = (long)in_h * in_w; a.plane = 0; a.sel = nullptr;
     a.sh = in_h; a.sw = in_w; a.scale_y = (float)in_h / (float)out_h; a.scale_x = (float)in_w / (float)out_w;
     a.H = out_h; a.W = out_w; a.out_f32 = nullptr; a.out_mask = (uint8_t*)out_mask_u8;
-    dim3 g1(csam_cdiv(out_h, POST_ROWS), 1, B);
+    dim3 g1(csam_cdiv(out_h, POST_ROWS), csam_cdiv(out_w, 1024), B);
     hipLaunchKernelGGL(mask_post_kernel<1>, g1, dim3(256), 0, s, a);
   }
   return CSAM_OK;
@@ -708,7 +709,7 @@ extern "C" int csam_mask_post(void* stream, const float* lowres, const int* sel,
                               int out_h, int out_w, float thr, float off, void* out_mask_u8, int* inter, int* uni,
                               int* box, float* tmp_f32) {
   CSAM_REQUIRE(lowres && sel && inter && uni && box && B > 0, "csam_mask_post: bad args");
-  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0,
                "csam_mask_post: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
@@ -725,7 +726,7 @@ extern "C" int csam_mask_post_scored(void* stream, const float* lowres, const in
                                      float score_thr, int B, int in_h, int in_w, int out_h, int out_w, float thr,
                                      float off, int* inter, int* uni, int* box, float* tmp_f32) {
   CSAM_REQUIRE(lowres && sel && score && inter && uni && box && B > 0, "csam_mask_post_scored: bad args");
-  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0,
                "csam_mask_post_scored: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(post_init_kernel, dim3(csam_cdiv(B, 256)), dim3(256), 0, s, inter, uni, box, B);
@@ -742,7 +743,7 @@ extern "C" int csam_mask_write(void* stream, const float* lowres, const int* sel
                                const int* slot_or_null, int B, int in_h, int in_w, int out_h, int out_w, float thr,
                                void* out_mask_u8, float* tmp_f32) {
   CSAM_REQUIRE(lowres && sel && out_mask_u8 && B > 0, "csam_mask_write: bad args");
-  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0 && out_w <= 1024,
+  CSAM_REQUIRE(in_h > 0 && in_w > 0 && in_h <= 1024 && in_w <= 1024 && out_h > 0 && out_w > 0,
                "csam_mask_write: bad sizes");
   const int rc = post_launch((hipStream_t)stream, lowres, sel, (const uint8_t*)keep_u8, slot_or_null, B, in_h, in_w,
                              out_h, out_w, thr, 0.f, out_mask_u8, nullptr, nullptr, nullptr, tmp_f32, 0);
@@ -762,8 +763,7 @@ extern "C" int csam_bilinear_f32(void* stream, const float* src, int n, int sh, 
   a.H = H; a.W = W; a.thr = 0.f; a.off = 0.f;
   a.out_f32 = dst; a.out_mask = nullptr; a.inter = nullptr; a.uni = nullptr; a.box = nullptr;
   a.keep = nullptr; a.slot = nullptr; a.stats = 0;
-  CSAM_REQUIRE(W <= 1024, "csam_bilinear_f32: W=%d > 1024", W);
-  dim3 grid(csam_cdiv(H, POST_ROWS), 1, n);
+  dim3 grid(csam_cdiv(H, POST_ROWS), csam_cdiv(W, 1024), n);
   hipLaunchKernelGGL(mask_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_bilinear_f32");
   return CSAM_OK;

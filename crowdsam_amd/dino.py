@@ -50,7 +50,7 @@ class DinoPlan:
         self.blocks = []
         # softmax scale and the base-2 conversion live in the q rows of the qkv projection (csam_flash_attn q_prescaled)
         qfold = torch.ones(3 * D, 1)
-        qfold[:D] = (64 ** -0.5) * hip.FLASH_QMUL
+        qfold[:D] = ((D // heads) ** -0.5) * hip.FLASH_QMUL     # the same head_dim forward() passes as `scale`
         for i in range(depth):
             B = f"blocks.{i}."
             self.blocks.append(dict(
@@ -82,7 +82,7 @@ class DinoPlan:
         D, nH, T = self.D, self.heads, T_DINO
         ws = self.ws
         x = ws["x"]
-        scale = 64 ** -0.5
+        scale = (D // nH) ** -0.5
         hip.dino_im2col(img_chw_f32, ws["col"], normalized_1022)
         x[0:1].copy_(self.cls_row)
         hip.gemm_f16(ws["col"], self.patch_w, out=x[1:], bias=self.patch_b, residual=self.pos[1:], M=5329)

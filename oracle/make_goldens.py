@@ -379,6 +379,83 @@ def golden_dino_hf():
                         err_vs_oracle_offset=np.array([e_off.max(), e_off.mean()]))
 
 
+def _hf_dino(depth=24):
+    from transformers import Dinov2Config, Dinov2Model
+    sd = synth.make_dino_state_dict()
+    cfg = Dinov2Config(hidden_size=1024, num_hidden_layers=depth, num_attention_heads=16, mlp_ratio=4, patch_size=14,
+                       image_size=518, qkv_bias=True, use_swiglu_ffn=False, layer_norm_eps=1e-6, hidden_act="gelu")
+    m = Dinov2Model(cfg).eval()
+    hf = {"embeddings.cls_token": sd["cls_token"], "embeddings.mask_token": sd["mask_token"],
+          "embeddings.position_embeddings": sd["pos_embed"],
+          "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(depth):
+        a, b = f"blocks.{i}.", f"encoder.layer.{i}."
+        qw, kw, vw = sd[a + "attn.qkv.weight"].chunk(3, 0)
+        qb, kb, vb = sd[a + "attn.qkv.bias"].chunk(3, 0)
+        for n, w, bb in (("query", qw, qb), ("key", kw, kb), ("value", vw, vb)):
+            hf[b + f"attention.attention.{n}.weight"], hf[b + f"attention.attention.{n}.bias"] = w, bb
+        for src, dst in (("norm1", "norm1"), ("norm2", "norm2"), ("attn.proj", "attention.output.dense"),
+                         ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            hf[b + dst + ".weight"], hf[b + dst + ".bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+        hf[b + "layer_scale1.lambda1"], hf[b + "layer_scale2.lambda1"] = sd[a + "ls1.gamma"], sd[a + "ls2.gamma"]
+    m.load_state_dict(hf, strict=True)
+    return m, sd
+
+
+def _hf_dino_offset_form(m, sd, xd, offset=0.1):
+    """transformers' DINOv2 blocks with the position embedding interpolated the way the dinov2 hub models of the
+    reference's era do it (interpolate_offset = 0.1: F.interpolate(scale_factor=((g + 0.1) / 37), bicubic) -- the form
+    `configs/crowdhuman_mi355x.yaml: model.dino_pos_offset: 0.1` ships): the block arithmetic is the independent
+    implementation, only the interpolated table is injected."""
+    from oracle import sam_oracle as so
+    gh, gw = xd.shape[2] // 14, xd.shape[3] // 14
+    table = so.dino_interp_pos_embed(sd["pos_embed"], gh, gw, offset)
+    m.embeddings.interpolate_pos_encoding = lambda emb, h, w: table.to(emb.dtype)
+    with torch.no_grad():
+        return m(pixel_values=xd, interpolate_pos_encoding=True).last_hidden_state[:, 1:]
+
+
+def full_frame(cfg_index):
+    """The frames of the full-composition GPU tests (tests/test_full_composition_gpu.py)."""
+    return synth.synthetic_crowd_frame(7, 1024, 150) if cfg_index == 2 else synth.synthetic_crowd_frame(4, 1500, 400)
+
+
+def golden_full_vitl():
+    """BASELINE configs[2] at full composition, stage outputs INSIDE the pipeline: the reference's 24-block ViT-L encoder
+    and (unpinned by nature, independent implementation) transformers' DINOv2-L x24 with the shipped (+0.1 offset)
+    position-embedding form, both on the preprocessed 1024^2 synthetic crowd frame the GPU test feeds CrowdSAM.generate."""
+    from oracle import sam_oracle as so
+    img = full_frame(2)
+    x = so.preprocess(torch.from_numpy(img).permute(2, 0, 1).float().contiguous())[None]
+    sam, sd, _ = load_ref_sam("vit_l")
+    with torch.no_grad():
+        y = sam.image_encoder(x)
+    m, dsd = _hf_dino()
+    xd = torch.nn.functional.interpolate(x, (1022, 1022), mode="bilinear")
+    d = _hf_dino_offset_form(m, dsd, xd)
+    np.savez_compressed(os.path.join(OUT, "full_vit_l.npz"), feat_sample=y[:, ::4, 1::4, 2::4].numpy(),
+                        feat_abs_sum=np.float64(y.double().abs().sum()), dino_sample=d[0, ::7, ::8].numpy(),
+                        dino_abs_sum=np.float64(d.double().abs().sum()))
+    print("full_vitl: |feat| %.4f |dino| %.4f" % (float(y.abs().mean()), float(d.abs().mean())))
+
+
+def golden_full_vith():
+    """BASELINE configs[4]: the reference's 32-block ViT-H encoder on the 1500^2 stress frame after the cv2-style
+    down-scale to 1024 (oracle/resize_oracle.py; the device resize is bit-exact against it: tests/test_resize_gpu.py)."""
+    from oracle import sam_oracle as so, resize_oracle as ro
+    img, _ = ro.resize_image(full_frame(4), 1024)[:2]
+    assert img.shape == (1024, 1024, 3)
+    x = so.preprocess(torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().contiguous())[None]
+    sam, sd, _ = load_ref_sam("vit_h")
+    with torch.no_grad():
+        y = sam.image_encoder(x)
+    np.savez_compressed(os.path.join(OUT, "full_vit_h.npz"), feat_sample=y[:, ::4, 1::4, 2::4].numpy(),
+                        feat_abs_sum=np.float64(y.double().abs().sum()))
+    print("full_vith: |feat| %.4f" % float(y.abs().mean()))
+
+
 def golden_pipeline_fuse():
     """Same run with test.fuse_simmap = True (crowdsam/model.py:273-286; its hard-coded .cuda() is the identity
     under the trap-2 shim)."""

@@ -49,9 +49,11 @@ class SamPredictor:
                     f32 = hip.u8hwc_to_f32chw(image)
                 return self.set_torch_image(f32[None], (h, w))
             th, tw = self.transform.get_preprocess_shape(h, w, size)
-            if mask is None and cal_image and max(h, w) < size and max(h, w) * 3.5 >= size:
+            if mask is None and cal_image and max(h, w) <= 3.5 * size:
                 # ResizeLongestSide.apply_image (PIL bilinear via torchvision, transforms.py:26-31) on the device: the
-                # 1023-pixel long side of SURVEY.md trap 9 (and any other enlargement) without a host round trip
+                # 1023-pixel long side of SURVEY.md trap 9, any other enlargement, and the shrink of a test.max_size >
+                # 1024 frame (Pillow widens the filter support to the shrink factor: <= 8 taps up to 3.5x) without a
+                # host round trip
                 from crowdsam_amd.resize import pil_bilinear_tables_device
                 dev = str(image.device)
                 _, f32 = hip.pil_resize_bilinear_u8(image.contiguous(), (th, tw), pil_bilinear_tables_device(w, tw, dev),

@@ -1,0 +1,92 @@
+"""BASELINE configs[2] and configs[4] at FULL composition through ``CrowdSAM.generate``:
+
+* configs[2]: SAM ViT-L x24 + DINOv2-L x24 + the 64x64 dense sweep on a 1024^2 synthetic crowd frame;
+* configs[4]: SAM ViT-H x32 + DINOv2-L x24 + the 128x128 dense sweep on a 1500^2 frame (device down-scale to 1024).
+
+Stage outputs are checked INSIDE the pipeline against tests/golden/full_vit_{l,h}.npz -- the reference's own encoder run
+on the same preprocessed frame, and transformers' DINOv2 blocks with the SHIPPED (+0.1 offset) position-embedding form
+(oracle/make_goldens.py::golden_full_vit{l,h}) -- and the result against the size-independent invariants of
+tests/test_stress_gpu.py (the oracle cannot finish 4096 / 16384 prompts in seconds)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(arch, grid, ppb):
+    from crowdsam.model import CrowdSAM
+    from crowdsam.utils import DEFAULT_TEST_CONFIG
+    from crowdsam_amd import synth
+    t = dict(DEFAULT_TEST_CONFIG)
+    t.update(grid_size=grid, points_per_batch=ppb, pos_sim_thresh=-float("inf"), filter_thresh=float("inf"),
+             max_prompts=grid * grid, stability_score_thresh=0.25, pred_iou_thresh=0.05)
+    cfg = {"environ": {"device": "cuda"}, "model": {"sam_model": arch, "sam_arch": "crowdsam", "n_class": 1,
+                                                    "trainfree": False, "dino_pos_offset": 0.1}, "test": t}
+    return CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict(arch), dino_state_dict=synth.make_dino_state_dict())
+
+
+def _invariants(m, img, cuda, frame, grid):
+    from crowdsam_amd import hip
+    from tests.test_stress_gpu import _decode, _rle_area_and_box
+    np.random.seed(0)
+    a = m.generate(img)
+    feats = m.predictor.features.float().cpu().numpy()                      # [1,256,64,64], this image's
+    dino = m.predictor.dino_feats.float().cpu().numpy().reshape(5329, 1024)
+    assert 0 < m.last_candidates <= grid * grid
+    np.random.seed(0)
+    b = m.generate(img)
+    for k in ("boxes", "scores", "points", "stability_score"):
+        assert np.array_equal(a[k], b[k]), k
+    assert [r["counts"] for r in a["rles"]] == [r["counts"] for r in b["rles"]]
+    boxes, scores = a["boxes"], a["scores"]
+    assert len(boxes) == len(scores) == len(a["rles"]) > 0
+    assert (boxes >= 0).all() and (boxes <= frame).all() and (a["points"] >= 0).all() and (a["points"] < frame).all()
+    assert (scores > 0.05).all() and (a["stability_score"] >= 0.25).all() and np.all(np.diff(scores) <= 0)
+    keep = hip.box_nms(torch.from_numpy(boxes).float().to(cuda), torch.from_numpy(scores).float().to(cuda), m.box_nms_thresh)
+    assert len(keep) == len(boxes)                                          # NMS idempotence
+    for i in range(0, len(boxes), max(1, len(boxes) // 6)):
+        rle = _decode(a["rles"][i]["counts"], *a["rles"][i]["size"])
+        area, bb = _rle_area_and_box(rle)
+        assert sum(rle["counts"]) == 1024 * 1024 and area > 0
+        np.testing.assert_allclose(boxes[i], np.array(bb, np.float32) / np.float32(m.downscale), rtol=1e-6)
+    return feats, dino
+
+
+def _check_feats(feats, g, mean_frac, max_frac, name):
+    ref = g["feat_sample"]
+    err = np.abs(feats[:, ::4, 1::4, 2::4] - ref)
+    scale = np.abs(ref).mean()
+    print("%s features inside the pipeline: mean|ref| %.4f  mean err %.5f (%.3f %%)  max err %.4f (%.2f %%)"
+          % (name, scale, err.mean(), 100 * err.mean() / scale, err.max(), 100 * err.max() / scale))
+    assert err.mean() < mean_frac * scale and err.max() < max_frac * scale, (err.mean() / scale, err.max() / scale)
+    assert abs(np.abs(feats.astype(np.float64)).sum() - float(g["feat_abs_sum"])) < 0.005 * float(g["feat_abs_sum"])
+
+
+def test_config2_vit_l_dinov2_l_grid64_full_composition(cuda):
+    from oracle.make_goldens import full_frame
+    g = np.load(os.path.join(G, "full_vit_l.npz"))
+    m = _model("vit_l", 64, 4096)
+    assert m.predictor.model.image_encoder.depth == 24 and m.predictor.dino_model.depth == 24
+    feats, dino = _invariants(m, full_frame(2), cuda, 1024, 64)
+    # measured on MI355X (r3): mean 0.21 % / max 2.2 % of mean |feature| -> bounds = measured x 2
+    _check_feats(feats, g, 0.005, 0.05, "ViT-L x24")
+    ref = g["dino_sample"]
+    err = np.abs(dino[::7, ::8] - ref)
+    scale = np.abs(ref).mean()
+    print("DINOv2-L x24 (+0.1 offset form, shipped) inside the pipeline: mean|ref| %.4f  mean err %.5f  max err %.4f"
+          % (scale, err.mean(), err.max()))
+    assert err.mean() < 0.01 * scale and err.max() < 0.1 * scale, (err.mean() / scale, err.max() / scale)
+
+
+def test_config4_vit_h_depth32_1500_frame_grid128_full_composition(cuda):
+    from oracle.make_goldens import full_frame
+    g = np.load(os.path.join(G, "full_vit_h.npz"))
+    m = _model("vit_h", 128, 4096)
+    assert m.predictor.model.image_encoder.depth == 32
+    feats, _ = _invariants(m, full_frame(4), cuda, 1500, 128)
+    assert abs(m.downscale - 1024 / 1500) < 1e-12 and m.image_hw == (1024, 1024)
+    _check_feats(feats, g, 0.005, 0.05, "ViT-H x32")

@@ -255,3 +255,37 @@ def test_generate_without_detections_and_area_selection(cuda):
         clear = (srt[:, -1] - srt[:, -2] > 200) if mode == "max_area" else (srt[:, 1] - srt[:, 0] > 200)
         assert clear.sum() >= 4
         np.testing.assert_allclose(o2["scores"][clear], ref_score[clear], rtol=0, atol=5e-3)
+
+
+def test_generate_max_size_1536_matches_oracle(cuda):
+    """test.max_size is a free knob in the reference (crowdsam/utils.py:141-156, configs/crowdhuman.yaml:50).  At 1536 the
+    768x1024 frame is cv2-enlarged to 1152x1536, Pillow-shrunk to 768x1024 for the encoder (device restatement, filter
+    support 1.5), and postprocess_masks' second interpolate goes 768x1024 -> 1152x1536 (mask_post column strips beyond
+    1024 pixels); masks, boxes and RLEs live in the 1152x1536 frame, boxes / points are divided by downscale 1.5."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle import pipeline_oracle as po
+    from oracle.make_goldens import PIPE_CFG, StandInDino, pipeline_image
+    cfg = dict(PIPE_CFG)
+    cfg.update(max_size=1536, max_prompts=16, min_mask_region_area=0)
+    img = pipeline_image()
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    np.random.seed(1)
+    out = m.generate(img)
+    assert m.image_hw == (1152, 1536) and abs(m.downscale - 1.5) < 1e-12
+    D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
+    np.random.seed(1)
+    o = po.OracleCrowdSAM(synth.make_sam_state_dict(ARCH), (depth, heads, gidx), StandInDino(), cfg, rng=np.random)
+    with torch.no_grad():
+        ref = o.generate(img)
+    print("max_size 1536: kept", out["boxes"].shape, "oracle", ref["boxes"].shape)
+    assert out["boxes"].shape == ref["boxes"].shape and len(ref["boxes"]) > 0
+    np.testing.assert_array_equal(out["points"], ref["points"])
+    np.testing.assert_allclose(out["scores"], ref["scores"], rtol=0, atol=5e-3)
+    assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / 1.5
+    assert all(r["size"] == [1152, 1536] for r in out["rles"])
+    import crowdsam.utils as cu
+    for i in range(0, len(out["rles"]), max(1, len(out["rles"]) // 4)):
+        a, b = cu.coco_decode_rle(out["rles"][i]), cu.coco_decode_rle(ref["rles"][i])
+        assert a.shape == b.shape == (1152, 1536)
+        assert (a != b).sum() <= 0.01 * max(int(b.sum()), 1)
