@@ -12,12 +12,15 @@ LIB = os.path.join(HERE, "libcsam_hip%s.so" % ("_" + TAG if TAG else ""))
 ARCH = "gfx950"
 
 
-# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the (unified, gfx950) VGPR file -- without it hipcc parks them in
-# AGPRs and pays a v_accvgpr_read/write per element around the softmax (15 % of the flash-attention loop's VALU issue
-# slots).  Measured per file: +32 % on flash attention, +20 % on windowed attention; neutral or negative on the GEMM
-# and the fused decoder kernels, which keep the default.
-EXTRA_FLAGS = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("CSAM_FLASH_DEFS", "").split(),
-               "attn_window.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# -amdgpu-mfma-vgpr-form (MFMA accumulators in the unified VGPR file instead of AGPRs: no v_accvgpr_read/write around a
+# softmax) was used for the attention kernels in rounds 1-2 and is NOT any more: it lets the register allocator recycle an
+# MFMA's SrcC quad as a ds_read destination `s_nop 2` later, and on gfx950 the LDS return can overtake the MFMA's late
+# SrcC read under matrix-pipe contention (wrong scores in ~1 % of the flash-attention launches; csrc/attn_flash.hip has
+# the analysis).  The score accumulators that the VALU reads are tied-operand inline-asm MFMAs in VGPRs instead.
+# CSAM_VGPR_FORM=1 restores the old flags for A/B builds.
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] if os.environ.get("CSAM_VGPR_FORM") == "1" else []
+EXTRA_FLAGS = {"attn_flash.hip": _VGPR_FORM + os.environ.get("CSAM_FLASH_DEFS", "").split(),
+               "attn_window.hip": list(_VGPR_FORM)}
 
 
 def sources():

@@ -19,6 +19,12 @@
 // scalar per lane per tile) - reference: one v_add per accumulator register, zero extra MFMA/LDS work.
 #include "csam_common.h"
 
+#ifdef FLASH_DBG_DUMP
+__device__ float* g_flash_dbg = nullptr;     // [wg][tid][48]: s_init rt=1 (16), scaled twr rt=1 (16), reference twr*bmul + c0 (16)
+extern "C" int csam_dbg_set_flash(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_flash_dbg), &p, sizeof(p));
+}
+#endif
 namespace {
 
 constexpr int KT = 64;                 // keys per tile
@@ -62,6 +68,129 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
   }
 }
 
+// MFMA groups as inline asm with TIED accumulators.  The softmax reads every score with the VALU, so the accumulators
+// of S = K Q^T want to live in VGPRs (in AGPRs every score costs a v_accvgpr_read and every seed a v_accvgpr_write:
+// +32 % on this loop).  Rounds 1-2 got that from hipcc's experimental -amdgpu-mfma-vgpr-form (and hipcc selects the
+// VGPR form by itself once the launch bounds leave <= 256 registers); in that form the register allocator un-ties vDst
+// from SrcC and re-uses the SrcC quad as the destination of the next ds_read_b128, `s_nop 2` behind the MFMA that reads
+// it.  While hunting the intermittent wrong bias described at the Tw seeds below that pattern was the first suspect: a
+// single-wave probe cannot make it fail (tools/probe/mfma_srcc_lds_war.hip, 0 wrong in 35 k trials) and the bias fault
+// turned out to be elsewhere, so it is UNPROVEN as a hazard -- but it rests on the matrix pipe having taken SrcC for
+// all 64 lanes before an LDS return can land, under any contention, and nothing documents that.  The MFMAs of this
+// kernel therefore do not depend on it: every accumulator is tied ("+v": vDst == SrcC, nothing else may be aimed at
+// the quad while the MFMA is pending), the fragments are fetched by the same blocks (ring of four quads, counted
+// lgkmcnt waits -- LDS returns in order, so counting inside a block only ever over-waits for the compiler's own LDS
+// operations), no load is left in flight when a block ends (the compiler may copy a block's outputs), and the wait
+// states the hazard recogniser would insert around MFMAs it cannot see are written out: VALU write -> MFMA read 2,
+// 8-pass XDL write -> VALU read 8 + 3 (LLVM GCNHazardRecognizer, gfx940 rows).  Same speed as the compiler-scheduled
+// loop (173 vs 177 us at T = 5330); tools/lint_mfma_srcc.py reports the pattern per source file at build time.
+// The K fragments of the tile are fetched by the same asm block (four ds_read_b128 in flight, counted lgkmcnt
+// waits -- LDS returns in order, so waits counted inside the block only ever over-wait for the compiler's own LDS
+// operations): fetched by C++ they ended up in ONE register quad, read / wait / two MFMAs eight times over.
+// s: the 8 accumulator quads [rt][kt]; q: the four query fragments [rt][ks]; ka0 / ka1: LDS byte address of this lane's
+// fragment in k-step 0 / 1 at key tile row block 0 (kt adds 512 B per odd kt and 4096 B per kt >= 2).
+__device__ __forceinline__ void scores_mfma(floatx4 (&s)[2][4], const half8_t (&q)[2][2], unsigned ka0, unsigned ka1) {
+  half8_t k0, k1, k2, k3;            // ring of four: a quad is re-filled for k-step 1 right behind the MFMAs that read it
+  asm volatile(
+      "ds_read_b128 %8, %16\n\t"
+      "ds_read_b128 %9, %16 offset:512\n\t"
+      "ds_read_b128 %10, %16 offset:4096\n\t"
+      "ds_read_b128 %11, %16 offset:4608\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %8, %12, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %4, %8, %14, %4\n\t"
+      "ds_read_b128 %8, %17\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %9, %12, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %5, %9, %14, %5\n\t"
+      "ds_read_b128 %9, %17 offset:512\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %10, %12, %2\n\t"
+      "v_mfma_f32_16x16x32_f16 %6, %10, %14, %6\n\t"
+      "ds_read_b128 %10, %17 offset:4096\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %11, %12, %3\n\t"
+      "v_mfma_f32_16x16x32_f16 %7, %11, %14, %7\n\t"
+      "ds_read_b128 %11, %17 offset:4608\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %8, %13, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %4, %8, %15, %4\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %9, %13, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %5, %9, %15, %5\n\t"
+      "s_waitcnt lgkmcnt(1)\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %10, %13, %2\n\t"
+      "v_mfma_f32_16x16x32_f16 %6, %10, %15, %6\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %11, %13, %3\n\t"
+      "v_mfma_f32_16x16x32_f16 %7, %11, %15, %7\n\t"
+      "s_nop 7\n\t"
+      "s_nop 3"
+      : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]),
+        "+v"(s[1][3]), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+      : "v"(q[0][0]), "v"(q[0][1]), "v"(q[1][0]), "v"(q[1][1]), "v"(ka0), "v"(ka1)
+      : "memory");
+}
+
+// Row sums lt^T = 1 . P^T (tied accumulators, zeroed by the caller); the result is tested by the VALU right away,
+// hence the 11 wait states.  (No loads are left in flight when an asm block ends: the compiler is free to copy a
+// block's outputs, and a copy of a register whose load has not returned copies garbage.)
+__device__ __forceinline__ void rowsum_mfma(floatx4 (&lt)[2], const half8_t (&p)[2][2], const half8_t& ones) {
+  asm volatile(
+      "s_nop 1\n\t"                                   // VALU (cvt / zero) write -> MFMA read
+      "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %2, %5, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %2, %6, %1\n\t"
+      "s_nop 7\n\t"
+      "s_nop 3"
+      : "+v"(lt[0]), "+v"(lt[1])
+      : "v"(ones), "v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]));
+}
+
+// O^T += V^T P^T: 16 tied MFMAs over the 8 V^T fragments (dims row dt*16 + fr, keys 32 st + 8 fg .. +7), ring of four
+// quads in the order (dt0,st0) (dt1,st0) (dt0,st1) (dt1,st1), dt 2 / 3 re-filled in place.
+__device__ __forceinline__ void pv_mfma(floatx4 (&o)[2][4], const half8_t (&p)[2][2], unsigned va0, unsigned va1) {
+  half8_t v0, v1, v2, v3;
+  asm volatile(
+      "ds_read_b128 %8, %16\n\t"                       // (dt 0, st 0)
+      "ds_read_b128 %9, %16 offset:2048\n\t"           // (dt 1, st 0)
+      "ds_read_b128 %10, %17\n\t"                      // (dt 0, st 1)
+      "ds_read_b128 %11, %17 offset:2048\n\t"          // (dt 1, st 1)
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %8, %12, %0\n\t"    // o[0][0] += v(0,0) p[0][0]
+      "v_mfma_f32_16x16x32_f16 %4, %8, %14, %4\n\t"    // o[1][0] += v(0,0) p[1][0]
+      "ds_read_b128 %8, %16 offset:4096\n\t"           // (dt 2, st 0)
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %9, %12, %1\n\t"    // o[0][1] += v(1,0) p[0][0]
+      "v_mfma_f32_16x16x32_f16 %5, %9, %14, %5\n\t"
+      "ds_read_b128 %9, %16 offset:6144\n\t"           // (dt 3, st 0)
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %10, %13, %0\n\t"   // o[0][0] += v(0,1) p[0][1]
+      "v_mfma_f32_16x16x32_f16 %4, %10, %15, %4\n\t"
+      "ds_read_b128 %10, %17 offset:4096\n\t"          // (dt 2, st 1)
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %11, %13, %1\n\t"   // o[0][1] += v(1,1) p[0][1]
+      "v_mfma_f32_16x16x32_f16 %5, %11, %15, %5\n\t"
+      "ds_read_b128 %11, %17 offset:6144\n\t"          // (dt 3, st 1)
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %8, %12, %2\n\t"    // o[0][2] += v(2,0) p[0][0]
+      "v_mfma_f32_16x16x32_f16 %6, %8, %14, %6\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %9, %12, %3\n\t"    // o[0][3] += v(3,0) p[0][0]
+      "v_mfma_f32_16x16x32_f16 %7, %9, %14, %7\n\t"
+      "s_waitcnt lgkmcnt(1)\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %10, %13, %2\n\t"   // o[0][2] += v(2,1) p[0][1]
+      "v_mfma_f32_16x16x32_f16 %6, %10, %15, %6\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %11, %13, %3\n\t"   // o[0][3] += v(3,1) p[0][1]
+      "v_mfma_f32_16x16x32_f16 %7, %11, %15, %7"
+      : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]),
+        "+v"(o[1][3]), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(p[0][0]), "v"(p[0][1]), "v"(p[1][0]), "v"(p[1][1]), "v"(va0), "v"(va1)
+      : "memory");
+}
+
 // K-tile LDS swizzle: fragment reads touch key rows {8a + b (+4)}, a,b in 0..3 (see the key permutation
 // below), so the XOR term must separate rows by bits 1 and 3..4 rather than by (row & 7).
 __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
@@ -73,7 +202,7 @@ __device__ __forceinline__ int kswz(int row) { return ((row >> 1) & 1) | (((row 
 #define FLASH_OCC 1
 #endif
 template <bool BIAS>
-__global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
+__global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const half_t* __restrict__ qkv, long ld,
                                                          int q_off, int k_off,
                                                          const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ traw,
@@ -123,6 +252,13 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
   // 32s + 8g + r + 4*(kt&1), so that a lane's 8 P values of a step are 8 CONSECUTIVE keys and the V^T
   // fragment is one 16-B read.  Row this lane supplies as the A operand of S^T = K Q^T:
   const int krow_in_step = 8 * (fr >> 2) + (fr & 3);
+  // LDS byte address of this lane's K fragment at kt = 0: row krow_in_step, 16-B slot (ks*4 + fg) ^ kswz(row); kswz sees
+  // only bits 1, 3, 4 of the row, which kt (+4, +32 rows) does not touch, so kt is an immediate offset
+  const unsigned kaddr0 = (unsigned)(unsigned long)(lptr_t)smem + krow_in_step * 128 + ((fg ^ kswz(krow_in_step)) << 4);
+  // V^T fragment: dims row dt*16 + fr (dt: +2048 B), 16-B slot (st*4 + fg) ^ (row & 7), at +8192 B in the tile slot
+  const unsigned vaddr0 = (unsigned)(unsigned long)(lptr_t)smem + 8192 + fr * 128 + ((fg ^ (fr & 7)) << 4);
+  const unsigned vaddr1 = (unsigned)(unsigned long)(lptr_t)smem + 8192 + fr * 128 + (((4 + fg) ^ (fr & 7)) << 4);
+  const unsigned kaddr1 = (unsigned)(unsigned long)(lptr_t)smem + krow_in_step * 128 + (((4 + fg) ^ kswz(krow_in_step)) << 4);
   floatx4 twr[2][4];
   const float* thp[2] = {nullptr, nullptr};
   if constexpr (BIAS) {
@@ -140,14 +276,29 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
       }
     }
   }
+  if constexpr (BIAS) {
+    // The scaled Tw quads are FINISHED here, in the prologue.  Left to the scheduler, hipcc sinks the 16 v_pk_mul_f32
+    // (raw table value x bmul) into the first key tile, right behind the first s_barrier and right in front of the
+    // v_pk_add_f32 that build the accumulator seeds -- and on MI355X that sequence intermittently loses: in 1-8 % of the
+    // launches (depending on what else sits between the barrier and the seeds) ONE seed register of ONE wave came out
+    // as c0 + 0 in lanes 48..63, i.e. its v_pk_add_f32 saw the Tw operand before the v_pk_mul_f32 ~15 instructions
+    // earlier had written that lane group (register dump of a failing launch: tools/dbg/flash_dump.py; key tile 0,
+    // second query tile, lane group 3 only; never with a zero Tw table; the raw table loads were complete, the
+    // accumulators tied, the scaled register itself correct a moment later).  Round 2 saw the same signature and
+    // mis-filed it as a register-recycling artefact.  With the products pinned before the loop, and the LDS-DMA issue
+    // between the barrier and the seeds, 0 of 1600 launches differ (tests/test_determinism_gpu.py keeps watching).
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      asm volatile("" : "+v"(twr[rt][0]), "+v"(twr[rt][1]), "+v"(twr[rt][2]), "+v"(twr[rt][3]));
+  }
   floatx4 o[2][4];
   float mref[2];              // softmax reference exponent of the query (base-2 units): P = 2^(s - mref)
-  floatx4 l[2];
+  float l[2];                 // softmax denominators (every lane of a query holds the same sum)
   const half8_t ones8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     mref[rt] = 0.f;
-    l[rt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    l[rt] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[rt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
@@ -185,8 +336,7 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
     } else {
       if (t + 1 < nt) stage(cur ^ 1, t + 1);
     }
-    const char* Kc = smem + cur * 16384;
-    const char* Vc = Kc + 8192;
+    const unsigned kbase = cur * 16384;
     cur = cur + 1 == FLASH_NS ? 0 : cur + 1;
 
     floatx4 s[2][4];
@@ -215,26 +365,25 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
           }
         }
       }
+      // tied-accumulator MFMAs + their K fragment reads (see scores_mfma): VALU-initialised quads in, VALU-readable out
+#ifdef FLASH_DBG_DUMP
       if constexpr (BIAS) {
-        // All eight initial quads exist, in registers of their own, BEFORE the first MFMA issues.  Left to the
-        // scheduler, hipcc (ROCm 7.2) computes them between the MFMAs and recycles a quad for the next initial value
-        // right after the MFMA that reads it as SrcC; the first-tile code built that way produced scores with one bias
-        // term missing in lanes 48..63 of one register (run-to-run varying rows; DESIGN.md section 4.1,
-        // tests/test_encoder_gpu.py::test_flash_attn_constant_bias_is_a_no_op).
-        asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]),
-                          "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]));
-      }
+        if (t == 0 && g_flash_dbg) {
+          float* d = g_flash_dbg + ((long)blockIdx.x * 256 + tid) * 48;
+          const int qc1 = qrow[1] < T ? qrow[1] : T - 1;
+          const float* twq1 = traw + ((long)head * T + qc1) * 256 + 128 + (qc1 & 63) + 63;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+          for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          const int krow = (kt >> 1) * 32 + krow_in_step + 4 * (kt & 1);
-          const half8_t kf = *(const half8_t*)(Kc + krow * 128 + (((ks * 4 + fg) ^ kswz(krow)) << 4));
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            s[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][ks], s[rt][kt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+              d[kt * 4 + j] = s[1][kt][j];
+              d[16 + kt * 4 + j] = twr[1][kt][j];
+              d[32 + kt * 4 + j] = __builtin_nontemporal_load(twq1 - ((kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j)) * bmul + (thv[1] - mref[1]);
+            }
         }
       }
+#endif
+      scores_mfma(s, qf, kaddr0 + kbase, kaddr1 + kbase);
       // lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr; out-of-range keys only on the last tile
       if ((t + 1) * KT > T) {
 #pragma unroll
@@ -265,11 +414,9 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
             pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
           }
       }
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        lt[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        lt[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[rt][1], lt[rt], 0, 0, 0);
-      }
+      lt[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+      lt[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+      rowsum_mfma(lt, pf, ones8);
     };
     // ---- softmax.  The loop is issue-bound (VALU and MFMA times of a SIMD add up), so the per-score work is ONE
     // v_exp_f32 and half a v_cvt_pk: no running maximum is tracked.  mref is set from the first tile's maximum and
@@ -311,24 +458,17 @@ __global__ __launch_bounds__(256, FLASH_OCC) void flash_attn_kernel(const half_t
       probs();
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) l[rt] += lt[rt];
-    // ---- O^T += V^T P^T: V^T fragment = dims row dt*16+fr, keys 32 st + 8 fg .. +7 (one 16-B read)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int vrow = dt * 16 + fr;
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const half8_t vf = *(const half8_t*)(Vc + vrow * 128 + (((st * 4 + fg) ^ (vrow & 7)) << 4));
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rt][st], o[rt][dt], 0, 0, 0);
-      }
-    }
+    for (int rt = 0; rt < 2; ++rt) l[rt] += lt[rt][0];
+    // ---- O^T += V^T P^T (tied-accumulator asm, see pv_mfma)
+    pv_mfma(o, pf, vaddr0 + kbase, vaddr1 + kbase);
   }
+  // the epilogue reads O with the VALU: XDL write -> VALU read wait states behind the last tile's MFMAs
+  asm volatile("s_nop 7\n\ts_nop 3" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[1][0]),
+               "+v"(o[1][1]), "+v"(o[1][2]), "+v"(o[1][3]));
 
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    const float inv = 1.0f / l[rt][0];
+    const float inv = 1.0f / l[rt];
     if (qrow[rt] < T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {

@@ -239,6 +239,12 @@ constexpr int T2_LD = 34;                            // Th 0..13 | Tw 14..27 | T
 constexpr int T_BYTES = 4 * 16 * T2_LD * 4;          // per-wave tables
 constexpr int SMEM2_BYTES = KE_BYTES + VT_BYTES + T_BYTES;
 
+// The three MFMA groups of the kernel (bias table, scores, P.V) are inline-asm blocks with tied accumulators: built from
+// the MFMA builtins hipcc selects the VGPR form here (launch bounds <= 256 registers) and recycled SrcC quads as
+// ds_read destinations two instructions behind the MFMA that reads them -- the hazard analysed in attn_flash.hip
+// (tools/lint_mfma_srcc.py flagged six such loads in this kernel).
+#include "attn_window_asm.inc"
+
 __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restrict__ qkv,
                                                            const float* __restrict__ qkv_bias,
                                                            const half_t* __restrict__ relcat,
@@ -295,6 +301,13 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
     const int key0 = kt * 16 + fg * 4;
     koff[kt] = ((key0 / WS) << 8) | (key0 % WS);
   }
+  // LDS byte addresses of this lane's fragments: K row fr of key tile 0, 16-B chunk fg (key tile: +16 rows, k-step: +64 B);
+  // V^T row dt*16 + fr at keys 4 fg (k-step s2: +64 B, second half of the fragment: +32 B)
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+  const unsigned kaddr = lds0 + fr * (KE_LD * 2) + fg * 16;
+  unsigned vaddr[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vaddr[dt] = lds0 + KE_BYTES + (dt * 16 + fr) * (VT_LD * 2) + fg * 8;
   __syncthreads();
 
   const float sl2 = scale * 1.4426950408889634f;     // scores in base-2 units
@@ -317,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
       }
     }
     // bias table of this query tile: T[j][q] = relcat[j] . q, scattered to Th[kh = qh + 13 - j], Tw[kw = qw + 13 - (j - 27)]
+    floatx4 t4[4];
+    win_bias_mfma(t4, rf, qf);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      floatx4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) t = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf[nt][ks], qf[ks], t, 0, 0, 0);
+      const floatx4 t = t4[nt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = nt * 16 + fg * 4 + r;
@@ -346,15 +359,10 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
     floatx4 p[14];
     float mx = -INFINITY;
     const float* trow = Tt + fr * T2_LD;
+    win_scores_mfma(p, qf, kaddr);
 #pragma unroll
     for (int kt = 0; kt < 13; ++kt) {
-      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-      const half_t* kr = Ke + (kt * 16 + fr) * KE_LD;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const half8_t kf = *(const half8_t*)(kr + (ks * 4 + fg) * 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], acc, 0, 0, 0);
-      }
+      floatx4 acc = p[kt];
       // lane holds S_raw[key = kt*16 + fg*4 + j][query = rt*16 + fr]; its keys are (kh0, kw0 + j), wrapping to kh0 + 1
       const int kh0 = koff[kt] >> 8, kw0 = koff[kt] & 255;
       const float2_t th = *(const float2_t*)(trow + (kh0 & ~1));                  // Th[kh0 & ~1], Th[(kh0 & ~1) + 1]
@@ -399,17 +407,11 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
         pf[s2][4 + e] = (half_t)p[2 * s2 + 1][e];
       }
     }
+    floatx4 o4[4];
+    win_pv_mfma(o4, pf, vaddr);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      floatx4 o = {0.f, 0.f, 0.f, 0.f};
-      const half_t* vr = Vt + (dt * 16 + fr) * VT_LD + fg * 4;
-#pragma unroll
-      for (int s2 = 0; s2 < 7; ++s2) {
-        const half4_t v0 = *(const half4_t*)(vr + 32 * s2);
-        const half4_t v1 = *(const half4_t*)(vr + 32 * s2 + 16);
-        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s2], o, 0, 0, 0);
-      }
+      const floatx4 o = o4[dt];
       if (inside) {
         half4_t h;
 #pragma unroll

@@ -32,10 +32,19 @@ def _model(arch, grid, ppb):
 def _invariants(m, img, cuda, frame, grid):
     from crowdsam_amd import hip
     from tests.test_stress_gpu import _decode, _rle_area_and_box
+    snap = {}
+    reset = m.predictor.reset_image
+
+    def grab_then_reset():      # the driver resets the predictor at the end of a crop (crowdsam/model.py:249): look first
+        if m.predictor.is_image_set:
+            snap["feat"] = m.predictor.features.float().cpu().numpy()                       # [1,256,64,64]
+            snap["dino"] = m.predictor.dino_feats.float().cpu().numpy().reshape(5329, 1024)
+        reset()
+
+    m.predictor.reset_image = grab_then_reset
     np.random.seed(0)
     a = m.generate(img)
-    feats = m.predictor.features.float().cpu().numpy()                      # [1,256,64,64], this image's
-    dino = m.predictor.dino_feats.float().cpu().numpy().reshape(5329, 1024)
+    feats, dino = snap["feat"], snap["dino"]
     assert 0 < m.last_candidates <= grid * grid
     np.random.seed(0)
     b = m.generate(img)

@@ -1,0 +1,150 @@
+"""debug: repeat csam_flash_attn (rel-pos variant) on the block-11 operands of the full ViT-L encoder and locate the
+elements that differ from launch to launch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from crowdsam_amd import hip, synth
+from crowdsam_amd.encoder import EncoderPlan
+D, depth, heads, gidx = synth.SAM_CONFIGS["vit_l"]
+dev = torch.device("cuda:0")
+sd = synth.make_sam_state_dict("vit_l")
+plan = EncoderPlan(sd, "image_encoder.", D, depth, heads, gidx, dev)
+img = torch.from_numpy(synth.synthetic_crowd_frame(7, 1024, 150)).permute(2, 0, 1).float().contiguous().to(dev)
+ws, nH = plan.ws, plan.heads
+scale = plan.hd ** -0.5
+target = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+hip.sam_im2col(img, ws["col"])
+x = hip.gemm_f16(ws["col"], plan.patch_w, out=ws["x"], bias=plan.patch_b, residual=plan.pos)
+for i, b in enumerate(plan.blocks):
+    hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
+    hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
+    if i == target:
+        break
+    if b["is_global"]:
+        hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)
+        hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"], q_prescaled=True)
+    else:
+        hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
+    hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)
+    hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"])
+    hip.gemm_f16(ws["h"], b["lin1_w"], out=ws["mlp"], bias=b["lin1_b"], act=hip.ACT_GELU)
+    hip.gemm_f16(ws["mlp"], b["lin2_w"], out=x, bias=b["lin2_b"], residual=x)
+b = plan.blocks[target]
+hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)
+torch.cuda.synchronize()
+qkv, traw = ws["qkv"].clone(), ws["traw"].clone()
+if "zero_traw" in sys.argv: traw.zero_()
+if "zero_th" in sys.argv: traw[:, :, :128] = 0          # Th columns (rel_pos_h part) only
+if "zero_tw" in sys.argv: traw[:, :, 128:] = 0          # Tw columns only
+if "const_th" in sys.argv: traw[:, :, :128] = 0.37      # Th constant over kh (and q): tile-independent
+print("qkv |mean| %.3f max %.1f ; traw |mean| %.3f max %.1f" % (qkv.float().abs().mean(), qkv.float().abs().max(),
+      traw.abs().mean(), traw.abs().max()))
+# fp32 reference of the softmax for a few heads (explicit)
+outs = []
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+QUIET = len(sys.argv) > 3
+for r in range(N):
+    o = torch.empty(4096, D, dtype=torch.float16, device=dev)
+    hip.flash_attn(qkv, o, 4096, nH, scale, D, relpos=traw, q_prescaled=True)
+    torch.cuda.synchronize()
+    outs.append(o)
+# majority reference = elementwise median over launches
+st = torch.stack([o.float() for o in outs])            # [N,4096,D]
+med = st.median(0).values
+nbad = 0
+for r, o in enumerate(outs):
+    d = (o.float() != med)
+    if d.any():
+        nbad += 1
+        idx = d.nonzero()
+        rows = idx[:, 0].unique()
+        cols = idx[:, 1].unique()
+        hd_ = (cols // 64).unique().tolist()
+        if not QUIET: print("launch %d: %d elements differ; %d query rows (first %s) heads %s dims-in-head %s; max |diff| %.4f; finite %s"
+              % (r, int(d.sum()), len(rows), rows[:8].tolist(), hd_, (cols % 64).unique()[:16].tolist(),
+                 float((o.float() - med).abs().max()), bool(torch.isfinite(o).all())))
+print("launches with differences: %d of %d" % (nbad, N))
+# ---- which key(s) got a wrong weight?  single-key fit of the difference of a bad row: d = alpha * (v_j - o)
+if nbad and not QUIET or (nbad and len(sys.argv) > 4):
+    V = qkv[:, 2 * D:].float()
+    for r, o in enumerate(outs):
+        d = (o.float() != med)
+        if not d.any():
+            continue
+        rows = d.nonzero()[:, 0].unique()
+        for row in rows[:12].tolist():
+            hh = int((d[row].nonzero()[:, 0] // 64).unique()[0])
+            dv = (o.float()[row, hh * 64:(hh + 1) * 64] - med[row, hh * 64:(hh + 1) * 64]).double()
+            base = med[row, hh * 64:(hh + 1) * 64].double()
+            Vh = V[:, hh * 64:(hh + 1) * 64].double()
+            U = Vh - base[None]                               # [4096, 64]
+            alpha = (U @ dv) / (U * U).sum(1)
+            res = ((dv[None] - alpha[:, None] * U) ** 2).sum(1)
+            j = int(res.argmin())
+            print("  launch %d row %d head %d: best single key %d (tile %d, in-tile %d: step %d fg %d half %d j %d) alpha %.4g residual/|d| %.3f"
+                  % (r, row, hh, j, j // 64, j % 64, (j % 64) // 32, ((j % 32) // 8), ((j % 8) // 4), j % 4, float(alpha[j]),
+                     float(res[j].sqrt() / dv.norm())))
+# ---- hypothesis test: is the difference of a bad row explained by the weights of a small key set of tile 0?
+if nbad and "hyp" in sys.argv:
+    V = qkv[:, 2 * D:].double()
+    def resid(dv, base, Vh, keys):
+        U = (Vh[keys] - base[None]).T                     # [64, n]
+        sol = torch.linalg.lstsq(U, dv[:, None]).solution
+        return float((U @ sol - dv[:, None]).norm() / dv.norm())
+    import random
+    random.seed(0)
+    for r, o in enumerate(outs):
+        d = (o.float() != med)
+        if not d.any():
+            continue
+        rows = d.nonzero()[:, 0].unique()
+        for row in rows[:6].tolist():
+            hh = int((d[row].nonzero()[:, 0] // 64).unique()[0])
+            dv = (o.float()[row, hh * 64:(hh + 1) * 64] - med[row, hh * 64:(hh + 1) * 64]).double()
+            if dv.norm() < 2e-3:
+                continue
+            base = med[row, hh * 64:(hh + 1) * 64].double()
+            Vh = V[:, hh * 64:(hh + 1) * 64]
+            h1 = resid(dv, base, Vh, list(range(56, 64)))
+            h1b = resid(dv, base, Vh, list(range(48, 56)))
+            h3 = resid(dv, base, Vh, list(range(24, 32)) + list(range(56, 64)))
+            t1 = resid(dv, base, Vh, list(range(64 + 56, 128)))
+            ctl = sum(resid(dv, base, Vh, random.sample(range(4096), 8)) for _ in range(5)) / 5
+            print("  launch %d row %d head %d |d| %.4f: residual keys56-63(tile0) %.3f | keys48-55 %.3f | fg3 of tile0 (16 keys) %.3f | keys56-63 of tile1 %.3f | random 8 keys %.3f"
+                  % (r, row, hh, float(dv.norm()), h1, h1b, h3, t1, ctl))
+# ---- one-parameter models: the weights of a key SET scaled by a common factor (a bias shift on those keys)
+if nbad and "sets" in sys.argv:
+    scale_ = plan.hd ** -0.5
+    Q = qkv[:, :D].double(); K = qkv[:, D:2 * D].double(); V = qkv[:, 2 * D:].double()
+    kidx = torch.arange(4096, device=dev)
+    kh, kw = kidx // 64, kidx % 64
+    fgk = (kidx % 32) // 8
+    tile = kidx // 64
+    cands = []
+    for r, o in enumerate(outs):
+        d = (o.float() != med)
+        if not d.any():
+            continue
+        for row in d.nonzero()[:, 0].unique().tolist():
+            hh = int((d[row].nonzero()[:, 0] // 64).unique()[0])
+            dv = (o.float()[row, hh * 64:(hh + 1) * 64] - med[row, hh * 64:(hh + 1) * 64]).double()
+            cands.append((float(dv.norm()), r, row, hh, dv))
+    cands.sort(key=lambda c: -c[0])
+    for nrm, r, row, hh, dv in cands[:8]:
+        q = Q[row, hh * 64:(hh + 1) * 64]
+        s2 = K[:, hh * 64:(hh + 1) * 64] @ q
+        tq = traw[hh, row].double()
+        qh, qw = row // 64, row % 64
+        s2 = s2 + (tq[(qh - kh + 63)] + tq[128 + (qw - kw + 63)]) / scale_
+        p = torch.softmax(s2 * 0.6931471805599453, 0)
+        o_ref = (p[:, None] * V[:, hh * 64:(hh + 1) * 64]).sum(0)
+        U = p[:, None] * (V[:, hh * 64:(hh + 1) * 64] - o_ref[None])          # per-key first-order direction
+        def fit(mask):
+            g = U[mask].sum(0)
+            a = (g @ dv) / (g @ g)
+            return float((dv - a * g).norm() / dv.norm()), float(a)
+        res = {"fg3 all tiles": fit(fgk == 3), "fg3 tile 0": fit((fgk == 3) & (tile == 0)), "fg3 tile 1": fit((fgk == 3) & (tile == 1)),
+               "fg3 tiles>=1": fit((fgk == 3) & (tile >= 1)), "fg2 tile 0": fit((fgk == 2) & (tile == 0)), "all keys tile 0": fit(tile == 0),
+               "kw in 24..31|56..63 (all tiles)": fit(((kw % 32) // 8) == 3)}
+        print("  launch %d row %d (wave %d rt %d) head %d |d| %.4f (ref-vs-median |.| %.4f): " % (r, row, (row % 128) // 32, (row % 32) // 16, hh, nrm,
+              float((o_ref - med[row, hh * 64:(hh + 1) * 64].double()).norm())) + " | ".join("%s %.2f (a=%.3g)" % (k, v[0], v[1]) for k, v in res.items()))

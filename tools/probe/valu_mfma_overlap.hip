@@ -86,27 +86,29 @@ static const char* NAMES[] = {"16 MFMA", "48 v_fma", "16x(MFMA+3 v_fma)", "16x(M
 
 #define RUN(BODY)                                                                                            \
   asm volatile(                                                                                              \
-      "v_mov_b32 v20, %2\n v_mov_b32 v21, %2\n v_mov_b32 v22, %2\n v_mov_b32 v23, %2\n"                       \
-      "v_mov_b32 v24, %2\n v_mov_b32 v25, %2\n v_mov_b32 v26, %2\n v_mov_b32 v27, %2\n"                       \
-      "v_mov_b32 v28, %3\n v_mov_b32 v29, %4\n v_mov_b32 v30, %3\n v_mov_b32 v31, %4\n"                       \
-      "s_mov_b32 s20, %5\n"                                                                                  \
-      "s_memtime s[22:23]\n s_waitcnt lgkmcnt(0)\n"                                                          \
+      "v_mov_b32 v20, %3\n v_mov_b32 v21, %3\n v_mov_b32 v22, %3\n v_mov_b32 v23, %3\n"                       \
+      "v_mov_b32 v24, %3\n v_mov_b32 v25, %3\n v_mov_b32 v26, %3\n v_mov_b32 v27, %3\n"                       \
+      "v_mov_b32 v28, %4\n v_mov_b32 v29, %5\n v_mov_b32 v30, %4\n v_mov_b32 v31, %5\n"                       \
+      "s_mov_b32 s20, %6\n"                                                                                  \
+      "s_memrealtime s[26:27]\n s_memtime s[22:23]\n s_waitcnt lgkmcnt(0)\n"                                 \
       "1:\n" BODY                                                                                            \
       "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                                    \
-      "s_nop 7\n s_nop 7\n s_memtime s[24:25]\n s_waitcnt lgkmcnt(0)\n"                                      \
-      "s_sub_u32 s22, s24, s22\n s_subb_u32 s23, s25, s23\n"                                                 \
-      "v_mov_b32 %0, s22\n v_add_f32 %1, v0, v32\n"                                                          \
-      : "=v"(dt), "=v"(sink)                                                                                 \
+      "s_nop 7\n s_nop 7\n s_memtime s[24:25]\n s_memrealtime s[28:29]\n s_waitcnt lgkmcnt(0)\n"             \
+      "s_sub_u32 s22, s24, s22\n s_subb_u32 s23, s25, s23\n s_sub_u32 s26, s28, s26\n"                       \
+      "v_mov_b32 %0, s22\n v_add_f32 %1, v0, v32\n v_mov_b32 %2, s26\n"                                      \
+      : "=v"(dt), "=v"(sink), "=v"(rt)                                                                       \
       : "v"(hz), "v"(c0), "v"(c1), "s"(iters)                                                                \
       : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", \
         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", \
         "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
-        "v50", "v51", "v52", "v53", "v54", "v55", "s20", "s22", "s23", "s24", "s25", "scc", "memory")
+        "v50", "v51", "v52", "v53", "v54", "v55", "s20", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "scc", \
+        "memory")
 
-__device__ __forceinline__ void run_mode(int mode, int iters, unsigned& dt, float& sink) {
+__device__ __forceinline__ void run_mode(int mode, int iters, unsigned& dt, float& sink, unsigned& rt) {
   const unsigned hz = 0x00010001u;   // two tiny fp16 values: accumulators stay finite
   const float c0 = 0.999f, c1 = 1e-3f;
   dt = 0;
+  rt = 0;
   sink = 0.f;
   switch (mode) {
     case K_M: RUN(BODY_M); break;
@@ -127,23 +129,23 @@ __device__ __forceinline__ void run_mode(int mode, int iters, unsigned& dt, floa
   }
 }
 
-// wave wa runs mode ma, wave wb runs mode mb (-1: nobody), all other waves of the 8-wave workgroup leave at once
-__global__ __launch_bounds__(512) void k(int wa, int ma, int wb, int mb, int iters, unsigned* out, float* sinkp) {
+// wave w runs mode modes.m[w] (-1: leaves at once); 16-wave workgroup: waves w, w+4, w+8, w+12 share a SIMD
+struct Modes { int m[16]; };
+__global__ __launch_bounds__(1024) void k(Modes modes, int iters, unsigned* out, float* sinkp) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned hwid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
   __syncthreads();
-  int mode = -1;
-  if (wave == wa) mode = ma;
-  if (wave == wb) mode = mb;
+  const int mode = modes.m[wave];
   if (mode < 0 || mode == K_IDLE) return;
-  unsigned dt;
+  unsigned dt, rt;
   float sink;
-  run_mode(mode, 64, dt, sink);          // warm-up (instruction cache)
-  run_mode(mode, iters, dt, sink);
+  run_mode(mode, 64, dt, sink, rt);      // warm-up (instruction cache)
+  run_mode(mode, iters, dt, sink, rt);
   if ((threadIdx.x & 63) == 0) {
     out[wave * 2] = dt;
     out[wave * 2 + 1] = hwid;
+    out[32 + wave] = rt;                 // the same interval in s_memrealtime ticks (100 MHz)
   }
   if (sink == 12345.f) *sinkp = sink;
 }
@@ -151,22 +153,43 @@ __global__ __launch_bounds__(512) void k(int wa, int ma, int wb, int mb, int ite
 static unsigned* d_out;
 static float* d_sink;
 
+static void many(const int* waves, const int* mds, int n) {
+  const int iters = 2000;
+  unsigned h[64] = {0};
+  Modes m;
+  for (int i = 0; i < 16; ++i) m.m[i] = -1;
+  for (int i = 0; i < n; ++i) m.m[waves[i]] = mds[i];
+  hipMemset(d_out, 0, sizeof(h));
+  hipLaunchKernelGGL(k, dim3(1), dim3(1024), 0, 0, m, iters, d_out, d_sink);
+  hipDeviceSynchronize();
+  hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
+  printf(" ");
+  for (int i = 0; i < n; ++i)
+    printf(" w%d(S%u) %s: %.1f |", waves[i], (h[waves[i] * 2 + 1] >> 4) & 3, NAMES[mds[i]], (double)h[waves[i] * 2] / iters);
+  printf("\n");
+}
+
 static void pair(int wa, int ma, int wb, int mb) {
   const int iters = 2000;
-  unsigned h[16] = {0};
+  unsigned h[64] = {0};
+  Modes m;
+  for (int i = 0; i < 16; ++i) m.m[i] = -1;
+  m.m[wa] = ma;
+  if (wb >= 0) m.m[wb] = mb;
   hipMemset(d_out, 0, sizeof(h));
-  hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, wa, ma, wb, mb, iters, d_out, d_sink);
+  hipLaunchKernelGGL(k, dim3(1), dim3(1024), 0, 0, m, iters, d_out, d_sink);
   hipDeviceSynchronize();
   hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
   auto simd = [&](int w) { return (h[w * 2 + 1] >> 4) & 3; };
-  printf("  wave %d (SIMD %u) %-22s: %8.1f cycles / body", wa, simd(wa), NAMES[ma], (double)h[wa * 2] / iters);
+  printf("  wave %d (SIMD %u) %-22s: %8.1f cycles / body [%.1f ns]", wa, simd(wa), NAMES[ma], (double)h[wa * 2] / iters,
+         10.0 * h[32 + wa] / iters);
   if (wb >= 0 && mb != K_IDLE)
     printf("   ||   wave %d (SIMD %u) %-22s: %8.1f cycles / body", wb, simd(wb), NAMES[mb], (double)h[wb * 2] / iters);
   printf("\n");
 }
 
 int main() {
-  hipMalloc(&d_out, 64);
+  hipMalloc(&d_out, 256);
   hipMalloc(&d_sink, 4);
   printf("one wave alone (body = 16 units; 16 MFMA 16x16x32 f16 = 256 pipe cycles at 16 each)\n");
   for (int m = 0; m < K_IDLE; ++m) pair(0, m, -1, -1);
@@ -182,6 +205,17 @@ int main() {
   pair(0, K_BLK2, 4, K_BLK2);
   pair(0, K_MP3, 4, K_MP3);
   pair(0, K_M, 4, K_IDLE);
+  printf("n waves on the SAME SIMD (waves 0, 4, 8, 12 of a 16-wave workgroup); cycles per body per wave\n");
+  {
+    const int w4[4] = {0, 4, 8, 12};
+    const int sets[][4] = {{K_F, K_F, K_F, K_F}, {K_P, K_P, K_P, K_P}, {K_E, K_E, K_E, K_E}, {K_M, K_F, K_F, K_F},
+                           {K_M, K_P, K_P, K_P}, {K_M, K_M, K_F, K_F}, {K_BLK, K_BLK, K_BLK, K_BLK},
+                           {K_BLK2, K_BLK2, K_BLK2, K_BLK2}, {K_MF2, K_MF2, K_MF2, K_MF2}, {K_M, K_M, K_M, K_M}};
+    for (auto& st : sets) {
+      many(w4, st, 3);
+      many(w4, st, 4);
+    }
+  }
   printf("two waves on DIFFERENT SIMDs (waves 0 and 1)\n");
   pair(0, K_M, 1, K_F);
   pair(0, K_M, 1, K_M);
