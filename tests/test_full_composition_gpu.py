@@ -17,19 +17,19 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(arch, grid, ppb):
+def _model(arch, grid, ppb, stab=0.25):
     from crowdsam.model import CrowdSAM
     from crowdsam.utils import DEFAULT_TEST_CONFIG
     from crowdsam_amd import synth
     t = dict(DEFAULT_TEST_CONFIG)
     t.update(grid_size=grid, points_per_batch=ppb, pos_sim_thresh=-float("inf"), filter_thresh=float("inf"),
-             max_prompts=grid * grid, stability_score_thresh=0.25, pred_iou_thresh=0.05)
+             max_prompts=grid * grid, stability_score_thresh=stab, pred_iou_thresh=0.05)
     cfg = {"environ": {"device": "cuda"}, "model": {"sam_model": arch, "sam_arch": "crowdsam", "n_class": 1,
                                                     "trainfree": False, "dino_pos_offset": 0.1}, "test": t}
     return CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict(arch), dino_state_dict=synth.make_dino_state_dict())
 
 
-def _invariants(m, img, cuda, frame, grid):
+def _invariants(m, img, cuda, frame, grid, stab=0.25):
     from crowdsam_amd import hip
     from tests.test_stress_gpu import _decode, _rle_area_and_box
     snap = {}
@@ -54,7 +54,7 @@ def _invariants(m, img, cuda, frame, grid):
     boxes, scores = a["boxes"], a["scores"]
     assert len(boxes) == len(scores) == len(a["rles"]) > 0
     assert (boxes >= 0).all() and (boxes <= frame).all() and (a["points"] >= 0).all() and (a["points"] < frame).all()
-    assert (scores > 0.05).all() and (a["stability_score"] >= 0.25).all() and np.all(np.diff(scores) <= 0)
+    assert (scores > 0.05).all() and (a["stability_score"] >= stab).all() and np.all(np.diff(scores) <= 0)
     keep = hip.box_nms(torch.from_numpy(boxes).float().to(cuda), torch.from_numpy(scores).float().to(cuda), m.box_nms_thresh)
     assert len(keep) == len(boxes)                                          # NMS idempotence
     for i in range(0, len(boxes), max(1, len(boxes) // 6)):
@@ -94,8 +94,9 @@ def test_config2_vit_l_dinov2_l_grid64_full_composition(cuda):
 def test_config4_vit_h_depth32_1500_frame_grid128_full_composition(cuda):
     from oracle.make_goldens import full_frame
     g = np.load(os.path.join(G, "full_vit_h.npz"))
-    m = _model("vit_h", 128, 4096)
+    # stability_score_thresh 0: with the seeded ViT-H weights no mask reaches 0.25 (the stress bench line uses 0 as well)
+    m = _model("vit_h", 128, 4096, stab=0.0)
     assert m.predictor.model.image_encoder.depth == 32
-    feats, _ = _invariants(m, full_frame(4), cuda, 1500, 128)
+    feats, _ = _invariants(m, full_frame(4), cuda, 1500, 128, stab=0.0)
     assert abs(m.downscale - 1024 / 1500) < 1e-12 and m.image_hw == (1024, 1024)
     _check_feats(feats, g, 0.005, 0.05, "ViT-H x32")
