@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--stub-step", action="store_true",
                     help="launcher self-test (tests/test_bench_launcher_cpu.py): gloo ranks, a step is a host no-op")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-cpu-e2e", action="store_true",
+                    help="skip the measured end-to-end oracle image (64 prompts, ~1.5 min of host time) of the cpu_baseline leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -421,9 +423,11 @@ def main():
             import subprocess
             try:
                 cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), args.arch,
-                                     str(n_prompts)], capture_output=True, text=True, timeout=240)
+                                     str(n_prompts)] + ([] if args.no_cpu_e2e else ["--e2e"]),
+                                    capture_output=True, text=True, timeout=420)
                 cb = json.loads(cp.stdout.strip().splitlines()[-1])
-                res["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "stages_s")}
+                res["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "stages_s", "e2e_measured")
+                                       if k in cb}
                 res["config"]["speedup_vs_cpu_port"] = value / cb["value"]
             except Exception as exc:   # noqa: BLE001  (never let the baseline leg break the bench line)
                 res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",

@@ -134,8 +134,17 @@ def test_decoder_production_batch_vs_reference_golden(cuda):
     s_ref = np.clip(g["iou"], 0, None) / (1 + np.exp(-g["cls"][..., 0]))
     s_got = np.clip(iou.cpu().numpy(), 0, None) / (1 + np.exp(-cls.cpu().numpy()[..., 0]))
     top2 = np.sort(s_ref, 1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 1e-2
-    assert clear.sum() > 100 and np.array_equal(s_ref.argmax(1)[clear], s_got.argmax(1)[clear])
+    margin = top2[:, 1] - top2[:, 0]
+    clear = margin > 1e-2
+    flips = s_ref.argmax(1) != s_got.argmax(1)
+    # say how many prompts sit INSIDE the margin and how many of those actually flip.  A flip can only
+    # happen where the reference's own margin is smaller than twice the score error; the score error is bounded above.
+    e_s = np.abs(s_got - s_ref).max()
+    print("B=320 PWD-Net selection: %d of 320 prompts inside the 1e-2 margin, %d inside 2 x the score error (%.2e), %d flips "
+          "(all inside: %s)" % ((~clear).sum(), (margin < 2 * e_s).sum(), e_s, flips.sum(), bool(np.all(margin[flips] < 2 * e_s))))
+    assert clear.sum() > 100 and not flips[clear].any()
+    assert e_s < 5e-3 and np.all(margin[flips] < 2 * e_s)          # every flip is explained by the score tolerance
+    assert flips.sum() <= max(3, int(0.02 * 320))                   # and they are rare: <= 2 % of the prompts
 
 
 @pytest.mark.parametrize("B", [3, 300])

@@ -237,5 +237,7 @@ def test_encoder_vit_l_full_depth_vs_reference_golden(cuda):
     err = np.abs(y[:, ::4, 1::4, 2::4] - ref)
     scale = np.abs(ref).mean()
     print("ViT-L x24: mean|ref| %.3f  max err %.4f  mean err %.5f" % (scale, err.max(), err.mean()))
-    assert err.mean() < 0.01 * scale and err.max() < 0.1 * scale, (err.mean(), err.max(), scale)
+    # the bound was 1 % / 10 %; measured on MI355X 0.10 % / 0.6 % (same kernels as the in-pipeline
+    # check of tests/test_full_composition_gpu.py) -> measured x 2.5
+    assert err.mean() < 0.0025 * scale and err.max() < 0.015 * scale, (err.mean(), err.max(), scale)
     assert abs(np.abs(y.astype(np.float64)).sum() - float(g["abs_sum"])) < 0.005 * float(g["abs_sum"])

@@ -81,14 +81,15 @@ def test_config2_vit_l_dinov2_l_grid64_full_composition(cuda):
     m = _model("vit_l", 64, 4096)
     assert m.predictor.model.image_encoder.depth == 24 and m.predictor.dino_model.depth == 24
     feats, dino = _invariants(m, full_frame(2), cuda, 1024, 64)
-    # measured on MI355X (r3): mean 0.21 % / max 2.2 % of mean |feature| -> bounds = measured x 2
-    _check_feats(feats, g, 0.005, 0.05, "ViT-L x24")
+    # measured on MI355X (r3): mean 0.10 % / max 0.59 % of mean |feature| -> bounds = measured x 2.5
+    _check_feats(feats, g, 0.0025, 0.015, "ViT-L x24")
     ref = g["dino_sample"]
     err = np.abs(dino[::7, ::8] - ref)
     scale = np.abs(ref).mean()
     print("DINOv2-L x24 (+0.1 offset form, shipped) inside the pipeline: mean|ref| %.4f  mean err %.5f  max err %.4f"
           % (scale, err.mean(), err.max()))
-    assert err.mean() < 0.01 * scale and err.max() < 0.1 * scale, (err.mean() / scale, err.max() / scale)
+    # measured: mean 0.06 % / max 0.37 % of mean |token| -> x 2.5
+    assert err.mean() < 0.0015 * scale and err.max() < 0.01 * scale, (err.mean() / scale, err.max() / scale)
 
 
 def test_config4_vit_h_depth32_1500_frame_grid128_full_composition(cuda):
@@ -99,4 +100,4 @@ def test_config4_vit_h_depth32_1500_frame_grid128_full_composition(cuda):
     assert m.predictor.model.image_encoder.depth == 32
     feats, _ = _invariants(m, full_frame(4), cuda, 1500, 128, stab=0.0)
     assert abs(m.downscale - 1024 / 1500) < 1e-12 and m.image_hw == (1024, 1024)
-    _check_feats(feats, g, 0.005, 0.05, "ViT-H x32")
+    _check_feats(feats, g, 0.003, 0.016, "ViT-H x32")          # measured 0.11 % / 0.62 %
