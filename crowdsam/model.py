@@ -326,33 +326,38 @@ class CrowdSAM:
         self.last_candidates = n
         if n == 0:
             return None
-        data = MaskData(masks=store["masks"][:n].view(torch.bool), iou_preds=store["score"][:n],
+        # The masks STAY in their store slots: the record carries the slot numbers (``mask_slots``) where the reference
+        # carries a (n, H, W) bool tensor, every filter permutes 4-byte slot numbers instead of gathering megabyte masks,
+        # and the small-region clean-up, the optional mask NMS / prior fusion and the run-length encoder address
+        # store["masks"][slot] directly (a crowded frame keeps hundreds of masks: two gathers of ~0.3 GB each before).
+        mstore = store["masks"]
+        data = MaskData(mask_slots=torch.arange(n, dtype=torch.int32, device=dev), iou_preds=store["score"][:n],
                         points=store["points"][:n].long(), categories=store["category"][:n].long(),
                         stability_score=store["stability"][:n], boxes=store["boxes"][:n].long())
         t0 = self._tick("gather", t0)
 
         keep = batched_nms(data["boxes"].float(), data["iou_preds"], None, self.box_nms_thresh)
         data.filter(keep)
-        if self.mask_nms_thresh > 0 and len(data["masks"]) > 0:
+        if self.mask_nms_thresh > 0 and len(data["mask_slots"]) > 0:
             # opt-in (test.mask_nms_thresh, off in the shipped config): the coverage NMS on 150x150 masks the
             # reference defines but never calls (crowdsam/utils.py:422-467), on device
-            data.filter(hip.mask_nms(data["masks"], data["iou_preds"], self.mask_nms_thresh))
+            data.filter(hip.mask_nms(mstore[data["mask_slots"].long()], data["iou_preds"], self.mask_nms_thresh))
         t0 = self._tick("nms", t0)
         if self.min_mask_region_area > 0:
             data = self.postprocess_small_regions(data, self.min_mask_region_area,
-                                                  max(self.box_nms_thresh, self.crop_nms_thresh))
+                                                  max(self.box_nms_thresh, self.crop_nms_thresh), mask_store=mstore)
         t0 = self._tick("small_regions", t0)
         if self.fuse_simmap:
             # crowdsam/model.py:273-286: score = sqrt(iou) * sqrt(clamp(mean of the resized prior over the mask + 0.5))
             fh, fw = self.sim_feat_size
-            cls = torch.clamp(hip.mask_mean_bilinear(data["masks"], self.sim_map[:fh, :fw]) + 0.5, 0, 1)
+            cls = torch.clamp(hip.mask_mean_bilinear(mstore[data["mask_slots"].long()], self.sim_map[:fh, :fw]) + 0.5, 0, 1)
             data["scores"] = data["iou_preds"] ** 0.5 * cls ** 0.5
         else:
             data["scores"] = data["iou_preds"]
-        data["rles"] = mask_to_rle_arrays(data["masks"])    # run lengths as ndarrays -> C string packer
+        data["rles"] = mask_to_rle_arrays(mstore, idx=data["mask_slots"].contiguous())    # run lengths -> C string packer
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
-        del data["masks"]
+        del data["mask_slots"]
         data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, self.downscale)
         data["points"] = utils.uncrop_points(data["points"], crop_box, self.downscale)
         data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["boxes"]))]).reshape(-1, 4)
@@ -439,10 +444,25 @@ class CrowdSAM:
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def postprocess_small_regions(mask_data, min_area, nms_thresh):
+    def postprocess_small_regions(mask_data, min_area, nms_thresh, mask_store=None):
         """Hole filling / island removal and a second NMS that prefers untouched masks
         (crowdsam/model.py:394-443).  The reference labels components on the host one mask at a time; here
-        csam_small_regions does all masks of the frame on device and also returns the post-edit boxes."""
+        csam_small_regions does all masks of the frame on device and also returns the post-edit boxes.
+        ``mask_store`` (driver path): the record holds ``mask_slots`` into this (cap, H, W) store instead of ``masks``; the
+        clean-up then runs IN PLACE on those slots (csam_small_regions_idx) -- an unchanged mask is written back
+        unchanged, an edited one that survives the NMS below is the edited one the reference would write back, and the
+        rest is discarded either way."""
+        if mask_store is not None and "mask_slots" in mask_data:
+            if len(mask_data["mask_slots"]) == 0:
+                return mask_data
+            changed, boxes = hip.small_regions_idx(mask_store, mask_data["mask_slots"].contiguous(), min_area)
+            scores = (changed == 0).float()
+            keep = batched_nms(boxes, scores, None, nms_thresh)
+            edited = keep[scores[keep] == 0]
+            if edited.numel():
+                mask_data["boxes"][edited] = boxes[edited].to(mask_data["boxes"].dtype)
+            mask_data.filter(keep)
+            return mask_data
         if len(mask_data["masks"]) == 0:
             return mask_data
         masks = mask_data["masks"]

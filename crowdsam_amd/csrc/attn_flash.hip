@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const hal
     // v_pk_add_f32 that build the accumulator seeds -- and on MI355X that sequence intermittently loses: in 1-8 % of the
     // launches (depending on what else sits between the barrier and the seeds) ONE seed register of ONE wave came out
     // as c0 + 0 in lanes 48..63, i.e. its v_pk_add_f32 saw the Tw operand before the v_pk_mul_f32 ~15 instructions
-    // earlier had written that lane group (register dump of a failing launch: tools/dbg/flash_dump.py; key tile 0,
+    // earlier had written that lane group (register dump of a failing launch: tests/dbg/flash_dump.py; key tile 0,
     // second query tile, lane group 3 only; never with a zero Tw table; the raw table loads were complete, the
     // accumulators tied, the scaled register itself correct a moment later).  Round 2 saw the same signature and
     // mis-filed it as a register-recycling artefact.  With the products pinned before the loop, and the LDS-DMA issue

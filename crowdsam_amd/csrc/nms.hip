@@ -212,12 +212,12 @@ __global__ __launch_bounds__(64) void mask_cov_kernel(const uint64_t* __restrict
 // Fortran-order flattening (i = x*H + y) where the value changes.  Thread = column; pass 1 counts
 // per column, pass 2 writes the sorted positions at the exclusive-scan offsets.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restrict__ masks, int H, int W,
-                                                        int* __restrict__ col_counts) {
+__global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
+                                                        int H, int W, int* __restrict__ col_counts) {
   const int n = blockIdx.y;
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= W) return;
-  const uint8_t* m = masks + (long)n * H * W;
+  const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
   uint8_t prev = x > 0 ? m[(long)(H - 1) * W + x - 1] : m[x];   // x==0: no change at i==0
   int c = 0;
   for (int y = 0; y < H; ++y) {
@@ -226,6 +226,54 @@ __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restric
     prev = v;
   }
   col_counts[(long)n * W + x] = c;
+}
+
+// Four columns per thread (W % 4 == 0): one 4-byte load per row instead of four byte loads; the same counts / positions.
+__global__ __launch_bounds__(256) void rle_count4_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
+                                                         int H, int W, int* __restrict__ col_counts) {
+  const int n = blockIdx.y;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x >= W) return;
+  const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
+  const uint32_t last = *(const uint32_t*)(m + (long)(H - 1) * W + x);      // last row of the four columns
+  uint32_t prev = (last << 8) | (x > 0 ? m[(long)(H - 1) * W + x - 1] : (m[x] != 0));   // column c starts after column c-1 ends
+  // bytes are 0 / 1: compare as packed bytes
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll 8
+  for (int y = 0; y < H; ++y) {
+    const uint32_t v = *(const uint32_t*)(m + (long)y * W + x);
+    const uint32_t d = v ^ prev;
+    c0 += d & 1u; c1 += (d >> 8) & 1u; c2 += (d >> 16) & 1u; c3 += (d >> 24) & 1u;
+    prev = v;
+  }
+  int* cc = col_counts + (long)n * W + x;
+  cc[0] = c0; cc[1] = c1; cc[2] = c2; cc[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void rle_write4_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
+                                                         int H, int W, const int* __restrict__ col_offsets,
+                                                         const long* __restrict__ mask_offsets, uint32_t* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x >= W) return;
+  const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
+  const int* co = col_offsets + (long)n * W + x;
+  uint32_t* ob = out + mask_offsets[n];
+  uint32_t* o0 = ob + co[0]; uint32_t* o1 = ob + co[1]; uint32_t* o2 = ob + co[2]; uint32_t* o3 = ob + co[3];
+  const uint32_t last = *(const uint32_t*)(m + (long)(H - 1) * W + x);
+  uint32_t prev = (last << 8) | (x > 0 ? m[(long)(H - 1) * W + x - 1] : (m[x] != 0));
+#pragma unroll 8
+  for (int y = 0; y < H; ++y) {
+    const uint32_t v = *(const uint32_t*)(m + (long)y * W + x);
+    const uint32_t d = v ^ prev;
+    if (d) {
+      if (d & 1u) *o0++ = (uint32_t)(x * H + y);
+      if (d & 0x100u) *o1++ = (uint32_t)((x + 1) * H + y);
+      if (d & 0x10000u) *o2++ = (uint32_t)((x + 2) * H + y);
+      if (d & 0x1000000u) *o3++ = (uint32_t)((x + 3) * H + y);
+    }
+    prev = v;
+  }
 }
 
 __global__ __launch_bounds__(1024) void rle_scan_kernel(int* __restrict__ col_counts, int W, int* __restrict__ totals) {
@@ -251,14 +299,14 @@ __global__ __launch_bounds__(1024) void rle_scan_kernel(int* __restrict__ col_co
   if (threadIdx.x == 0) totals[n] = buf[W - 1];
 }
 
-__global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restrict__ masks, int H, int W,
-                                                        const int* __restrict__ col_offsets,
+__global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
+                                                        int H, int W, const int* __restrict__ col_offsets,
                                                         const long* __restrict__ mask_offsets,
                                                         uint32_t* __restrict__ out) {
   const int n = blockIdx.y;
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= W) return;
-  const uint8_t* m = masks + (long)n * H * W;
+  const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
   uint32_t* o = out + mask_offsets[n] + col_offsets[(long)n * W + x];
   uint8_t prev = x > 0 ? m[(long)(H - 1) * W + x - 1] : m[x];
   for (int y = 0; y < H; ++y) {
@@ -340,21 +388,40 @@ extern "C" int csam_mask_nms(void* stream, const void* masks_u8, const float* sc
   return CSAM_OK;
 }
 
-extern "C" int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals) {
+// masks_u8[idx[i]] for i < N when idx is given (store slots of the kept masks: no gather before the encoder), else masks_u8[i]
+extern "C" int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
+                                  int* col_offsets, int* totals) {
   CSAM_REQUIRE(masks_u8 && col_offsets && totals && N > 0 && H > 0 && W > 0 && W <= 4096, "csam_rle_count: bad args");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rle_count_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, s, (const uint8_t*)masks_u8, H, W,
-                     col_offsets);
+  if (W % 4 == 0 && ((long)H * W) % 4 == 0 && ((uintptr_t)masks_u8 & 3) == 0)
+    hipLaunchKernelGGL(rle_count4_kernel, dim3(csam_cdiv(W, 1024), N), dim3(256), 0, s, (const uint8_t*)masks_u8, idx_or_null, H,
+                       W, col_offsets);
+  else
+    hipLaunchKernelGGL(rle_count_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, s, (const uint8_t*)masks_u8, idx_or_null, H,
+                       W, col_offsets);
   hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(1024), 0, s, col_offsets, W, totals);
   CSAM_LAUNCH_CHECK("csam_rle_count");
   return CSAM_OK;
 }
 
-extern "C" int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
-                              const long* mask_offsets, uint32_t* out_positions) {
+extern "C" int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
+                                  const int* col_offsets, const long* mask_offsets, uint32_t* out_positions) {
   CSAM_REQUIRE(masks_u8 && col_offsets && mask_offsets && out_positions && N > 0, "csam_rle_write: bad args");
-  hipLaunchKernelGGL(rle_write_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, (hipStream_t)stream,
-                     (const uint8_t*)masks_u8, H, W, col_offsets, mask_offsets, out_positions);
+  if (W % 4 == 0 && ((long)H * W) % 4 == 0 && ((uintptr_t)masks_u8 & 3) == 0)
+    hipLaunchKernelGGL(rle_write4_kernel, dim3(csam_cdiv(W, 1024), N), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)masks_u8, idx_or_null, H, W, col_offsets, mask_offsets, out_positions);
+  else
+    hipLaunchKernelGGL(rle_write_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)masks_u8, idx_or_null, H, W, col_offsets, mask_offsets, out_positions);
   CSAM_LAUNCH_CHECK("csam_rle_write");
   return CSAM_OK;
+}
+
+extern "C" int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals) {
+  return csam_rle_count_idx(stream, masks_u8, nullptr, N, H, W, col_offsets, totals);
+}
+
+extern "C" int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
+                              const long* mask_offsets, uint32_t* out_positions) {
+  return csam_rle_write_idx(stream, masks_u8, nullptr, N, H, W, col_offsets, mask_offsets, out_positions);
 }

@@ -523,6 +523,402 @@ __global__ __launch_bounds__(256) void cc_extent_kernel(const uint8_t* __restric
   }
 }
 
+// =====================================================================================================================
+// Round 3: the same labelling WITHOUT per-pixel label arrays ("compact" form, csam_small_regions_idx).
+// The two-level form above still keeps two int32 values per pixel (tile-root pointer L, area S): 8 B written and ~20 B
+// read per mask byte and pass -- 355 one-megapixel masks move ~14 GB for a 0.36 GB input, and that traffic, not the
+// labelling, is what its 10 ms are.  Only components that reach a tile edge can continue in another tile, so only the
+// 252 RING pixels of a 64 x 64 tile need an identity outside the tile's LDS:
+//   scan    label the tile in LDS (same run-start / north-link union-find), count every tile component, give each one
+//           that owns ring pixels its smallest ring slot as representative; write per ring slot (256 per tile) its
+//           parent slot RP, and at the representative the component's area inside the tile RA and its raster-first pixel
+//           RF.  Components without ring pixels are complete: their small / big / arg-max flags go to the mask's meta now;
+//   border  the cross-edge links of cc_border_kernel (one union per contact run) on the ring forest RP;
+//   total   every representative adds its area to its global root (RT) and min-reduces the first pixel (RFT);
+//   ringmeta  flags of the ring components (global roots) -> meta;
+//   apply   no labelling: a pixel's tile root comes from a 2-byte-per-pixel array the scan left behind (R16), the tile's
+//           root pixels resolve their component's area (own count, or RT of their representative's global root) into a
+//           4 KB decision table, the tile's bytes are rewritten in place; the islands pass also reduces the box extents of
+//           what it writes.
+// Per pass: mask bytes read twice and written once, 2 B per pixel of roots written and read, 5 x 4 B per ring slot
+// (1/16 of a pixel): ~8 B per pixel instead of ~28.
+// Masks are addressed through an index list (store slots), so the NMS survivors are cleaned up where they lie.
+// =====================================================================================================================
+constexpr int C2_INF = 0x7fffffff;
+constexpr int C2_LDS = 64 * 8 + 4096 * 4 + 3 * 256 * 4; // row bit masks | P (parents, then rep : count per root) | ring records
+
+__device__ __forceinline__ int c2_ring_slot(int r, int c) { return r == 0 ? c : r == 63 ? 64 + c : c == 0 ? 128 + r : 192 + r; }
+// ring slot t -> tile-local (r, c); slots 128, 191, 192, 255 duplicate corner pixels owned by the row slots
+__device__ __forceinline__ bool c2_slot_rc(int t, int& r, int& c) {
+  if (t < 64) { r = 0; c = t; return true; }
+  if (t < 128) { r = 63; c = t - 64; return true; }
+  if (t < 192) { r = t - 128; c = 0; return r != 0 && r != 63; }
+  r = t - 192; c = 63;
+  return r != 0 && r != 63;
+}
+// start column of the horizontal run that contains `lane` in a row whose work bits are `bits` (lane is a work pixel)
+__device__ __forceinline__ int c2_run_start(unsigned long long bits, int lane) {
+  const unsigned long long below = (lane == 0) ? 0ull : (~bits & ((1ull << lane) - 1ull));
+  return below ? (64 - __clzll(below)) : 0;
+}
+
+__device__ __forceinline__ void c2_meta_reduce(unsigned long long key, int flags, RegionMeta* mm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off);
+    key = o > key ? o : key;
+    flags |= __shfl_xor(flags, off);
+  }
+  __shared__ unsigned long long rkey[4];
+  __shared__ int rflags[4];
+  if (lane == 0) { rkey[wave] = key; rflags[wave] = flags; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; ++w) {
+    key = rkey[w] > key ? rkey[w] : key;
+    flags |= rflags[w];
+  }
+  if (flags & 1) atomicOr(&mm->any_small, 1);
+  if (flags & 2) atomicOr(&mm->any_big, 1);
+  if (key) atomicMax(&mm->best, key);
+}
+
+// scan: labels one 64 x 64 tile in LDS and leaves, in global memory,
+//   R16[tile][pixel]  0xffff: not a work pixel; < 0x1000: the pixel's tile root (tile-local index r*64 + c of the component's
+//                     raster-first pixel); at the root pixel itself the component's record instead: 0x8000 | area inside the
+//                     tile (complete component), or 0xC000 | representative ring slot
+//   RP / RA / RF / RT / RFT[tile][ring slot]   the ring forest (see above)
+// A pixel's first parent is the start of its horizontal run, so only run starts walk the forest; their roots stay in
+// registers and reach the other pixels of the run by a wave shuffle (a row is one wave's iteration), which frees the
+// parent array: the same 16 KB then hold the per-root (representative : area) words.  16.5 KB of LDS per workgroup keeps
+// eight workgroups on a CU -- the union-find is a chain of dependent LDS atomics and lives on occupancy.
+template <int HOLES>
+__global__ __launch_bounds__(256, 8) void cc2_scan_kernel(const uint8_t* __restrict__ base, const int* __restrict__ idx,
+                                                       unsigned short* __restrict__ R16,
+                                                       int* __restrict__ RP, int* __restrict__ RA, int* __restrict__ RF,
+                                                       int* __restrict__ RT, int* __restrict__ RFT,
+                                                       RegionMeta* __restrict__ meta, int H, int W, int thresh) {
+  extern __shared__ __attribute__((aligned(16))) char c2smem[];
+  unsigned long long* rowbits = (unsigned long long*)c2smem;
+  int* P = (int*)(c2smem + 512);
+  unsigned* RC = (unsigned*)P;                          // after the labelling: (representative ring slot | 0xffff) << 16 | area
+  const int mi = blockIdx.y;
+  const uint8_t* m = base + (long)(idx ? idx[mi] : mi) * H * W;
+  const int sw = (W + 63) >> 6;
+  const int ty = blockIdx.x / sw, tx = blockIdx.x - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = x0 + lane;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i, y = y0 + r;
+    const bool wk = y < H && x < W && work_at<HOLES>(m, W, y, x);
+    const unsigned long long bits = __ballot(wk);
+    if (lane == 0) rowbits[r] = bits;
+    P[r * 64 + lane] = wk ? r * 64 + c2_run_start(bits, lane) : -1;
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {                      // north links: cc_tile_kernel's decision tree
+    const int r = wave * 16 + i;
+    if (r == 0) continue;
+    const unsigned long long cur = rowbits[r], up = rowbits[r - 1];
+    if (!((cur >> lane) & 1ull)) continue;
+    const bool w = lane > 0 && ((cur >> (lane - 1)) & 1ull);
+    const bool b = (up >> lane) & 1ull;
+    const bool c = lane < 63 && ((up >> (lane + 1)) & 1ull);
+    const int p = r * 64 + lane;
+    if (w) {
+      if (c && !b) lds_union(P, p, p - 63);
+      continue;
+    }
+    if (b) {
+      lds_union(P, p, p - 64);
+      continue;
+    }
+    const bool a = lane > 0 && ((up >> (lane - 1)) & 1ull);
+    if (a) lds_union(P, p, p - 65);
+    if (c) lds_union(P, p, p - 63);
+  }
+  __syncthreads();
+  // run starts: the run's final root, two 16-bit values per register (0xffff: not a run start) -- the kernel must stay
+  // under 64 registers to keep eight waves per SIMD
+  unsigned sroot2[8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned long long bits = rowbits[wave * 16 + i];
+    const bool start = ((bits >> lane) & 1ull) && (lane == 0 || !((bits >> (lane - 1)) & 1ull));
+    const unsigned v = start ? (unsigned)lds_find_halve(P, (wave * 16 + i) * 64 + lane) : 0xffffu;
+    if (i & 1) sroot2[i >> 1] |= v << 16;
+    else sroot2[i >> 1] = v;
+  }
+  auto sroot = [&](int i) -> int {
+    const unsigned v = (sroot2[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+    return v == 0xffffu ? -1 : (int)v;
+  };
+  __syncthreads();                                      // every walk is done: the parent array becomes the RC table
+  for (int i = threadIdx.x; i < 4096; i += 256) RC[i] = 0xffff0000u;
+  __syncthreads();
+  const int tile_id = mi * (int)gridDim.x + (int)blockIdx.x;
+  unsigned short* r16 = R16 + (long)tile_id * 4096;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i;
+    const unsigned long long bits = rowbits[r];
+    const bool wk = (bits >> lane) & 1ull;
+    const int sr = sroot(i);
+    if (sr >= 0) {                                      // run length -> the root's area
+      const unsigned long long rest = ~(bits >> lane);
+      const int len = rest ? __ffsll((long long)rest) - 1 : 64 - lane;
+      atomicAdd(&RC[sr], (unsigned)len);
+    }
+    const int from = __shfl(sr, wk ? c2_run_start(bits, lane) : lane);   // every pixel: root of its run
+    if (!(wk && from == r * 64 + lane)) r16[r * 64 + lane] = wk ? (unsigned short)from : (unsigned short)0xffffu;
+    if (wk && (r == 0 || r == 63 || lane == 0 || lane == 63)) {   // ring pixel: 16-bit min of the slot in the high half
+      const unsigned slot = (unsigned)c2_ring_slot(r, lane);
+      unsigned old = RC[from];
+      while ((old >> 16) > slot) {
+        const unsigned seen = atomicCAS(&RC[from], old, (slot << 16) | (old & 0xffffu));
+        if (seen == old) break;
+        old = seen;
+      }
+    }
+  }
+  __syncthreads();
+  const int cb = tile_id * 256;
+  int* ring = (int*)(c2smem + 512 + 4096 * 4);          // [3][256] staged ring records: RP | RA | RF
+  ring[threadIdx.x] = -1;
+  ring[256 + threadIdx.x] = 0;
+  ring[512 + threadIdx.x] = C2_INF;
+  __syncthreads();
+  unsigned long long key = 0ull;
+  int flags = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave * 16 + i, q = r * 64 + lane;
+    const int sr = sroot(i);
+    if (r == 0 || r == 63) {                            // ring rows: every work pixel of the row
+      const unsigned long long bits = rowbits[r];
+      const bool wk = (bits >> lane) & 1ull;
+      const int from = __shfl(sr, wk ? c2_run_start(bits, lane) : lane);
+      if (wk) {
+        const int slot = c2_ring_slot(r, lane);
+        const unsigned w = RC[from];
+        ring[slot] = cb + (int)(w >> 16);
+        if ((int)(w >> 16) == slot) {
+          ring[256 + slot] = (int)(w & 0xffffu);
+          ring[512 + slot] = (y0 + (from >> 6)) * W + x0 + (from & 63);
+        }
+      }
+    } else {                                            // ring columns: lane 0 is its own run start, lane 63 asks its run start
+      const unsigned long long bits = rowbits[r];
+      const bool w63 = (bits >> 63) & 1ull;
+      const int from63 = __shfl(sr, w63 ? c2_run_start(bits, 63) : 63);
+      const bool mine = (lane == 0 && (bits & 1ull)) || (lane == 63 && w63);
+      if (mine) {
+        const int from = lane == 0 ? sr : from63;
+        const int slot = c2_ring_slot(r, lane);
+        const unsigned w = RC[from];
+        ring[slot] = cb + (int)(w >> 16);
+        if ((int)(w >> 16) == slot) {
+          ring[256 + slot] = (int)(w & 0xffffu);
+          ring[512 + slot] = (y0 + (from >> 6)) * W + x0 + (from & 63);
+        }
+      }
+    }
+    if (sr != q) continue;                              // tile roots: their R16 entry becomes the component's record
+    const unsigned w = RC[q];
+    if ((w >> 16) != 0xffffu) {
+      r16[q] = (unsigned short)(0xC000u | (w >> 16));   // 0x8000: root record, 0x4000: ring component, low bits: ring slot
+      continue;
+    }
+    const int area = (int)(w & 0xffffu);                // complete component (no ring pixel): area <= 4096, flags now
+    r16[q] = (unsigned short)(0x8000u | (unsigned)area);
+    flags |= area < thresh ? 1 : 2;
+    const unsigned p = (unsigned)((y0 + r) * W + x0 + lane);
+    const unsigned long long k = ((unsigned long long)(unsigned)area << 32) | (0xffffffffu - p);
+    key = k > key ? k : key;
+  }
+  __syncthreads();
+  RP[cb + threadIdx.x] = ring[threadIdx.x];
+  RA[cb + threadIdx.x] = ring[256 + threadIdx.x];
+  RF[cb + threadIdx.x] = ring[512 + threadIdx.x];
+  RT[cb + threadIdx.x] = 0;
+  RFT[cb + threadIdx.x] = C2_INF;
+  c2_meta_reduce(key, flags, meta + mi);
+}
+
+// cc_border_kernel on the ring forest: the same contact-run logic, endpoints named by their compact ring slot
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc2_border_kernel(const uint8_t* __restrict__ base, const int* __restrict__ idx,
+                                                         int* __restrict__ RP, int H, int W) {
+  const int mi = blockIdx.y;
+  const uint8_t* m = base + (long)(idx ? idx[mi] : mi) * H * W;
+  const int sw = (W + 63) >> 6, tiles = ((H + 63) >> 6) * sw;
+  auto at = [&](int y, int x) -> bool { return y >= 0 && x >= 0 && x < W && y < H && work_at<HOLES>(m, W, y, x); };
+  auto cs = [&](int y, int x) -> int { return (mi * tiles + (y >> 6) * sw + (x >> 6)) * 256 + c2_ring_slot(y & 63, x & 63); };
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= 2 * tiles) return;
+  const int tile = wv < tiles ? wv : wv - tiles;
+  const int ty = tile / sw, tx = tile - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64;
+  if (wv < tiles) {                                     // the row below a horizontal tile edge (or row 0)
+    const int y = y0, x = x0 + lane;
+    const bool in = x < W;
+    const bool cur = in && at(y, x);
+    const bool up = in && at(y - 1, x);
+    const unsigned long long cb = __ballot(cur), ub = __ballot(up);
+    if (!cur) return;
+    if (lane == 0 && at(y, x - 1)) uf_union(RP, cs(y, x), cs(y, x - 1));
+    if (y == 0) return;
+    const unsigned long long cn = cb & ub;
+    const bool n_here = (cn >> lane) & 1ull;
+    const bool n_left = lane > 0 && ((cn >> (lane - 1)) & 1ull);
+    const bool n_right = lane < 63 && ((cn >> (lane + 1)) & 1ull);
+    if (n_here) {
+      if (!n_left) uf_union(RP, cs(y, x), cs(y - 1, x));
+      return;
+    }
+    const bool upl = lane > 0 ? ((ub >> (lane - 1)) & 1ull) : at(y - 1, x0 - 1);
+    const bool upr = lane < 63 ? ((ub >> (lane + 1)) & 1ull) : at(y - 1, x0 + 64);
+    if (upl && !n_left) uf_union(RP, cs(y, x), cs(y - 1, x - 1));
+    if (upr && !n_right) uf_union(RP, cs(y, x), cs(y - 1, x + 1));
+    return;
+  }
+  const int y = y0 + lane;
+  if (lane == 0 || y >= H) return;
+  if (at(y, x0)) {                                      // first column: W / NW into the tile on the left
+    const bool n = at(y - 1, x0);
+    if (at(y, x0 - 1)) {
+      if (!(n && at(y - 1, x0 - 1))) uf_union(RP, cs(y, x0), cs(y, x0 - 1));
+    } else if (!n && at(y - 1, x0 - 1)) {
+      uf_union(RP, cs(y, x0), cs(y - 1, x0 - 1));
+    }
+  }
+  const int xr = x0 + 63;                               // last column: NE into the tile on the right
+  if (xr + 1 < W && at(y, xr) && !at(y - 1, xr) && !at(y, xr + 1) && at(y - 1, xr + 1))
+    uf_union(RP, cs(y, xr), cs(y - 1, xr + 1));
+}
+
+__global__ __launch_bounds__(256) void cc2_total_kernel(int* __restrict__ RP, const int* __restrict__ RA,
+                                                        const int* __restrict__ RF, int* __restrict__ RT,
+                                                        int* __restrict__ RFT, long slots) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= slots) return;
+  const int a = RA[i];
+  if (a <= 0) return;
+  const int root = uf_find(RP, (int)i);
+  atomicAdd(RT + root, a);
+  atomicMin(RFT + root, RF[i]);
+}
+
+__global__ __launch_bounds__(256) void cc2_ringmeta_kernel(const int* __restrict__ RP, const int* __restrict__ RT,
+                                                           const int* __restrict__ RFT, RegionMeta* __restrict__ meta,
+                                                           int per_mask, int thresh) {
+  const int mi = blockIdx.y;
+  const int per = (per_mask + gridDim.x - 1) / gridDim.x;
+  const int s0 = blockIdx.x * per, s1 = min(per_mask, s0 + per);
+  unsigned long long key = 0ull;
+  int flags = 0;
+  for (int s = s0 + threadIdx.x; s < s1; s += 256) {
+    const int i = mi * per_mask + s;
+    if (RP[i] != i) continue;
+    const int area = RT[i];
+    if (area <= 0) continue;
+    flags |= area < thresh ? 1 : 2;
+    const unsigned long long k = ((unsigned long long)(unsigned)area << 32) | (0xffffffffu - (unsigned)RFT[i]);
+    key = k > key ? k : key;
+  }
+  c2_meta_reduce(key, flags, meta + mi);
+}
+
+// apply: no labelling -- a pixel's tile root comes from R16, the tile's root pixels work out their component's decision
+// (area from its own R16 record, or from the ring forest's totals) into a 4 KB LDS table, every pixel looks its root's decision up.
+template <int HOLES>
+__global__ __launch_bounds__(256) void cc2_apply_kernel(const uint8_t* in_base, uint8_t* out_base, const int* __restrict__ idx,
+                                                        const unsigned short* __restrict__ R16, const int* __restrict__ RP,
+                                                        const int* __restrict__ RT, const int* __restrict__ RFT,
+                                                        const RegionMeta* __restrict__ meta, int* __restrict__ ext, int H, int W,
+                                                        int thresh) {
+  __shared__ uint8_t dec[4096];
+  const int mi = blockIdx.y;
+  const long moff = (long)(idx ? idx[mi] : mi) * H * W;
+  const uint8_t* m = in_base + moff;
+  uint8_t* o = out_base + moff;
+  const int sw = (W + 63) >> 6;
+  const int ty = blockIdx.x / sw, tx = blockIdx.x - ty * sw;
+  const int x0 = tx * 64, y0 = ty * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = x0 + lane;
+  const RegionMeta mm = meta[mi];
+  int ex0 = W, ey0 = H, ex1 = -1, ey1 = -1;
+  if (!mm.any_small) {                                 // nothing to edit in this pass: copy (or leave in place)
+    for (int i = 0; i < 16; ++i) {
+      const int y = y0 + wave * 16 + i;
+      if (y >= H || x >= W) continue;
+      const uint8_t v = m[(long)y * W + x] != 0;
+      if (o != m) o[(long)y * W + x] = v;
+      if (!HOLES && v) { ex0 = min(ex0, x); ex1 = max(ex1, x); ey0 = min(ey0, y); ey1 = max(ey1, y); }
+    }
+  } else {
+    const int tile_id = mi * (int)gridDim.x + (int)blockIdx.x;
+    const unsigned short* r16 = R16 + (long)tile_id * 4096;
+    const int cb = tile_id * 256;
+    const unsigned best_first = 0xffffffffu - (unsigned)(mm.best & 0xffffffffull);
+    unsigned short roots[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = (wave * 16 + i) * 64 + lane;
+      const unsigned short rt = r16[q];
+      roots[i] = rt;
+      if (rt == 0xffffu || !(rt & 0x8000u)) continue;    // root pixels carry their component's record
+      roots[i] = (unsigned short)q;
+      int area = (int)(rt & 0x3fffu);
+      unsigned first = (unsigned)((y0 + (q >> 6)) * W + x0 + (q & 63));
+      if (rt & 0x4000u) {
+        const int g = uf_find(RP, cb + (int)(rt & 0x3fffu));
+        area = RT[g];
+        first = (unsigned)RFT[g];
+      }
+      // 1 = the component's pixels are SET in the output
+      dec[q] = HOLES ? (area < thresh) : (mm.any_big ? (area >= thresh) : (first == best_first));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int y = y0 + wave * 16 + i;
+      if (y >= H || x >= W) continue;
+      const unsigned short rt = roots[i];
+      bool v;
+      if (HOLES) v = rt == 0xffffu || dec[rt] != 0;      // foreground stays; small background components are filled
+      else v = rt != 0xffffu && dec[rt] != 0;
+      o[(long)y * W + x] = v ? 1 : 0;
+      if (!HOLES && v) { ex0 = min(ex0, x); ex1 = max(ex1, x); ey0 = min(ey0, y); ey1 = max(ey1, y); }
+    }
+  }
+  if (!HOLES) {                                        // box extents of the final mask: <= 4 atomics per tile
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ex0 = min(ex0, __shfl_xor(ex0, off)); ey0 = min(ey0, __shfl_xor(ey0, off));
+      ex1 = max(ex1, __shfl_xor(ex1, off)); ey1 = max(ey1, __shfl_xor(ey1, off));
+    }
+    __shared__ int red[4][4];
+    if (lane == 0) { red[wave][0] = ex0; red[wave][1] = ey0; red[wave][2] = ex1; red[wave][3] = ey1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        ex0 = min(ex0, red[w][0]); ey0 = min(ey0, red[w][1]);
+        ex1 = max(ex1, red[w][2]); ey1 = max(ey1, red[w][3]);
+      }
+      if (ex1 >= 0) {
+        int* e = ext + (long)mi * 4;
+        atomicMin(e + 0, ex0); atomicMin(e + 1, ey0);
+        atomicMax(e + 2, ex1); atomicMax(e + 3, ey1);
+      }
+    }
+  }
+}
+
 __global__ void cc_prepare_kernel(RegionMeta* meta, int* ext, int n, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n) {
@@ -610,6 +1006,64 @@ extern "C" int csam_mask_mean_bilinear(void* stream, const uint8_t* masks, int n
   const dim3 grid(std::min(std::min(std::max(1024 / n, 16), 256), std::max(1, segs / 8)), n);
   hipLaunchKernelGGL(mask_mean_bilinear_kernel, grid, dim3(256), 0, s, masks, sim, fh, fw, ld_sim, H, W, sum, count);
   CSAM_LAUNCH_CHECK("csam_mask_mean_bilinear");
+  return CSAM_OK;
+}
+
+extern "C" long csam_small_regions_idx_workspace_bytes(int n, int H, int W) {
+  if (n <= 0 || H <= 0 || W <= 0) return 0;
+  const long tiles = (long)n * ((H + 63) >> 6) * ((W + 63) >> 6);
+  return 5 * align256(tiles * 256 * 4) + align256(tiles * 4096 * 2) + align256((long)2 * n * sizeof(RegionMeta)) +
+         align256((long)n * 16);
+}
+
+// remove_small_regions (holes, then islands) on the masks masks_base[idx[i]] (idx == NULL: i), i < n, written to
+// out_base[idx[i]] -- out_base may equal masks_base (in place).  Compact form: see the comment above cc2_scan_kernel.
+extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, const int* idx, uint8_t* out_base,
+                                      int* changed, float* boxes, int n, int H, int W, int min_area, void* ws,
+                                      long ws_bytes) {
+  CSAM_REQUIRE(masks_base && out_base && changed && boxes && ws, "csam_small_regions_idx: null pointer");
+  CSAM_REQUIRE(n > 0 && H > 0 && W > 0 && (long)H * W < (1L << 31), "csam_small_regions_idx: bad shape");
+  const int tiles = ((H + 63) >> 6) * ((W + 63) >> 6);
+  const long slots = (long)n * tiles * 256;
+  CSAM_REQUIRE(n <= 65535 && slots < (1L << 31), "csam_small_regions_idx: too many masks for one call");
+  CSAM_REQUIRE(ws_bytes >= csam_small_regions_idx_workspace_bytes(n, H, W), "csam_small_regions_idx: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  char* w = (char*)ws;
+  int* RP = (int*)w; w += align256(slots * 4);
+  int* RA = (int*)w; w += align256(slots * 4);
+  int* RF = (int*)w; w += align256(slots * 4);
+  int* RT = (int*)w; w += align256(slots * 4);
+  int* RFT = (int*)w; w += align256(slots * 4);
+  unsigned short* R16 = (unsigned short*)w; w += align256((long)n * tiles * 4096 * 2);
+  RegionMeta* meta = (RegionMeta*)w; w += align256((long)2 * n * sizeof(RegionMeta));
+  int* ext = (int*)w;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)cc2_scan_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
+    (void)hipFuncSetAttribute((const void*)cc2_scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
+    attr = true;
+  }
+  const dim3 block(256), tgrid(tiles, n), bgrid(csam_cdiv(2 * tiles, 4), n), sgrid((unsigned)csam_cdiv(slots, 256));
+  const dim3 mgrid(std::min(16, std::max(1, tiles / 4)), n);
+  hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);
+  // pass 1: holes (components of the complement), masks -> out
+  hipLaunchKernelGGL(cc2_scan_kernel<1>, tgrid, block, C2_LDS, stream, masks_base, idx, R16, RP, RA, RF, RT, RFT, meta, H, W,
+                     min_area);
+  hipLaunchKernelGGL(cc2_border_kernel<1>, bgrid, block, 0, stream, masks_base, idx, RP, H, W);
+  hipLaunchKernelGGL(cc2_total_kernel, sgrid, block, 0, stream, RP, RA, RF, RT, RFT, slots);
+  hipLaunchKernelGGL(cc2_ringmeta_kernel, mgrid, block, 0, stream, RP, RT, RFT, meta, tiles * 256, min_area);
+  hipLaunchKernelGGL(cc2_apply_kernel<1>, tgrid, block, 0, stream, masks_base, out_base, idx, R16, RP, RT, RFT, meta, ext,
+                     H, W, min_area);
+  // pass 2: islands (components of the hole-filled mask), out -> out
+  hipLaunchKernelGGL(cc2_scan_kernel<0>, tgrid, block, C2_LDS, stream, out_base, idx, R16, RP, RA, RF, RT, RFT, meta + n, H,
+                     W, min_area);
+  hipLaunchKernelGGL(cc2_border_kernel<0>, bgrid, block, 0, stream, out_base, idx, RP, H, W);
+  hipLaunchKernelGGL(cc2_total_kernel, sgrid, block, 0, stream, RP, RA, RF, RT, RFT, slots);
+  hipLaunchKernelGGL(cc2_ringmeta_kernel, mgrid, block, 0, stream, RP, RT, RFT, meta + n, tiles * 256, min_area);
+  hipLaunchKernelGGL(cc2_apply_kernel<0>, tgrid, block, 0, stream, out_base, out_base, idx, R16, RP, RT, RFT, meta + n,
+                     ext, H, W, min_area);
+  hipLaunchKernelGGL(cc_finish_kernel, dim3(csam_cdiv(n, 256)), dim3(256), 0, stream, meta, ext, n, changed, boxes);
+  CSAM_LAUNCH_CHECK("csam_small_regions_idx");
   return CSAM_OK;
 }
 

@@ -57,10 +57,13 @@ SIGNATURES = {
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
     "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_rle_count_idx": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "csam_rle_write_idx": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "csam_mask_nms": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _L],
     "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
     "csam_mask_mean_bilinear": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
+    "csam_small_regions_idx": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
@@ -91,6 +94,7 @@ LONG_RETURNS = {
     "csam_box_nms_workspace_bytes": [_I],
     "csam_mask_nms_workspace_bytes": [_I],
     "csam_small_regions_workspace_bytes": [_I, _I, _I],
+    "csam_small_regions_idx_workspace_bytes": [_I, _I, _I],
     "csam_t2i_fused_workspace_bytes": [_I],
     "csam_flash_attn_workspace_bytes": [_I, _I],
     "csam_i2t_rank_workspace_bytes": [_I],
@@ -566,6 +570,29 @@ def small_regions(masks, min_area):
     return out, changed, boxes
 
 
+def small_regions_idx(mask_store, idx, min_area, out_store=None):
+    """Compact form (csam_small_regions_idx): cleans up the masks ``mask_store[idx[i]]`` WHERE THEY LIE (``out_store`` None:
+    in place; else the same slots of ``out_store``) -- no gather of the NMS survivors, no per-pixel label arrays.
+    mask_store u8/bool [cap,H,W]; idx int32 [n] device tensor or None (= the first n = cap masks).
+    -> (changed int32 [n], boxes f32 [n,4])."""
+    cap, H, W = mask_store.shape
+    assert mask_store.is_contiguous()
+    m8 = mask_store.view(torch.uint8) if mask_store.dtype == torch.bool else mask_store
+    o8 = m8 if out_store is None else (out_store.view(torch.uint8) if out_store.dtype == torch.bool else out_store)
+    n = cap if idx is None else int(idx.shape[0])
+    changed = torch.empty((n,), dtype=torch.int32, device=m8.device)
+    boxes = torch.empty((n, 4), dtype=torch.float32, device=m8.device)
+    if n == 0:
+        return changed, boxes
+    if idx is not None:
+        assert idx.dtype == torch.int32 and idx.is_contiguous()
+    nbytes = lib().csam_small_regions_idx_workspace_bytes(n, H, W)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=m8.device)
+    call("csam_small_regions_idx", _stream(), _ptr(m8), _ptr(idx), _ptr(o8), _ptr(changed), _ptr(boxes), n, H, W,
+         int(min_area), _ptr(ws), nbytes)
+    return changed, boxes
+
+
 def mask_nms(masks, scores, thr):
     """Coverage NMS over 150x150 nearest-resampled masks (crowdsam/utils.py mask_iou_nms).  masks u8/bool [N,H,W],
     scores f32 [N] -> kept indices int64 (device) in descending-score order."""
@@ -582,18 +609,20 @@ def mask_nms(masks, scores, thr):
     return keep[: int(count.item())]
 
 
-def rle_encode(masks):
-    """Column-major change positions of u8 masks [N,H,W] -> (positions uint32 (device), offsets int64 (host, N+1))."""
-    N, H, W = masks.shape
+def rle_encode(masks, idx=None):
+    """Column-major change positions of u8 masks -> (positions uint32 (device), offsets int64 (host, N+1)).
+    ``idx`` None: masks [N,H,W]; else masks is a store [cap,H,W] and idx (int32 device [N]) names the slots to encode."""
+    cap, H, W = masks.shape
+    N = cap if idx is None else int(idx.shape[0])
     col = torch.empty((N, W), dtype=torch.int32, device=masks.device)
     totals = torch.empty(N, dtype=torch.int32, device=masks.device)
-    call("csam_rle_count", _stream(), _ptr(masks), N, H, W, _ptr(col), _ptr(totals))
+    call("csam_rle_count_idx", _stream(), _ptr(masks), _ptr(idx), N, H, W, _ptr(col), _ptr(totals))
     tot = totals.cpu().to(torch.int64)
     offs = torch.zeros(N + 1, dtype=torch.int64)
     offs[1:] = torch.cumsum(tot, 0)
     out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int32, device=masks.device)
     offs_dev = offs[:-1].to(masks.device)
-    call("csam_rle_write", _stream(), _ptr(masks), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
+    call("csam_rle_write_idx", _stream(), _ptr(masks), _ptr(idx), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
     return out, offs
 
 

@@ -297,10 +297,23 @@ int csam_mask_nms(void* stream, const void* masks_u8, const float* scores, int N
 int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals);
 int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
                    const long* mask_offsets, uint32_t* out_positions);
+/* The same two passes over the masks masks_u8[idx[i]] (idx NULL: i): the run-length encoder reads the kept masks in
+ * their store slots instead of a gathered copy (amg.py:107-135 via crowdsam/model.py:288-296). */
+int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W, int* col_offsets,
+                       int* totals);
+int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
+                       const int* col_offsets, const long* mask_offsets, uint32_t* out_positions);
 
 /* ---- small-region clean-up (amg.py:267-291 remove_small_regions mode "holes" then "islands", 8-connected,
  * as driven by crowdsam/model.py:394-443): masks u8 [n,H,W] -> out u8 (may alias masks), changed int32 [n]
  * (either pass modified the mask), boxes f32 [n,4] XYXY of the edited masks (amg.py:293-324) */
+/* Compact form of csam_small_regions (round 3): the same hole filling + island removal on the masks masks_base[idx[i]]
+ * (idx NULL: i) written to out_base[idx[i]] (out_base may equal masks_base: in place) -- the NMS survivors are cleaned up
+ * in their store slots, and no per-pixel label array exists (ring-forest labelling, csrc/regions.hip).  Replaces the host
+ * loop of crowdsam/model.py:394-443 over amg.py:267-291 exactly like csam_small_regions. */
+long csam_small_regions_idx_workspace_bytes(int n, int H, int W);
+int csam_small_regions_idx(void* stream, const uint8_t* masks_base, const int* idx_or_null, uint8_t* out_base, int* changed,
+                           float* boxes, int n, int H, int W, int min_area, void* workspace, long workspace_bytes);
 long csam_small_regions_workspace_bytes(int n, int H, int W);
 int csam_small_regions(void* stream, const uint8_t* masks, uint8_t* out, int* changed, float* boxes, int n, int H,
                        int W, int min_area, void* workspace, long workspace_bytes);

@@ -150,17 +150,21 @@ def _runs_from_positions(pos, first_set, hw):
     return np.concatenate([[0], runs]) if first_set else runs
 
 
-def mask_to_rle_arrays(tensor):
+def mask_to_rle_arrays(tensor, idx=None):
     """mask_to_rle_pytorch with the run lengths kept as int64 ndarrays (what the driver feeds straight into
-    the C string packer: a crowded frame has 1e5+ runs per mask, Python lists would dominate the tail)."""
+    the C string packer: a crowded frame has 1e5+ runs per mask, Python lists would dominate the tail).
+    ``idx`` (device int32 [b]): ``tensor`` is a (cap, h, w) mask store and only the slots named by idx are encoded, in
+    that order, where they lie."""
     b, h, w = tensor.shape
+    if idx is not None:
+        b = int(idx.shape[0])
     if b == 0:
         return []
     if tensor.is_cuda:
         m8 = (tensor.view(torch.uint8) if tensor.dtype == torch.bool else tensor.to(torch.uint8)).contiguous()
-        pos, offs = hip.rle_encode(m8)
+        pos, offs = hip.rle_encode(m8, idx)
         pos = pos.cpu().numpy().astype(np.int64)
-        first = m8[:, 0, 0].cpu().numpy().astype(bool)
+        first = (m8[:, 0, 0] if idx is None else m8[idx.long(), 0, 0]).cpu().numpy().astype(bool)
         # run lengths of ALL masks in one pass (a crowded frame keeps hundreds of masks: per-mask numpy calls were the
         # tail's largest host cost): per mask the sequence [0 if the first pixel is set] 0 pos... hw, differenced
         offs = np.asarray(offs, dtype=np.int64)

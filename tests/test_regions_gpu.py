@@ -28,12 +28,32 @@ def _oracle(masks, min_area):
 
 
 def _check(cuda, masks, min_area):
+    """Both device forms against the oracle: the two-level form with per-pixel labels (csam_small_regions) and the compact
+    ring-forest form the driver uses (csam_small_regions_idx), the latter in place, through an index list that picks the
+    masks out of a larger store in shuffled order, and once more into a separate output store."""
     from crowdsam_amd import hip
-    out, changed, boxes = hip.small_regions(torch.as_tensor(masks).to(cuda), min_area)
     ro, rc, rb = _oracle(masks, min_area)
+    out, changed, boxes = hip.small_regions(torch.as_tensor(masks).to(cuda), min_area)
     assert np.array_equal(changed.cpu().numpy(), rc)
     assert np.array_equal(out.cpu().numpy().astype(bool), ro)
     assert np.array_equal(boxes.cpu().numpy(), rb)
+    n = len(masks)
+    rng = np.random.RandomState(n)
+    slots = rng.permutation(n + 3)[:n].astype(np.int32)              # store of n + 3 masks, survivors scattered
+    store = torch.zeros((n + 3,) + masks.shape[1:], dtype=torch.uint8, device=cuda)
+    store[torch.as_tensor(slots).long().to(cuda)] = torch.as_tensor(masks).to(cuda).to(torch.uint8)
+    untouched = store.clone()
+    idx = torch.as_tensor(slots).to(cuda)
+    out2 = torch.full_like(store, 7)
+    ch2, bx2 = hip.small_regions_idx(store, idx, min_area, out_store=out2)
+    assert torch.equal(store, untouched)                              # input store not written
+    assert np.array_equal(ch2.cpu().numpy(), rc) and np.array_equal(bx2.cpu().numpy(), rb)
+    assert np.array_equal(out2[idx.long()].cpu().numpy().astype(bool), ro)
+    ch3, bx3 = hip.small_regions_idx(store, idx, min_area)            # in place
+    assert np.array_equal(ch3.cpu().numpy(), rc) and np.array_equal(bx3.cpu().numpy(), rb)
+    assert np.array_equal(store[idx.long()].cpu().numpy().astype(bool), ro)
+    rest = np.setdiff1d(np.arange(n + 3), slots)
+    assert int(store[torch.as_tensor(rest).long().to(cuda)].sum()) == 0      # slots outside the list untouched
 
 
 @pytest.mark.parametrize("hw", [(683, 1024), (1024, 683), (97, 130), (64, 64), (5, 200)])
