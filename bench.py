@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Crowd-SAM dense-prompt inference throughput on MI355X (contract in the task brief).
 
-One "step" = one synthetic 1024x1024 crowd frame through the whole hot path (SAM ViT-L encoder +
+One "step" = one synthetic 1024x1024 CROWDED frame (~320 masks kept, see --crowd-keep) through the whole hot path (SAM ViT-L encoder +
 DINOv2-L + dense sweep of a 64x64 prompt grid = 4096 prompts through the two-way decoder, PWD-Net
 selection, fused mask post-processing, NMS, small-region clean-up, RLE) -> final numpy result.
 Weights are synthetic (seeded, reference key layout): there are no checkpoints on the box.
@@ -210,8 +210,9 @@ def main():
     ap.add_argument("--encoder-only", action="store_true",
                     help="BASELINE configs[1]: SAM image-encoder forward only on a random normalised 1024^2 tensor")
     ap.add_argument("--crowd-keep", type=int, default=700,
-                    help="second measured leg (dense mode): ~this many masks per image survive NMS into the small-region "
-                         "clean-up + RLE (box NMS off, score cut calibrated on the warm-up frames); 0 disables the leg")
+                    help="dense mode: the timed frames are CROWDED -- box NMS off and a predicted-IoU cut calibrated on a warm-up "
+                         "frame let ~this many candidates through, ~320 masks per image then go through small-region clean-up "
+                         "+ RLE; 0 = time the shipped thresholds (random-weight masks collapse to ~1 in NMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stub-step", action="store_true",
                     help="launcher self-test (tests/test_bench_launcher_cpu.py): gloo ranks, a step is a host no-op")
@@ -268,22 +269,40 @@ def main():
         torch.cuda.synchronize()
 
     from crowdsam_amd.distributed import detections_to_rows, gather_rows
-    n_kept = 0
-    n_pre_nms = 0
-    rows = [np.zeros((0, 6), np.float32)]
-    for i in range(args.warmup):
-        model.generate(frames[i])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        out = model.generate(frames[i])
-        n_kept += len(out["boxes"])
-        n_pre_nms += model.last_candidates
-        rows.append(detections_to_rows(rank * args.steps + i - args.warmup, out["boxes"], out["scores"]))
-    torch.cuda.synchronize()
-    my_elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # HEADLINE = the CROWDED frame.  With seeded random weights the 4096 candidate masks are
+    # near-identical blobs, the shipped box NMS (0.65) keeps ~1 of them and the tail of the path (small-region clean-up by
+    # connected components, RLE, COCO strings) would run on ONE mask.  A crowded CrowdHuman frame keeps hundreds.  So the
+    # timed region runs with box NMS off and a predicted-IoU cut calibrated on a warm-up frame such that ~crowd_keep
+    # candidates pass it: ~320 masks per image then survive the small-region NMS and go through the whole tail.  The sweep
+    # (encoders + 4096 prompts through the decoder + mask statistics) is the same either way.  --crowd-keep 0 times the
+    # shipped thresholds instead; that figure is also reported as config.nms_collapsed_leg.
+    shipped = (model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh)
+    crowded = args.crowd_keep > 0 and args.mode == "dense"
+    if crowded:
+        model.box_nms_thresh = model.crop_nms_thresh = 1.0
+        model.generate(frames[0])
+        sc = np.sort(model._store["score"][:model.last_candidates].float().cpu().numpy())[::-1]
+        model.pred_iou_thresh = float(sc[min(args.crowd_keep, len(sc) - 1)]) if len(sc) else shipped[2]
+
+    def timed_leg(collect_rows):
+        kept = pre = 0
+        rws = [np.zeros((0, 6), np.float32)]
+        for i in range(args.warmup):
+            model.generate(frames[i])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            out = model.generate(frames[i])
+            kept += len(out["boxes"])
+            pre += model.last_candidates
+            if collect_rows:
+                rws.append(detections_to_rows(rank * args.steps + i - args.warmup, out["boxes"], out["scores"]))
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        barrier()
+        return time.perf_counter() - t0, mine, kept, pre, rws
+
+    elapsed, my_elapsed, n_kept, n_pre_nms, rows = timed_leg(True)
     rank_rates = [args.steps / my_elapsed]
     if world > 1:
         # the one collective of the design: the variable-length detection gather over RCCL, after
@@ -296,17 +315,12 @@ def main():
         assert len(allrows) == int(sum(c[0].item() for c in cnts)), "detection gather lost rows"
         assert bool(np.all(np.diff(allrows[:, 0]) >= 0)), "gathered rows are not in rank (== image) order"
         rank_rates = [float(c[1].item()) for c in cnts]
-    # second measured leg: the tail of the path under load.  With random weights the candidate masks are near-identical
-    # blobs and box NMS keeps ~1 per image, so connected components + RLE run on one mask in the headline number; here
-    # box NMS is off and a score cut calibrated on a warm-up frame lets ~crowd_keep candidates through, so
-    # csam_small_regions / csam_rle_* / the COCO string packer are timed on a crowded-frame-sized survivor set.
-    crowd = None
-    if args.crowd_keep > 0 and args.mode == "dense" and rank == 0:
-        saved = (model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh)
-        model.box_nms_thresh = model.crop_nms_thresh = 1.0
-        model.generate(frames[0])
-        sc = np.sort(model._store["score"][:model.last_candidates].float().cpu().numpy())[::-1]
-        model.pred_iou_thresh = float(sc[min(args.crowd_keep, len(sc) - 1)]) if len(sc) else saved[2]
+    # second leg (rank 0): the SHIPPED thresholds on the same frames -- box NMS 0.65 collapses the random-weight blobs to
+    # ~1 mask per image, so the tail is almost free: the number rounds 1-2 reported as the headline
+    collapsed = None
+    if crowded and rank == 0:
+        keep_crowd = (model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh)
+        model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = shipped
         model.generate(frames[0])
         torch.cuda.synchronize()
         tc = time.perf_counter()
@@ -315,12 +329,12 @@ def main():
             kept_c += len(model.generate(frames[i])["boxes"])
         torch.cuda.synchronize()
         tc = time.perf_counter() - tc
-        crowd = {"what": "same frames, box NMS off, predicted-IoU cut %.4f (keeps ~%d candidates): every survivor goes "
-                         "through small-region clean-up (device connected components), RLE and COCO string packing"
-                         % (model.pred_iou_thresh, args.crowd_keep),
-                 "ms_per_step": 1e3 * tc / args.steps, "images_per_sec": args.steps / tc,
-                 "kept_masks_per_image": kept_c / args.steps}
-        model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = saved
+        collapsed = {"what": "same frames with the shipped box_nms_thresh %.2f / pred_iou_thresh %.2f: the near-identical "
+                             "random-weight masks collapse in NMS, connected components + RLE + string packing run on ~1 mask"
+                             % (shipped[0], shipped[2]),
+                     "ms_per_step": 1e3 * tc / args.steps, "images_per_sec": args.steps / tc,
+                     "kept_masks_per_image": kept_c / args.steps}
+        model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = keep_crowd
     # roofline leg: the same K steps once more with HIP events around every launch of the dominant kernel
     # (the timed region above replays hipGraphs, inside which per-launch events cannot be recorded).
     timer = None
@@ -360,7 +374,8 @@ def main():
                                     "prompt grid (%d prompts, %d per decoder batch) + PWD-Net selection + fused mask "
                                     "post + NMS + small-region clean-up + RLE; synthetic %dx%d crowd frames, "
                                     "seeded random weights; stability_score_thresh %.2f (calibrated so ~half of the "
-                                    "prompts survive to NMS with random weights), other thresholds as shipped"
+                                    "prompts pass the stability filter with random weights); CROWDED-FRAME survivor count, see "
+                                    "config.crowded_frame"
                                     % (args.arch, args.mode, args.grid, args.grid, n_prompts, args.points_per_batch,
                                        args.frame, args.frame, args.stability_thresh)),
                        "masks_per_sec": value * n_prompts if args.mode == "dense" else None,
@@ -368,8 +383,13 @@ def main():
                        "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}",
                        "per_rank_images_per_sec": rank_rates},
         }
-        if crowd is not None:
-            res["config"]["crowd_leg"] = crowd
+        if crowded:
+            res["config"]["crowded_frame"] = ("box NMS off, predicted-IoU cut %.4f calibrated on a warm-up frame (keeps ~%d of the "
+                                              "4096 candidates): %.0f masks per image survive the small-region NMS and run through "
+                                              "connected components, RLE and COCO string packing"
+                                              % (model.pred_iou_thresh, args.crowd_keep, n_kept / args.steps))
+        if collapsed is not None:
+            res["config"]["nms_collapsed_leg"] = collapsed
         if timer is not None:
             full = timer.summary()
             summ = {k: v for k, v in full.items() if k in GEMM_NAMES}
