@@ -378,8 +378,12 @@ __device__ __forceinline__ half4_t i2s_load8(const char* sbase, unsigned voff) {
   asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
   return r;
 }
+// gfx940+ data hazard: a VMEM store of more than 64 bits followed by a VALU write of its data VGPRs needs 2 wait states
+// (LLVM's hazard recognizer pads compiler-emitted stores; it does not look inside inline asm).  Without the s_nop the
+// next instruction -- e.g. the address computation of the next ds_read into the same quad -- can replace the first dword
+// of the stored 16 bytes (seen in csam_i2t_t2i: LDS addresses in every fourth column of the key rows).
 __device__ __forceinline__ void i2s_store16(char* sbase, unsigned voff, half8_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
 #define I2S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -1604,7 +1608,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         char* dst = (char*)(p.masks + (((long)b * 4 * 256) + 4 * i0) * 256 + half * 128);     // uniform base
         const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
 #ifndef CSAM_UP_NOSTORE
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(dst) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");   // see i2s_store16
 #else
         asm volatile("" ::"v"(voff), "s"(dst));
 #endif
@@ -2468,6 +2472,459 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
   const int per = csam_cdiv(B, T2R_OCC * n_cu);     // whole prompts per workgroup, T2R_OCC workgroups per CU
   hipLaunchKernelGGL(t2i_rank_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
   CSAM_LAUNCH_CHECK("csam_t2i_rank");
+  return CSAM_OK;
+}
+
+// =====================================================================================================
+// csam_i2t_t2i (round 3): the image->token half-block of layer L AND the token->image attention of the NEXT block (layer
+// L+1, or the final attention) in one pass over the key state.  csam_i2t_rank[_proj] writes the new keys (8.6 GB per 4096
+// prompts) and csam_t2i_rank reads them straight back; the reader's queries depend on the token side only (the self-
+// attention + norm1 of the next layer run BEFORE this kernel), so the read is folded into the write:
+//   * one 8-wave workgroup per CU walks whole prompts; waves 0-3 are PRODUCERS (the csam_i2t_rank tile body: 16 tokens per
+//     wave -> scores over 7 keys, P . M_b, residual, LayerNorm -> a swizzled [16][512 B] LDS slice -> coalesced stores),
+//     waves 4-7 are READERS (the csam_t2i_rank tile body: wave w owns heads 2w, 2w+1 -> S^T = X Qp^T + kpe q^T, online
+//     softmax, Y^T += X^T P^T through transposed LDS reads);
+//   * the four producer slices of one step ARE a 64-key reader tile (same row pitch, same chunk ^ (row & 15) swizzle):
+//     the readers consume step g - 1 from one half of a 2 x 32 KB buffer while the producers fill the other half with
+//     step g; ONE workgroup barrier per 64 tokens;
+//   * producer wave w and reader wave w share a SIMD: LayerNorm VALU of one runs under the MFMAs of the other
+//     (tools/probe/valu_mfma_overlap.hip: a VALU wave and an MFMA wave on one SIMD overlap).
+// The reader performs the arithmetic of csam_t2i_rank on bit-identical key rows in the same order, so Y is bit-identical
+// to csam_i2t_rank[_proj] followed by csam_t2i_rank (tests/test_decoder_gpu.py).  The key_pe operand and Qp come from the
+// same prep kernels.  HBM: the 2 (layer 0) / 2 (layer 1) MB per prompt the separate reader pulled back are gone.
+// =====================================================================================================
+namespace {
+
+#ifndef FUSE_ABL
+#define FUSE_ABL 0        // developer ablation: 1 = readers idle, 2 = producers do not store
+#endif
+#ifdef FUSE_TS            // developer timing: s_memtime stamps of one producer tile and one reader step (workgroup 0)
+__device__ long long* g_fuse_ts = nullptr;
+#define FTS(role, k) do { if (g_fuse_ts && blockIdx.x == 0 && g == 40 && lane == 0 && (wave & 3) == 1) \
+    g_fuse_ts[(role) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FTS(role, k) do {} while (0)
+#endif
+template <bool PROJ>
+struct IF {
+  static constexpr int KP = IR_M_BYTES;
+  static constexpr int TILES = IR_M_BYTES + (PROJ ? IR_KP_BYTES : 0);     // 2 x (4 producer slices = 64 keys x 512 B)
+  static constexpr int STEP = 4 * IR_SLICE;                               // 32 KB
+  static constexpr int PAR = TILES + 2 * STEP;
+  static constexpr int SMEM = PAR + 3 * 256 * 4;
+};
+
+template <bool PROJ>
+__global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, int prompts_per_wg) {
+  typedef IF<PROJ> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  float* par = (float*)(smem + G::PAR);
+  for (int i = tid; i < 256; i += 512) {
+    par[i] = p.bo[i];
+    par[256 + i] = p.gamma[i];
+    par[512 + i] = p.beta[i];
+  }
+  const int spp = p.T / 64;                          // steps (64 tokens) per prompt
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, p.B);
+  I2S_BARRIER();                                     // (0) par visible
+
+  if (wave < 4) {
+    // =============================== producers: csam_i2t_rank tile body, tile = 4 * step + wave ===============================
+    const int ptid = tid;                            // 0 .. 255
+    half8_t eye_lo, eye_hi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      eye_lo[e] = (half_t)((fg < 2 && fg * 8 + e == fr) ? 1.f : 0.f);
+      eye_hi[e] = (half_t)((fg >= 2 && (fg - 2) * 8 + e == fr) ? 1.f : 0.f);
+    }
+    const bool key7 = (fg & 1) == 1;
+    floatx4 qraw[4];
+    floatx4 xres[8];
+    int g = 0;                                       // step counter of this workgroup (buffer parity)
+    for (int b = b_first; b < b_last; ++b) {
+      // every producer finished the previous prompt's last tile before the barrier that ended that step
+      {
+        const char* src = (const char*)(p.M + (long)b * 256 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = ptid + i * 256, row = c >> 3, sl = c & 7;
+          i2s_glds16(src, (unsigned)(row * 128 + ((sl ^ (row & 7)) << 4)), lds0 + (unsigned)(wave * 1024 + i * 4096));
+        }
+        if constexpr (PROJ) {
+          const char* ksrc = (const char*)(p.Kp + (long)b * 64 * 256);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int c = ptid + i * 256, row = c >> 5, sl = c & 31;
+            i2s_glds16(ksrc, (unsigned)(row * 512 + ((sl ^ (row & 15)) << 4)),
+                       lds0 + (unsigned)(G::KP + wave * 1024 + i * 4096));
+          }
+        }
+      }
+      half8_t kfr[4];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        half8_t kv = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int j = fr & 7, hsel = fr >> 3;
+        if (j < 7 && (fg >> 1) == hsel)
+          kv = *(const half8_t*)(p.ks + ((long)b * 7 + j) * 128 + (2 * pr + hsel) * 16 + (fg & 1) * 8);
+        kfr[pr] = kv;
+        asm volatile("" : "+v"(kfr[pr]));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      I2S_BARRIER();                                 // (P) M_b / Kp_b of every producer wave have landed
+
+      auto prefetch = [&](int tile) {
+        const int t0 = tile * 16;
+        const char* qb = (const char*)(p.Q + (long)b * p.q_bstride + (long)t0 * 128);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) qraw[pr] = i2s_load16(qb + pr * 64, (unsigned)(fr * 256 + fg * 16));
+        const char* xb = (const char*)(p.X + (long)b * p.x_bstride + (long)t0 * 256);
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) xres[nj] = i2s_load16(xb + nj * 64, (unsigned)(fr * 512 + fg * 16));
+      };
+      prefetch(wave);
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(xres[0]), "+v"(xres[1]), "+v"(xres[2]),
+                     "+v"(xres[3]), "+v"(xres[4]), "+v"(xres[5]), "+v"(xres[6]), "+v"(xres[7])
+                   :: "memory");
+
+      for (int st = 0; st < spp; ++st, ++g) {
+        const int tile = st * 4 + wave;
+        const int t0 = tile * 16;
+        char* slice = smem + G::TILES + (g & 1) * G::STEP + wave * IR_SLICE;
+        FTS(0, 0);
+        floatx4 sc[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          half8_t qf;
+          __builtin_memcpy(&qf, &qraw[pr], 16);
+          sc[pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[pr], qf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        if constexpr (PROJ) {
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj) {
+            half8_t xf;
+            __builtin_memcpy(&xf, &xres[nj], 16);
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+              const int row = pr * 16 + fr;
+              const half8_t kp = *(const half8_t*)(smem + G::KP + row * 512 + (((nj * 4 + fg) ^ fr) << 4));
+              sc[pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kp, xf, sc[pr], 0, 0, 0);
+            }
+          }
+        }
+        FTS(0, 1);
+        half8_t pf[2];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const floatx4 s4 = sc[pr];
+          const float s3 = key7 ? -INFINITY : s4[3];
+          float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          const float p0 = csam_exp2(s4[0] - mx), p1 = csam_exp2(s4[1] - mx);
+          const float p2 = csam_exp2(s4[2] - mx), p3 = csam_exp2(s3 - mx);
+          float sum = (p0 + p1) + (p2 + p3);
+          sum += __shfl_xor(sum, 16, 64);
+          const float inv = __builtin_amdgcn_rcpf(sum);
+          const int o = (pr & 1) * 4;
+          pf[pr >> 1][o] = (half_t)(p0 * inv);
+          pf[pr >> 1][o + 1] = (half_t)(p1 * inv);
+          pf[pr >> 1][o + 2] = (half_t)(p2 * inv);
+          pf[pr >> 1][o + 3] = (half_t)(p3 * inv);
+        }
+        FTS(0, 2);
+        floatx4 acc[16];
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) {
+          half8_t xf;
+          __builtin_memcpy(&xf, &xres[nj], 16);
+          const floatx4 b0 = *(const floatx4*)(par + nj * 32 + fg * 4);
+          const floatx4 b1 = *(const floatx4*)(par + nj * 32 + 16 + fg * 4);
+          acc[2 * nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_lo, xf, b0, 0, 0, 0);
+          acc[2 * nj + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_hi, xf, b1, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+        FTS(0, 3);
+        if (st + 1 < spp) prefetch(tile + 4);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int ni = 0; ni < 16; ++ni) {
+            if ((ni & 3) == 0) asm volatile("" ::: "memory");
+            const int row = ni * 16 + fr;
+            const half8_t mf = *(const half8_t*)(smem + row * 128 + (((ks * 4 + fg) ^ (row & 7)) << 4));
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf, pf[ks], acc[ni], 0, 0, 0);
+          }
+        }
+        FTS(0, 4);
+        float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) {
+          const float2_t a = {acc[ni][0], acc[ni][1]}, c2 = {acc[ni][2], acc[ni][3]};
+          s2 += a;
+          q2 = __builtin_elementwise_fma(a, a, q2);
+          s2 += c2;
+          q2 = __builtin_elementwise_fma(c2, c2, q2);
+        }
+        const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float mean = ssum[0] * (1.f / 256.f);
+        const float var = fmaxf(qsum[0] * (1.f / 256.f) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float2_t rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
+        FTS(0, 5);
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) {
+          if ((ni & 3) == 0) asm volatile("" ::: "memory");
+          const floatx4 gm = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
+          const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
+          const float2_t g0 = {gm[0], gm[1]}, g1 = {gm[2], gm[3]}, b0 = {be[0], be[1]}, b1 = {be[2], be[3]};
+          const float2_t v0 = {acc[ni][0], acc[ni][1]}, v1 = {acc[ni][2], acc[ni][3]};
+          const float2_t y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(v0, rs2, nm2), g0, b0);
+          const float2_t y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(v1, rs2, nm2), g1, b1);
+          const int chunk = ni * 2 + (fg >> 1);
+          *(half4_t*)(slice + fr * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
+              half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
+        }
+        FTS(0, 6);
+        // next tile's operands land here; the asm RE-DEFINES them, so whatever copies the register allocator places on
+        // the loop edge move landed data (an in-flight asm load result must never reach a compiler-made copy)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(xres[0]), "+v"(xres[1]), "+v"(xres[2]),
+                       "+v"(xres[3]), "+v"(xres[4]), "+v"(xres[5]), "+v"(xres[6]), "+v"(xres[7])
+                     :: "memory");
+        FTS(0, 7);
+        char* obase = (char*)(p.out + ((long)b * p.T + t0) * 256);
+#if !(FUSE_ABL & 2)
+        {
+          half8_t rb[8];                               // all eight read-backs in flight (the accumulators are dead), then the stores
+#pragma unroll
+          for (int i = 0; i < 8; ++i) rb[i] = *(const half8_t*)(slice + (lane + i * 64) * 16);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int idx = lane + i * 64, row = idx >> 5, sl = idx & 31;
+            i2s_store16(obase, (unsigned)(row * 512 + ((sl ^ (row & 15)) << 4)), rb[i]);
+          }
+        }
+#endif
+        FTS(0, 8);
+        I2S_BARRIER();                               // (T) step g is in LDS; the readers are done with step g - 1
+        FTS(0, 9);
+      }
+    }
+    I2S_BARRIER();                                   // (E) pairs with the readers' drain step
+  } else {
+    // =============================== readers: csam_t2i_rank tile body over the producers' slices ===============================
+    constexpr int MI = T2S_MI;
+    const int rw = wave - 4;                         // owns heads 2 rw, 2 rw + 1
+    const int pl = lane & 15;
+    unsigned troff[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int row = kh * 16 + fg * 4 + (pl >> 2);
+      troff[kh] = row * 512 + (pl & 1) * 8;
+    }
+    const int trow[2] = {(fg * 4 + (pl >> 2)) & 15, (16 + fg * 4 + (pl >> 2)) & 15};
+    const int tsub = (pl & 3) >> 1;
+    floatx4 kpf[2][MI];                              // key_pe fragments of the NEXT step, both 32-key halves
+    // the asm RE-DEFINES the fragments after the wait: copies the register allocator makes on loop edges move landed data
+    auto land_kpe = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kpf[0][0]), "+v"(kpf[0][1]), "+v"(kpf[1][0]), "+v"(kpf[1][1])::"memory");
+    };
+    auto fetch_kpe = [&](int st) {
+      const char* base = (const char*)(r.kpe + (long)st * 64 * 128);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          kpf[h][mi] = i2s_load16(base + (h * 32 + mi * 16) * 128 * 2, (fr * 128 + rw * 32 + fg * 8) * 2);
+    };
+    half8_t qp[8];
+    half8_t qblk;
+    floatx4 y[16];
+    float m, l;
+    auto new_prompt = [&](int b) {
+      const half_t* src = r.Qp + ((long)b * 64 + rw * 16 + fr) * 256 + fg * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qp[ks] = *(const half8_t*)(src + ks * 32);
+      qblk = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const int hh = fr >> 3, j = fr & 7;
+      if (j < 7 && (fg >> 1) == hh)
+        qblk = *(const half8_t*)(r.qs + ((long)b * 7 + j) * 128 + (rw * 2 + hh) * 16 + (fg & 1) * 8);
+      asm volatile("" : "+v"(qblk), "+v"(qp[0]), "+v"(qp[7]));
+#pragma unroll
+      for (int n = 0; n < 16; ++n) y[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+      m = -INFINITY;
+      l = 0.f;
+    };
+    // step k of this workgroup: prompt b_first + k / spp, step k % spp.  `more` = another step follows: its key_pe
+    // fragments are requested now (never request registers nobody waits for: the compiler would recycle them in flight)
+    auto consume = [&](int k, bool more) {
+      const int st = k % spp, b = b_first + k / spp;
+      const int g = k;                               // (FTS)
+      (void)g;
+      FTS(1, 0);
+      if (st == 0) new_prompt(b);
+      floatx4 kcur[2][MI];                           // this step's key_pe fragments (landed: see land_kpe)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) kcur[h][mi] = kpf[h][mi];
+      asm volatile("" ::: "memory");
+      if (more) fetch_kpe(st + 1 < spp ? st + 1 : 0);   // the next prompt starts at step 0 again
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const char* xb = smem + G::TILES + (k & 1) * G::STEP + h * T2S_BUF;
+        floatx4 sa[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          half8_t kp8;
+          __builtin_memcpy(&kp8, &kcur[h][mi], 16);
+          sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kp8, qblk, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        {
+          // the reader has ~80 spare registers: all 16 key fragments of the half-step in flight at once (the stand-alone
+          // kernel keeps one step of read-ahead and waits an LDS round trip per MFMA pair)
+          half8_t xf[8][MI];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              xf[ks][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks][mi], qp[ks], sa[mi], 0, 0, 0);
+        }
+        FTS(1, 1 + 3 * h);
+        float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
+                         fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = csam_exp2(m - mnew);
+        m = mnew;
+        float ps = 0.f;
+        half8_t pb;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pe = csam_exp2(sa[mi][e] - mnew);
+            ps += pe;
+            pb[mi * 4 + e] = (half_t)pe;
+          }
+        l = l * alpha + ps;
+        if (__ballot(alpha != 1.f) != 0ull) {
+#pragma unroll
+          for (int n = 0; n < 16; ++n) y[n] *= alpha;
+        }
+        FTS(1, 2 + 3 * h);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          const half4_t a0 = ds_tr_b64(xb + troff[0] + (((2 * n + tsub) ^ trow[0]) << 4));
+          const half4_t a1 = ds_tr_b64(xb + troff[1] + (((2 * n + tsub) ^ trow[1]) << 4));
+          const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
+        }
+        FTS(1, 3 + 3 * h);
+      }
+      if (more) land_kpe();                          // requested a whole step ago: no exposed latency
+      if (st == spp - 1) {
+        float ls = l;
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        const float inv = 1.f / ls;
+        const int hh = fr >> 3, j = fr & 7;
+        if (j < 7) {
+          half_t* dst = r.Y + (((long)b * 7 + j) * 8 + rw * 2 + hh) * 256 + fg * 4;
+#pragma unroll
+          for (int n = 0; n < 16; ++n) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(y[n][e] * inv);
+            *(half4_t*)(dst + n * 16) = o;
+          }
+        }
+      }
+    };
+    fetch_kpe(0);
+    land_kpe();
+    int g = 0;
+    for (int b = b_first; b < b_last; ++b) {
+      I2S_BARRIER();                                 // (P)
+      for (int st = 0; st < spp; ++st, ++g) {
+#if !(FUSE_ABL & 1)
+        if (g > 0) consume(g - 1, true);
+#endif
+        I2S_BARRIER();                               // (T)
+      }
+    }
+    if (g > 0) consume(g - 1, false);                // drain: the last step of the last prompt
+    I2S_BARRIER();                                   // (E)
+  }
+}
+
+}  // namespace
+
+// image->token half-block + the next block's token->image attention.  Wq_f16 == null: the hoisted-Q layer-0 form
+// (csam_i2t_rank's operands, Q_f16 = the shared image-side queries); else the projected form (csam_i2t_rank_proj's, Q_f16 =
+// qpe16).  The reader operands are csam_t2i_rank's.  workspace: csam_i2t_t2i_workspace_bytes(B) = M_b | Kp_b | Qp_b.
+#ifdef FUSE_TS
+extern "C" int csam_dbg_set_fuse_ts(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_ts), &p, sizeof(p)); }
+#endif
+extern "C" long csam_i2t_t2i_workspace_bytes(int B) { return (long)B * (IR_M_BYTES + IR_KP_BYTES + 64 * 256 * 2); }
+
+extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                            const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
+                            const float* bo, const float* gamma, const float* beta, float eps, void* out_f16,
+                            const void* t2i_Wk_f16, const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T,
+                            void* workspace, long workspace_bytes) {
+  CSAM_REQUIRE(X_f16 && Q_f16 && k_scaled_f16 && v_f16 && Wo_f16 && bo && gamma && beta && out_f16 && t2i_Wk_f16 &&
+                   t2i_kpe_f16 && t2i_qs_f16 && Y_f16 && workspace,
+               "csam_i2t_t2i: null pointer");
+  CSAM_REQUIRE(B > 0 && T > 0 && T % 64 == 0, "csam_i2t_t2i: T must be a multiple of 64");
+  if (workspace_bytes < csam_i2t_t2i_workspace_bytes(B)) {
+    csam_set_error("csam_i2t_t2i: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<false>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  half_t* Mws = (half_t*)workspace;
+  half_t* Kpws = Mws + (long)B * 256 * 64;
+  half_t* Qpws = Kpws + (long)B * 64 * 256;
+  const dim3 pgrid(B < 2 * n_cu ? B : 2 * n_cu);
+  hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, s, (const half_t*)v_f16, (const half_t*)Wo_f16, Mws);
+  if (Wq_f16)
+    hipLaunchKernelGGL(i2t_rank_kp_kernel, pgrid, dim3(256), 0, s, (const half_t*)k_scaled_f16, (const half_t*)Wq_f16, Kpws, B);
+  hipLaunchKernelGGL(t2i_rank_prep_kernel, pgrid, dim3(256), 0, s, (const half_t*)t2i_qs_f16, (const half_t*)t2i_Wk_f16, Qpws, B);
+  IrArgs a;
+  a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
+  a.ks = (const half_t*)k_scaled_f16; a.M = Mws; a.Kp = Wq_f16 ? Kpws : nullptr; a.bo = bo; a.gamma = gamma; a.beta = beta;
+  a.eps = eps; a.out = (half_t*)out_f16; a.B = B; a.T = T;
+  T2rArgs t;
+  t.X = nullptr; t.Qp = Qpws; t.qs = (const half_t*)t2i_qs_f16; t.kpe = (const half_t*)t2i_kpe_f16; t.Y = (half_t*)Y_f16;
+  t.B = B; t.T = T;
+  const int per = csam_cdiv(B, n_cu);               // whole prompts per workgroup, one 8-wave workgroup per CU
+  if (Wq_f16)
+    hipLaunchKernelGGL((i2t_t2i_kernel<true>), dim3(csam_cdiv(B, per)), dim3(512), IF<true>::SMEM, s, a, t, per);
+  else
+    hipLaunchKernelGGL((i2t_t2i_kernel<false>), dim3(csam_cdiv(B, per)), dim3(512), IF<false>::SMEM, s, a, t, per);
+  CSAM_LAUNCH_CHECK("csam_i2t_t2i");
   return CSAM_OK;
 }
 

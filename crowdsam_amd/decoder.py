@@ -116,6 +116,8 @@ class DecoderPlan:
         self.i2t_rank = os.environ.get("CSAM_I2T_RANK", "1") != "0"       # rank-56 layer-0 image->token (B >= 256)
         self.i2t_rank_l1 = os.environ.get("CSAM_I2T_RANK_L1", "1") != "0"  # ... and layer 1 (csam_i2t_rank_proj)
         self.t2i_rank = os.environ.get("CSAM_T2I_RANK", "1") != "0"       # rank-56 token->image, layers 1 / final (B >= 256)
+        # image->token of layer L + token->image of the next block in one pass over the key state (csam_i2t_t2i, B >= 256)
+        self.i2t_t2i = os.environ.get("CSAM_I2T_T2I", "1") != "0"
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -259,7 +261,8 @@ class DecoderPlan:
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
             t2i_ws=torch.empty(hip.attn_t2i_workspace_bytes(B, 8) // 4, dtype=f, device=dev),
             # per-prompt M_b^T of the rank-56 layer-0 image->token kernel (32 KB / prompt; only used from 256 prompts)
-            i2t_rank_ws=e(hip.i2t_rank_proj_workspace_bytes(B if B >= 256 else 1) // 2))
+            i2t_rank_ws=e(hip.i2t_rank_proj_workspace_bytes(B if B >= 256 else 1) // 2),
+            i2t_t2i_ws=e(hip.i2t_t2i_workspace_bytes(B if B >= 256 else 1) // 2))
         self.allocB = B
         self.batch_graphs.clear()
 
@@ -352,8 +355,9 @@ class DecoderPlan:
             if fused_args is not None and "rank" in fused_args and self.t2i_rank and self.t2i_stream and B >= 256:
                 # rank-56 form (csam_t2i_rank): no per-key K / V projections; Wv and the out-projection in one GEMM
                 R = fused_args["rank"]
-                hip.gemm_f16(qpe16, R["q_w_s"], out=ws["t2i_q"][:M7], bias=R["q_b_s"])
-                hip.t2i_rank(fused_args["X"], R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_qp"], ws["t2i_y"], B, T_IMG)
+                if not fused_args.get("y_ready"):        # else: csam_i2t_t2i produced Y together with these keys
+                    hip.gemm_f16(qpe16, R["q_w_s"], out=ws["t2i_q"][:M7], bias=R["q_b_s"])
+                    hip.t2i_rank(fused_args["X"], R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_qp"], ws["t2i_y"], B, T_IMG)
                 hip.gemm_f16(ws["t2i_y"][:M7], R["wc"], out=ws["tmp32"][:M7], bias=R["bc"], residual=queries)
                 hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
                 return
@@ -365,14 +369,14 @@ class DecoderPlan:
                 hip.t2i_stream(ws["t2i_q"], ws["t2i_o"], B, fused_args["X"], fused_args["Wkv"], fused_args["kpe"],
                                fused_args["bv"], T_IMG)
             elif fused_args is not None:
-                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **{k: v for k, v in fused_args.items() if k != "rank"})
+                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **{k: v for k, v in fused_args.items() if k not in ("rank", "y_ready")})
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
             hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
             hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
 
-        for li, L in enumerate(self.layers):
-            # ---- token self-attention (transformer.py:164-170)
+        def self_attn(li, L):
+            """token self-attention + norm1 (transformer.py:164-170)"""
             if li == 0:
                 hip.add_cast(tokens0, out16=q16)
                 hip.gemm_f16(q16, L["sa_qk_w"], out=ws["sa_qk"][:M7], bias=L["sa_qk_b"])
@@ -383,15 +387,28 @@ class DecoderPlan:
             hip.gemm_f16(ws["sa_o"][:M7], L["sa_o_w"], out=ws["tmp32"][:M7], bias=L["sa_o_b"],
                          residual=None if li == 0 else queries)
             ln_queries(L["norm1_g"], L["norm1_b"])
+
+        def rank_consts(blk, prefix):
+            return dict(q_w_s=blk[prefix + "q_w_s"], q_b_s=blk[prefix + "q_b_s"], k_w=blk[prefix + "k_w"],
+                        kpe16=blk[prefix + "kpe16"], wc=blk[prefix + "wc"], bc=blk[prefix + "bc"])
+
+        # csam_i2t_t2i: the image->token pass of layer li also runs the token->image attention of the NEXT block over the
+        # keys it is writing.  That block's queries depend on the token side only, so its self-attention + norm1 (and the
+        # q projection) are issued BEFORE the pass; y_ready tells the next block that Y is already in ws["t2i_y"].
+        fuse_next = (self.fused and self.i2t_stream and self.i2t_rank and self.i2t_rank_l1 and self.t2i_rank
+                     and self.t2i_stream and self.i2t_t2i and B >= 256)
+        y_ready = False
+        for li, L in enumerate(self.layers):
+            if not y_ready:
+                self_attn(li, L)
             # ---- token -> image cross attention (:173-177)
             if li == 0:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
                     dict(K0=st["k0"], V0T=st["v0t"]) if self.fused else None, cast16=q16)
             elif self.fused:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], None, 0, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
-                    dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"],
-                         rank=dict(q_w_s=L["t2i_q_w_s"], q_b_s=L["t2i_q_b_s"], k_w=L["t2i_k_w"], kpe16=L["t2i_kpe16"],
-                                   wc=L["t2i_wc"], bc=L["t2i_bc"])), cast16=q16)
+                    dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"], rank=rank_consts(L, "t2i_"),
+                         y_ready=y_ready), cast16=q16)
             else:
                 hip.gemm_f16_resmod(keys_in, L["t2i_kv_w"], ws["kv"][:BT], L["t2i_kv_b"], L["t2i_kv_pe"], T_IMG, M=BT)
                 t2i(L["t2i_q_w"], L["t2i_q_b"], ws["kv"], 256, T_IMG * 256, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
@@ -405,7 +422,22 @@ class DecoderPlan:
             kw, kb = (L["i2t_k_w_s"], L["i2t_k_b_s"]) if stream else (L["i2t_k_w"], L["i2t_k_b"])
             hip.gemm_f16(qpe16, kw, out=ws["i2t_k"][:M7], bias=kb)
             hip.gemm_f16(q16, L["i2t_v_w"], out=ws["i2t_v"][:M7], bias=L["i2t_v_b"])
-            if stream:
+            if fuse_next:
+                last = li + 1 == len(self.layers)
+                R = rank_consts(self.final, "") if last else rank_consts(self.layers[li + 1], "t2i_")
+                if not last:                        # the next layer's token-side prologue (i2t_k / i2t_v are already taken)
+                    self_attn(li + 1, self.layers[li + 1])
+                hip.gemm_f16(qpe16, R["q_w_s"], out=ws["t2i_q"][:M7], bias=R["q_b_s"])
+                if li == 0:
+                    hip.i2t_t2i(st["src16"], 0, st["qi0"], 0, None, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                L["norm4_g"], L["norm4_b"], 1e-5, keys_out, R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_y"],
+                                B, T_IMG, ws["i2t_t2i_ws"])
+                else:
+                    hip.i2t_t2i(keys_in, T_IMG * 256, L["i2t_q_peb16"], 0, L["i2t_q_w"], ws["i2t_k"], ws["i2t_v"],
+                                L["i2t_o_w"], L["i2t_o_b"], L["norm4_g"], L["norm4_b"], 1e-5, keys_out, R["k_w"], R["kpe16"],
+                                ws["t2i_q"], ws["t2i_y"], B, T_IMG, ws["i2t_t2i_ws"])
+                y_ready = True
+            elif stream:
                 if li == 0 and self.i2t_rank and B >= 256:
                     # hoisted-Q layer in its rank-56 form (whole prompts per workgroup: needs >= 256 prompts)
                     hip.i2t_rank(st["src16"], 0, st["qi0"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
@@ -445,8 +477,7 @@ class DecoderPlan:
         hs16 = ws["hs16"][:M7]
         if self.fused:
             t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
-                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"],
-                     rank=dict(q_w_s=F["q_w_s"], q_b_s=F["q_b_s"], k_w=F["k_w"], kpe16=F["kpe16"], wc=F["wc"], bc=F["bc"])),
+                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"], rank=rank_consts(F, ""), y_ready=y_ready),
                 cast16=hs16)
         else:
             hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)

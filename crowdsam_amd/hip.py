@@ -71,6 +71,7 @@ SIGNATURES = {
     "csam_i2t_rank_proj": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _L],
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_t2i_rank": [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I],
+    "csam_i2t_t2i": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _L],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
@@ -99,6 +100,7 @@ LONG_RETURNS = {
     "csam_flash_attn_workspace_bytes": [_I, _I],
     "csam_i2t_rank_workspace_bytes": [_I],
     "csam_i2t_rank_proj_workspace_bytes": [_I],
+    "csam_i2t_t2i_workspace_bytes": [_I],
 }
 
 _lib = None
@@ -781,6 +783,20 @@ def t2i_rank(X, Wk, kpe16, q_scaled, Qp_ws, Y, B, T=4096):
     (already x 0.25 log2 e); Qp_ws f16 >= [B*64,256] scratch; Y f16 [B*7, 8*256] <- softmax-weighted key sums per (query, head)."""
     call("csam_t2i_rank", _stream(), _ptr(X), _ptr(Wk), _ptr(kpe16), _ptr(q_scaled), _ptr(Qp_ws), Qp_ws.numel() * 2, _ptr(Y), B, T)
     return Y
+
+
+def i2t_t2i_workspace_bytes(B):
+    return lib().csam_i2t_t2i_workspace_bytes(B)
+
+
+def i2t_t2i(X, x_bstride, Q, q_bstride, Wq, k_scaled, v, Wo, bo, gamma, beta, eps, out, t2i_Wk, t2i_kpe16, t2i_q_scaled, Y,
+            B, T, workspace):
+    """``i2t_rank`` (Wq None: Q = hoisted image-side queries) / ``i2t_rank_proj`` (Q = qpe16) writing ``out``, with the NEXT
+    block's ``t2i_rank`` folded in: Y f16 [B*7, 8*256] comes from the new keys while they are still in LDS."""
+    call("csam_i2t_t2i", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq) if Wq is not None else None,
+         _ptr(k_scaled), _ptr(v), _ptr(Wo), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ptr(t2i_Wk),
+         _ptr(t2i_kpe16), _ptr(t2i_q_scaled), _ptr(Y), B, T, _ptr(workspace), workspace.numel() * workspace.element_size())
+    return out, Y
 
 
 def head_gather(qkv, qkv_bias, Qs, K, VT, D, nH, hd, Tp, T_valid, window, scale):

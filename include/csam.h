@@ -212,6 +212,18 @@ int csam_i2t_rank_proj(void* stream, const void* X_f16, long x_prompt_stride, co
                        const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
                        const float* gamma, const float* beta, float eps, void* out_f16, int B, int T, void* workspace,
                        long workspace_bytes);
+/* csam_i2t_rank / csam_i2t_rank_proj (Wq_f16 null: hoisted-Q form, Q_f16 = the shared image-side queries [T,128]; else
+ * the projected form, Q_f16 = qpe_f16) with the token->image attention of the NEXT block (transformer.py:173-177 of layer
+ * L+1, or :105-112) folded in: the reader half of each workgroup takes the new key rows from LDS instead of HBM.  The reader
+ * operands are csam_t2i_rank's (t2i_Wk_f16 [128,256], t2i_kpe_f16 [T,128], t2i_qs_f16 [B*7,128] scaled queries of the NEXT
+ * block -- they depend on the token side only); Y_f16 [B*7, 8*256] is bit-identical to csam_i2t_rank[_proj] followed by
+ * csam_t2i_rank.  workspace: csam_i2t_t2i_workspace_bytes(B). */
+long csam_i2t_t2i_workspace_bytes(int B);
+int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                 const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
+                 const float* gamma, const float* beta, float eps, void* out_f16, const void* t2i_Wk_f16,
+                 const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T, void* workspace,
+                 long workspace_bytes);
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,

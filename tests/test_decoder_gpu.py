@@ -147,6 +147,32 @@ def test_decoder_production_batch_vs_reference_golden(cuda):
     assert flips.sum() <= max(3, int(0.02 * 320))                   # and they are rare: <= 2 % of the prompts
 
 
+def test_decoder_i2t_t2i_fusion_is_bitwise_the_unfused_sweep(cuda):
+    """csam_i2t_t2i (image->token pass + the next block's token->image attention in one kernel; the next layer's token
+    self-attention is issued ahead of it) must not move a single bit of the decoder's outputs: same arithmetic on the
+    same fp16 key rows, only their route (LDS instead of HBM) and the launch order of independent token ops differ."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    sd = synth.make_sam_state_dict("vit_test128")
+    plan = DecoderPlan(sd, cuda, n_class=1, max_batch=320)
+    assert plan.i2t_t2i and plan.t2i_rank and plan.i2t_rank and plan.i2t_rank_l1
+    _set_image(plan, cuda)
+    pts = np.random.RandomState(5).randint(0, 1024, size=(320, 2)).astype(np.float32)
+    coords = torch.from_numpy(pts).to(cuda).contiguous()
+    outs = {}
+    for on in (True, False, True):
+        plan.i2t_t2i = on
+        plan.batch_graphs.clear()
+        m, iou, cls = plan.run_batch(coords)
+        torch.cuda.synchronize()
+        cur = (m.clone(), iou.clone(), cls.clone())
+        if on in outs:
+            assert all(torch.equal(a, b) for a, b in zip(outs[on], cur))       # repeatable
+        outs[on] = cur
+    for a, b, name in zip(outs[True], outs[False], ("masks", "iou", "cls")):
+        assert torch.equal(a, b), (name, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize("B", [3, 300])
 def test_upscale_stream_vs_oracle_fp32(cuda, B):
     """csam_upscale_stream -- the largest kernel of the benchmark -- directly against the oracle's fp32 restatement of

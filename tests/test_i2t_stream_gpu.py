@@ -136,3 +136,51 @@ def test_i2t_rank_projected(cuda, B):
     out3 = torch.zeros_like(out)
     hip.i2t_rank_proj(X, T * 256, qpe16, Wq, k_s, v, Wo, bo, g, be, 1e-5, out3, B, T, ws)
     assert torch.equal(out.view(torch.int16), out3.view(torch.int16))
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 530])
+@pytest.mark.parametrize("proj", [False, True])
+def test_i2t_t2i_is_bitwise_the_two_kernels(cuda, B, proj):
+    """csam_i2t_t2i (image->token producers + the next block's token->image readers in one pass) must write the keys of
+    csam_i2t_rank[_proj] and the Y of csam_t2i_rank over those keys BIT-EXACTLY: the reader half does the same arithmetic
+    on the same fp16 key rows in the same order, only from LDS instead of HBM.  Bitwise repeatable."""
+    from crowdsam_amd import hip
+    T = 4096
+    gen = torch.Generator().manual_seed(400 + B + int(proj))
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(cuda)
+    k, v = r(B * 7, 128, sc=0.8), r(B * 7, 128, sc=0.8).half()
+    Wo, bo = r(256, 128, sc=0.08).half(), r(256, sc=0.2)
+    g, be = (torch.rand(256, generator=gen) + 0.5).to(cuda), r(256, sc=0.2)
+    k_s = (k * SC).half()
+    # reader operands (csam_t2i_rank)
+    Wk = r(128, 256, sc=0.06).half()
+    kpe16 = r(T, 128, sc=0.5).half()
+    qs = (r(B * 7, 128, sc=1.2) * SC).half()
+    qp = torch.empty(B * 64, 256, dtype=torch.float16, device=cuda)
+    out = torch.zeros(B * T, 256, dtype=torch.float16, device=cuda)
+    ws = torch.empty(hip.i2t_rank_proj_workspace_bytes(B) // 2, dtype=torch.float16, device=cuda)
+    if proj:
+        nX = min(B, 5)
+        Xs = r(nX * T, 256, sc=0.7).half()
+        idx = torch.arange(B, device=cuda) % nX
+        X = Xs.view(nX, T * 256)[idx].contiguous().view(B * T, 256) if B > nX else Xs
+        Wq, Q = r(128, 256, sc=0.06).half(), r(T, 128, sc=0.5).half()
+        hip.i2t_rank_proj(X, T * 256, Q, Wq, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, ws)
+        xs = T * 256
+    else:
+        X, Q, Wq = r(T, 256, sc=0.7).half(), r(T, 128, sc=0.9).half(), None
+        hip.i2t_rank(X, 0, Q, 0, k_s, v, Wo, bo, g, be, 1e-5, out, B, T, ws)
+        xs = 0
+    Y = torch.zeros(B * 7, 2048, dtype=torch.float16, device=cuda)
+    hip.t2i_rank(out, Wk, kpe16, qs, qp, Y, B, T)
+    wsf = torch.empty(hip.i2t_t2i_workspace_bytes(B) // 2, dtype=torch.float16, device=cuda)
+    for _ in range(2):
+        out2 = torch.full_like(out, float("nan"))
+        Y2 = torch.full_like(Y, float("nan"))
+        hip.i2t_t2i(X, xs, Q, 0, Wq, k_s, v, Wo, bo, g, be, 1e-5, out2, Wk, kpe16, qs, Y2, B, T, wsf)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), \
+            (out.float() - out2.float()).abs().max().item()
+        bad = (Y.view(torch.int16) != Y2.view(torch.int16))
+        assert not bad.any(), (int(bad.sum()), (Y.float() - Y2.float()).abs().max().item(),
+                               bad.view(B, 7, 8, 256).any(-1).nonzero()[:8].tolist())

@@ -1,0 +1,41 @@
+"""The ISA lints of tools/ as a build gate (no GPU: hipcc cross-compiles to gfx950 assembly).
+
+tools/lint_asm_loads.py: no instruction may read, and the compiler may not recycle, a register an inline-asm global load
+is still filling (the bug class behind the intermittent Y differences of the first csam_i2t_t2i), and every inline-asm
+store wider than 64 bits is padded for the gfx940+ store-data hazard."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_inflight_asm_load_is_read_or_recycled():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_asm_loads.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "decoder_fused.hip" in r.stdout
+
+
+def test_lint_detects_the_hazards(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lint_asm_loads as L
+    isa = tmp_path / "k.s"
+    isa.write_text("""
+_Z1kv:                                  ; @k
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v1, s[2:3]
+	;;#ASMEND
+	v_mov_b64_e32 v[8:9], v[4:5]
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	v_mov_b64_e32 v[10:11], v[6:7]
+	;;#ASMSTART
+	global_store_dwordx4 v1, v[8:11], s[2:3]
+	;;#ASMEND
+	v_add_u32_e32 v8, s1, v2
+	s_endpgm
+""")
+    kinds = sorted(x[0] for x in L.scan(str(isa)))
+    assert kinds == ["inflight", "store"], kinds
