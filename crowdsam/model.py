@@ -293,7 +293,9 @@ class CrowdSAM:
                 n_batches += 1
                 self._tick("eps.batch", tb)
                 if prune and n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
-                    if int(counts[1].item()) == 0:        # nothing was left behind this round's selection
+                    # the alive flags AFTER this round's pruning (counts[1] is the selection's view, taken before it: a
+                    # prune that empties the list would cost up to four more full-width empty rounds)
+                    if int(alive_dev.count_nonzero().item()) == 0:
                         break
         else:
             all_pts_dev = None

@@ -156,12 +156,3 @@ __device__ __forceinline__ float csam_wave_max(float v) {
   return v;
 }
 
-// MFMA accumulators in AGPRs, always.  When a kernel's launch bounds leave <= 256 registers per lane hipcc (ROCm 7.2)
-// infers "amdgpu-agpr-alloc"="0" and selects the VGPR form of every MFMA; the register allocator then un-ties vDst from
-// SrcC where that saves a copy and recycles the SrcC quad -- e.g. as the destination of the next ds_read_b128, `s_nop 2`
-// behind the MFMA.  On gfx950 a 16x16x32 MFMA takes SrcC for lanes 48..63 in its last pass, and under matrix-pipe
-// contention the LDS return can land first (round 3: wrong rel-pos bias in ~1 % of the csam_flash_attn launches; analysis
-// in attn_flash.hip, build-time check tools/lint_mfma_srcc.py).  Naming an AGPR in an (empty) asm statement keeps the
-// function's AGPR budget open, which makes hipcc select the AGPR form: accumulators then live where no load can be
-// aimed at them.  First statement of every kernel that issues MFMAs through the builtins.
-#define CSAM_AGPR_ACCUMULATORS() asm volatile("" ::: "a0")

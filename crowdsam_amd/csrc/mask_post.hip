@@ -502,7 +502,8 @@ __global__ __launch_bounds__(1024) void post_finalize_compact_kernel(
         bool near = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = (float)bx[e] / edge.downscale + edge.crop[e & 1];
+          // tensor / Python-scalar on the reference's device path is a multiply by the fp32 reciprocal (ATen's div-by-scalar)
+          const float v = (float)bx[e] * (1.0f / edge.downscale) + edge.crop[e & 1];
           near = near || (fabsf(v - edge.crop[e]) <= edge.atol && !(fabsf(v - edge.orig[e]) <= edge.atol));
         }
         k = k && !near;

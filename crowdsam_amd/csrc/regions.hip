@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void cc_extent_kernel(const uint8_t* __restric
 // Masks are addressed through an index list (store slots), so the NMS survivors are cleaned up where they lie.
 // =====================================================================================================================
 constexpr int C2_INF = 0x7fffffff;
+constexpr unsigned short C2_TILE_EMPTY = 0xfffeu, C2_TILE_FULL = 0xfffdu;   // R16[tile][0] markers of trivial tiles
 constexpr int C2_LDS = 64 * 8 + 4096 * 4 + 3 * 256 * 4; // row bit masks | P (parents, then rep : count per root) | ring records
 
 __device__ __forceinline__ int c2_ring_slot(int r, int c) { return r == 0 ? c : r == 63 ? 64 + c : c == 0 ? 128 + r : 192 + r; }
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256, 8) void cc2_scan_kernel(const uint8_t* __restr
                                                        unsigned short* __restrict__ R16,
                                                        int* __restrict__ RP, int* __restrict__ RA, int* __restrict__ RF,
                                                        int* __restrict__ RT, int* __restrict__ RFT,
-                                                       RegionMeta* __restrict__ meta, int H, int W, int thresh) {
+                                                       RegionMeta* __restrict__ meta, int H, int W, int thresh, int no_trivial) {
   extern __shared__ __attribute__((aligned(16))) char c2smem[];
   unsigned long long* rowbits = (unsigned long long*)c2smem;
   int* P = (int*)(c2smem + 512);
@@ -619,6 +620,29 @@ __global__ __launch_bounds__(256, 8) void cc2_scan_kernel(const uint8_t* __restr
     P[r * 64 + lane] = wk ? r * 64 + c2_run_start(bits, lane) : -1;
   }
   __syncthreads();
+  {
+    // Trivial tiles -- no work pixel, or (tile inside the frame) nothing but work pixels -- are most of a real mask's 256
+    // tiles (a person covers a few percent of the frame: the islands pass sees empty tiles, the holes pass full ones).
+    // They skip the union-find, the area table and the 8 KB of root records: R16[tile][0] carries a marker the apply
+    // kernel checks first.  A full tile is ONE component rooted at its first pixel, represented by ring slot 0, with every
+    // ring slot a member; an empty tile has no ring members at all.
+    const unsigned long long rb = rowbits[lane];
+    const bool all0 = __ballot(rb != 0ull) == 0ull;
+    const bool all1 = __ballot(rb != ~0ull) == 0ull;   // 64 rows of 64 set bits: implies x0 + 63 < W and y0 + 63 < H
+    if ((all0 || all1) && !no_trivial) {
+      const int tile_id = mi * (int)gridDim.x + (int)blockIdx.x;
+      const int cb = tile_id * 256, t = threadIdx.x;
+      if (t == 0) R16[(long)tile_id * 4096] = all0 ? C2_TILE_EMPTY : C2_TILE_FULL;
+      int rr, cc;
+      const bool member = all1 && c2_slot_rc(t, rr, cc);
+      RP[cb + t] = member ? cb : -1;
+      RA[cb + t] = (all1 && t == 0) ? 4096 : 0;
+      RF[cb + t] = (all1 && t == 0) ? y0 * W + x0 : C2_INF;
+      RT[cb + t] = 0;
+      RFT[cb + t] = C2_INF;
+      return;                                           // no complete component here: nothing for the flags / best key
+    }
+  }
   for (int i = 0; i < 16; ++i) {                      // north links: cc_tile_kernel's decision tree
     const int r = wave * 16 + i;
     if (r == 0) continue;
@@ -865,6 +889,29 @@ __global__ __launch_bounds__(256) void cc2_apply_kernel(const uint8_t* in_base, 
     const unsigned short* r16 = R16 + (long)tile_id * 4096;
     const int cb = tile_id * 256;
     const unsigned best_first = 0xffffffffu - (unsigned)(mm.best & 0xffffffffull);
+    const unsigned short mark = r16[0];
+    if (mark == C2_TILE_EMPTY || mark == C2_TILE_FULL) {
+      // one decision for the whole tile; nothing is read back but the ring totals of slot 0 (full tiles)
+      bool v;                                            // value of every output pixel of the tile
+      if (mark == C2_TILE_EMPTY) {
+        v = HOLES;                                       // holes pass: all foreground, stays; islands pass: all background
+      } else {
+        const int g = uf_find(RP, cb);
+        const int area = RT[g];
+        const unsigned first = (unsigned)RFT[g];
+        v = HOLES ? (area < thresh) : (mm.any_big ? (area >= thresh) : (first == best_first));
+      }
+      const bool same = mark == C2_TILE_EMPTY ? true : (HOLES ? !v : v);   // output == input
+      if (o != m || !same) {
+        for (int i = 0; i < 16; ++i) {
+          const int y = y0 + wave * 16 + i;
+          if (y < H && x < W) o[(long)y * W + x] = v ? 1 : 0;
+        }
+      }
+      if (!HOLES && v) {                                 // (a full tile lies inside the frame)
+        ex0 = x; ex1 = x; ey0 = y0 + wave * 16; ey1 = y0 + wave * 16 + 15;
+      }
+    } else {
     unsigned short roots[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -894,6 +941,7 @@ __global__ __launch_bounds__(256) void cc2_apply_kernel(const uint8_t* in_base, 
       else v = rt != 0xffffu && dec[rt] != 0;
       o[(long)y * W + x] = v ? 1 : 0;
       if (!HOLES && v) { ex0 = min(ex0, x); ex1 = max(ex1, x); ey0 = min(ey0, y); ey1 = max(ey1, y); }
+    }
     }
   }
   if (!HOLES) {                                        // box extents of the final mask: <= 4 atomics per tile
@@ -1047,8 +1095,12 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
   const dim3 mgrid(std::min(16, std::max(1, tiles / 4)), n);
   hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);
   // pass 1: holes (components of the complement), masks -> out
+  static const int no_trivial = [] {                   // developer A/B: label trivial tiles like any other
+    const char* e = getenv("CSAM_CC_NO_TRIVIAL");
+    return e && e[0] == '1' ? 1 : 0;
+  }();
   hipLaunchKernelGGL(cc2_scan_kernel<1>, tgrid, block, C2_LDS, stream, masks_base, idx, R16, RP, RA, RF, RT, RFT, meta, H, W,
-                     min_area);
+                     min_area, no_trivial);
   hipLaunchKernelGGL(cc2_border_kernel<1>, bgrid, block, 0, stream, masks_base, idx, RP, H, W);
   hipLaunchKernelGGL(cc2_total_kernel, sgrid, block, 0, stream, RP, RA, RF, RT, RFT, slots);
   hipLaunchKernelGGL(cc2_ringmeta_kernel, mgrid, block, 0, stream, RP, RT, RFT, meta, tiles * 256, min_area);
@@ -1056,7 +1108,7 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
                      H, W, min_area);
   // pass 2: islands (components of the hole-filled mask), out -> out
   hipLaunchKernelGGL(cc2_scan_kernel<0>, tgrid, block, C2_LDS, stream, out_base, idx, R16, RP, RA, RF, RT, RFT, meta + n, H,
-                     W, min_area);
+                     W, min_area, no_trivial);
   hipLaunchKernelGGL(cc2_border_kernel<0>, bgrid, block, 0, stream, out_base, idx, RP, H, W);
   hipLaunchKernelGGL(cc2_total_kernel, sgrid, block, 0, stream, RP, RA, RF, RT, RFT, slots);
   hipLaunchKernelGGL(cc2_ringmeta_kernel, mgrid, block, 0, stream, RP, RT, RFT, meta + n, tiles * 256, min_area);

@@ -183,6 +183,7 @@ def mask_to_rle_arrays(tensor, idx=None):
         keep[so[1:] - 1] = False
         bounds[keep] = pos[: int(offs[-1])]
         runs = np.diff(bounds)                        # the difference across a mask boundary lands on a dropped slot
+        runs.setflags(write=False)                    # every mask's counts is a VIEW of this array (MaskData.cat copies shallowly)
         out = []
         for i in range(b):
             out.append({"size": [h, w], "counts": runs[so[i]: so[i + 1] - 1]})

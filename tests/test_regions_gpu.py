@@ -138,3 +138,47 @@ def test_tile_edges(cuda):
     big = np.stack([np.kron(rng.rand(16, 16) > 0.5, np.ones((64, 64), bool)),       # whole tiles on / off, 1024 x 1024
                     rng.rand(1024, 1024) > 0.5])
     _check(cuda, big, 100)
+
+
+def test_trivial_tiles(cuda):
+    """The fast paths of the compact form: tiles without a work pixel and tiles made of nothing else skip the labelling.
+    Person-like masks (most tiles empty in the islands pass, full in the holes pass), tile-aligned 64 x 64 islands and
+    holes whose area (4096) sits on either side of min_area, full tiles glued to ragged neighbours, frame sizes whose
+    last tile column / row is partial (such a tile is never 'full')."""
+    H, W = 512, 640
+    yy, xx = np.mgrid[:H, :W]
+    m = []
+    a = ((yy - 250) / 180.0) ** 2 + ((xx - 300) / 90.0) ** 2 < 1.0           # a person-sized ellipse ...
+    a[240:246, 290:300] = False                                               # ... with a small hole
+    a[10:14, 600:606] = True                                                  # ... and a far-away speck
+    m.append(a)
+    b = np.zeros((H, W), bool)                                                # aligned 64 x 64 island next to a bigger body
+    b[64:128, 128:192] = True
+    b[300:500, 100:400] = True
+    m.append(b)
+    c = np.ones((H, W), bool)                                                 # aligned 64 x 64 hole and a ragged one
+    c[128:192, 256:320] = False
+    c[320:390, 330:397] = False
+    m.append(c)
+    d = np.zeros((H, W), bool)                                                # only full tiles: the largest is kept by the fallback
+    d[0:64, 0:64] = True
+    d[192:256, 320:448] = True
+    m.append(d)
+    e = np.zeros((H, W), bool)                                                # full tiles with a one-pixel bridge through a corner
+    e[64:128, 64:128] = True
+    e[128:192, 128:192] = True
+    e[256:320, 576:640] = True                                                # last (full) column of tiles
+    e[448:512, 0:64] = True
+    m.append(e)
+    masks = np.stack(m)
+    for min_area in (100, 4096, 4097, 9000):
+        _check(cuda, masks, min_area)
+    Hp, Wp = 200, 330                                                          # partial last tiles
+    f = np.ones((2, Hp, Wp), bool)
+    f[1, 192:200, :] = False
+    f[0, 100:164, 300:330] = False
+    g = np.zeros((2, Hp, Wp), bool)
+    g[0, 128:200, 256:330] = True
+    g[1, 0:64, 320:330] = True
+    for min_area in (100, 3000):
+        _check(cuda, np.concatenate([f, g]), min_area)
