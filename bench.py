@@ -32,9 +32,9 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
     needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
         rows = [v for k, v in d["kernels"].items() if k.startswith(kernel_prefix)]

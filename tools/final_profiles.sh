@@ -29,5 +29,5 @@ python tests/dbg/fused_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_i2t
 for b in 530 700; do python tests/dbg/fused_diff.py $b proj 2>&1 | grep mismatch >> gpurun_out/${TAG}_i2t_t2i_vs_separate.txt; done
 ./tools/probe/valu_mfma_overlap > gpurun_out/${TAG}_valu_mfma_overlap_probe.txt 2>&1
 ./tools/probe/mfma_srcc_lds_war > gpurun_out/${TAG}_mfma_srcc_lds_war_probe.txt 2>&1
-python tests/dbg/flash_repeat.py q > gpurun_out/${TAG}_flash_repeat.txt 2>&1
+python tests/dbg/flash_repeat.py 11 1000 q > gpurun_out/${TAG}_flash_repeat.txt 2>&1
 python tests/dbg/tile_classes.py 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/${TAG}_crowd_tile_classes.txt
