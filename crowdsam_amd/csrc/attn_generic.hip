@@ -96,6 +96,68 @@ __global__ __launch_bounds__(256) void softmax_relpos_kernel(const float* __rest
   }
 }
 
+// The same softmax with a row held in registers (round 3: the three-pass form above spent 6 of ViT-H's 21 ms encoder on
+// integer divisions and re-reads).  NPL = Tp / 64 scores per lane; a key's (kh, kw) does not depend on the query, so the
+// two table offsets of a lane's keys are worked out once per wave -- or not at all on the 64 x 64 global grid, where key
+// k = lane + 64 j is simply (kh, kw) = (j, lane).  One wave walks ROWS query rows.  Same operations in the same order as
+// the three-pass kernel (per-lane partial sums over ascending k, then the wave reduction): results are bit-identical.
+template <int NPL, bool GRID64, int ROWS>
+__global__ __launch_bounds__(256) void softmax_relpos_reg_kernel(const float* __restrict__ S, const float* __restrict__ traw,
+                                                                 half_t* __restrict__ P, int Tp, int Tvalid, int side,
+                                                                 float inv_scale) {
+  const int g = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  int kh[GRID64 ? 1 : NPL], kw[GRID64 ? 1 : NPL];
+  if constexpr (!GRID64) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int k = lane + 64 * j;
+      kh[j] = k / side;
+      kw[j] = k - kh[j] * side;
+    }
+  }
+  for (int r = 0; r < ROWS; ++r) {
+    const int q = q0 + r;
+    if (q >= Tp) return;
+    half_t* prow = P + ((long)g * Tp + q) * Tp;
+    if (q >= Tvalid) {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) prow[lane + 64 * j] = (half_t)0.f;
+      continue;
+    }
+    const float* srow = S + ((long)g * Tp + q) * Tp;
+    const float* th = traw + ((long)g * Tp + q) * 256 + (q / side) + side - 1;
+    const float* tw = traw + ((long)g * Tp + q) * 256 + 128 + (q % side) + side - 1;
+    float v[NPL];
+    float mx = -INFINITY;
+    const float twl = GRID64 ? tw[-lane] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int k = lane + 64 * j;
+      if (k < Tvalid) {
+        const float b = GRID64 ? (th[-j] + twl) : (th[-kh[j]] + tw[-kw[j]]);
+        v[j] = srow[k] + b * inv_scale;
+        mx = fmaxf(mx, v[j]);
+      } else {
+        v[j] = -INFINITY;
+      }
+    }
+    mx = csam_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j)
+      if (lane + 64 * j < Tvalid) sum += __expf(v[j] - mx);
+    sum = csam_wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int k = lane + 64 * j;
+      prow[k] = (half_t)(k < Tvalid ? __expf(v[j] - mx) * inv : 0.f);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void head_scatter_kernel(const half_t* __restrict__ Op, half_t* __restrict__ out, int D,
                                                            int nH, int hd, int Tp, int Tvalid, int window) {
   const int g = blockIdx.y, h = g % nH, w = g / nH;
@@ -125,8 +187,19 @@ extern "C" int csam_softmax_relpos(void* stream, const float* S, const float* re
                                    int T_valid, int side, float inv_scale) {
   CSAM_REQUIRE(S && relpos_raw && P_f16 && G > 0 && G <= 65535 && Tp > 0 && T_valid <= Tp && side > 0,
                "csam_softmax_relpos: bad args");
-  hipLaunchKernelGGL(softmax_relpos_kernel, dim3(csam_cdiv(Tp, 4), G), dim3(256), 0, (hipStream_t)stream, S, relpos_raw,
-                     (half_t*)P_f16, Tp, T_valid, side, inv_scale);
+  static const bool three_pass = [] {                  // developer A/B: CSAM_SOFTMAX_RELPOS=0 -> the three-pass kernel
+    const char* e = getenv("CSAM_SOFTMAX_RELPOS");
+    return e && e[0] == '0';
+  }();
+  if (!three_pass && Tp == 256)                          // a padded 14 x 14 window: 4 scores per lane, 4 rows per wave
+    hipLaunchKernelGGL((softmax_relpos_reg_kernel<4, false, 4>), dim3(csam_cdiv(Tp, 16), G), dim3(256), 0, (hipStream_t)stream, S,
+                       relpos_raw, (half_t*)P_f16, Tp, T_valid, side, inv_scale);
+  else if (!three_pass && Tp == 4096 && side == 64)      // the global 64 x 64 grid: 64 scores per lane
+    hipLaunchKernelGGL((softmax_relpos_reg_kernel<64, true, 1>), dim3(csam_cdiv(Tp, 4), G), dim3(256), 0, (hipStream_t)stream, S,
+                       relpos_raw, (half_t*)P_f16, Tp, T_valid, side, inv_scale);
+  else
+    hipLaunchKernelGGL(softmax_relpos_kernel, dim3(csam_cdiv(Tp, 4), G), dim3(256), 0, (hipStream_t)stream, S, relpos_raw,
+                       (half_t*)P_f16, Tp, T_valid, side, inv_scale);
   CSAM_LAUNCH_CHECK("csam_softmax_relpos");
   return CSAM_OK;
 }

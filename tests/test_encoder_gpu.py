@@ -241,3 +241,29 @@ def test_encoder_vit_l_full_depth_vs_reference_golden(cuda):
     # check of tests/test_full_composition_gpu.py) -> measured x 2.5
     assert err.mean() < 0.0025 * scale and err.max() < 0.015 * scale, (err.mean(), err.max(), scale)
     assert abs(np.abs(y.astype(np.float64)).sum() - float(g["abs_sum"])) < 0.005 * float(g["abs_sum"])
+
+
+@pytest.mark.parametrize("shape", [(256, 196, 14, 7), (4096, 4096, 64, 2), (384, 300, 20, 3)])
+def test_softmax_relpos_register_form_vs_fp32(cuda, shape):
+    """csam_softmax_relpos (generic attention route, head_dim != 64): P = softmax(S + (Th[kh] + Tw[kw]) / scale) over the
+    valid keys, zero rows / columns in the padding.  The padded-window (Tp 256) and global-grid (Tp 4096, side 64) shapes run
+    the register-resident kernel, any other shape the three-pass kernel -- all against the same fp32 statement."""
+    from crowdsam_amd import hip
+    Tp, Tv, side, G = shape
+    gen = torch.Generator().manual_seed(Tp + side)
+    S = (torch.randn(G, Tp, Tp, generator=gen) * 2.0).to(cuda)
+    traw = (torch.randn(G, Tp, 256, generator=gen) * 0.7).to(cuda)
+    P = torch.full((G, Tp, Tp), 9.0, dtype=torch.float16, device=cuda)
+    inv_scale = 1.7
+    hip.softmax_relpos(S, traw, P, G, Tp, Tv, side, inv_scale)
+    q = torch.arange(Tv, device=cuda)
+    k = torch.arange(Tv, device=cuda)
+    ih = (q // side)[:, None] - (k // side)[None, :] + side - 1          # Th[kh] = traw[q, q/side + side-1 - kh]
+    iw = (q % side)[:, None] - (k % side)[None, :] + side - 1
+    th = torch.gather(traw[:, :Tv, :128], 2, ih[None].expand(G, -1, -1))
+    tw = torch.gather(traw[:, :Tv, 128:], 2, iw[None].expand(G, -1, -1))
+    ref = torch.softmax(S[:, :Tv, :Tv] + (th + tw) * inv_scale, -1)
+    got = P.float()
+    assert (got[:, :Tv, :Tv] - ref).abs().max().item() < 1e-3
+    assert got[:, Tv:, :].abs().max().item() == 0 if Tv < Tp else True
+    assert got[:, :, Tv:].abs().max().item() == 0 if Tv < Tp else True
