@@ -422,12 +422,223 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// head_dim 80 (ViT-H, round 3): the same kernel with three k-steps -- 32 + 32 + 16, the last one a 16x16x16 MFMA on
+// 8-byte fragments, so no dimension is padded -- and five 16-dim output tiles.  K rows are 176 B, V^T has 80 rows: 91 KB
+// of LDS with per-wave bias tables, one workgroup per CU, so the workgroup has EIGHT waves (the 13 query tiles of a window
+// in two rounds) and the 25 x nH grid runs in two rounds of 256.  relcat is [64, 80] here.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HD80 = 80;
+constexpr int KE80_LD = 88;                          // halfs per K row: 80 + 8 pad (176 B)
+constexpr int KE80_BYTES = NPAD * KE80_LD * 2;       // 36608
+constexpr int VT80_BYTES = HD80 * VT_LD * 2;         // 37120
+constexpr int NW80 = 8;
+constexpr int T80_BYTES = NW80 * 16 * T2_LD * 4;
+constexpr int SMEM80_BYTES = KE80_BYTES + VT80_BYTES + T80_BYTES;
+
+__global__ __launch_bounds__(64 * NW80, 1) void win_attn2_hd80_kernel(const half_t* __restrict__ qkv,
+                                                                      const float* __restrict__ qkv_bias,
+                                                                      const half_t* __restrict__ relcat,
+                                                                      half_t* __restrict__ out, int D, int nH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ke = (half_t*)smem;
+  half_t* Vt = (half_t*)(smem + KE80_BYTES);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* Tt = (float*)(smem + KE80_BYTES + VT80_BYTES) + wave * 16 * T2_LD;
+  const int head = blockIdx.x % nH, win = blockIdx.x / nH;
+  const int wy = win / 5, wx = win % 5;
+  const long ld = 3L * D;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero
+  for (int it = tid; it < (NPAD / 2) * 20; it += 64 * NW80) {
+    const int ip = it / 20, r = it % 20, which = 1 + r / 10, ch = r % 10;       // token pair, k|v, 8-channel chunk
+    half8_t v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = 2 * ip + t;
+      v[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < NTOK) {
+        const int y = wy * WS + i / WS, x = wx * WS + i % WS;
+        const int col = which * D + head * HD80 + ch * 8;
+        if (y < 64 && x < 64) {
+          v[t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[t][e] = (half_t)qkv_bias[col + e];
+        }
+      }
+    }
+    if (which == 1) {
+      *(half8_t*)(Ke + (2 * ip) * KE80_LD + ch * 8) = v[0];
+      *(half8_t*)(Ke + (2 * ip + 1) * KE80_LD + ch * 8) = v[1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[0][e], v[1][e]};
+    }
+  }
+  for (int it = tid; it < HD80 * 12; it += 64 * NW80)   // keys 208..231 of V^T (read by the last, half-empty k-step)
+    *(half2_t*)(Vt + (it / 12) * VT_LD + NPAD + 2 * (it % 12)) = half2_t{0, 0};
+
+  half8_t rf[4][2];
+  half4_t rg[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) rf[nt][ks] = *(const half8_t*)(relcat + (nt * 16 + fr) * HD80 + (ks * 4 + fg) * 8);
+    rg[nt] = *(const half4_t*)(relcat + (nt * 16 + fr) * HD80 + 64 + fg * 4);
+  }
+  int koff[13];
+#pragma unroll
+  for (int kt = 0; kt < 13; ++kt) {
+    const int key0 = kt * 16 + fg * 4;
+    koff[kt] = ((key0 / WS) << 8) | (key0 % WS);
+  }
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+  const unsigned kaddr = lds0 + fr * (KE80_LD * 2) + fg * 16;
+  const unsigned kaddr16 = lds0 + fr * (KE80_LD * 2) + 128 + fg * 8;
+  unsigned vaddr[5];
+#pragma unroll
+  for (int dt = 0; dt < 5; ++dt) vaddr[dt] = lds0 + KE80_BYTES + (dt * 16 + fr) * (VT_LD * 2) + fg * 8;
+  __syncthreads();
+
+  const float sl2 = scale * 1.4426950408889634f;
+  const float l2e = 1.4426950408889634f;
+  for (int rt = wave; rt < 13; rt += NW80) {
+    const int qi = rt * 16 + fr;
+    const int qh = qi / WS, qw = qi % WS;
+    const int y = wy * WS + qh, x = wx * WS + qw;
+    const bool inside = qi < NTOK && y < 64 && x < 64;
+    half8_t qf[2];
+    half4_t qg = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = head * HD80 + (ks * 4 + fg) * 8;
+      qf[ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (inside) {
+        qf[ks] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
+      } else if (qi < NTOK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)qkv_bias[col + e];
+      }
+    }
+    {
+      const int col = head * HD80 + 64 + fg * 4;
+      if (inside) {
+        qg = *(const half4_t*)(qkv + (long)(y * 64 + x) * ld + col);
+      } else if (qi < NTOK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qg[e] = (half_t)qkv_bias[col + e];
+      }
+    }
+    floatx4 t4[4];
+    win_bias_mfma80(t4, rf, rg, qf, qg);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const floatx4 t = t4[nt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = nt * 16 + fg * 4 + r;
+        int col = -1;
+        if (j < 27) {
+          const int kh = qh + 13 - j;
+          if (kh >= 0 && kh < WS) col = kh;
+        } else if (j < 54) {
+          const int kw = qw + 13 - (j - 27);
+          if (kw >= 0 && kw < WS) col = TW_OFF + kw;
+        }
+        if (col >= 0) {
+          const float tv = t[r] * l2e;
+          Tt[fr * T2_LD + col] = tv;
+          if (col >= TW_OFF && col < TW_OFF + 4) Tt[fr * T2_LD + col + WS] = tv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    floatx4 p[14];
+    float mx = -INFINITY;
+    const float* trow = Tt + fr * T2_LD;
+    win_scores_mfma80(p, qf, qg, kaddr, kaddr16);
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt) {
+      floatx4 acc = p[kt];
+      const int kh0 = koff[kt] >> 8, kw0 = koff[kt] & 255;
+      const float2_t th = *(const float2_t*)(trow + (kh0 & ~1));
+      const float th0 = (kh0 & 1) ? th[1] : th[0];
+      const float th1 = (kh0 & 1) ? trow[min(kh0 + 1, WS - 1)] : th[1];
+      const float2_t twa = *(const float2_t*)(trow + TW_OFF + kw0);
+      const float2_t twb = *(const float2_t*)(trow + TW_OFF + kw0 + 2);
+      const float tw[4] = {twa[0], twa[1], twb[0], twb[1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kt * 16 + fg * 4 + j;
+        const float bias = ((kw0 + j >= WS) ? th1 : th0) + tw[j];
+        const float sv = (kk < NTOK) ? fmaf(acc[j], sl2, bias) : -INFINITY;
+        acc[j] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      p[kt] = acc;
+    }
+    p[13] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 14; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = csam_exp2(p[kt][j] - mx);
+        p[kt][j] = e;
+        sum += e;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    half8_t pf[7];
+#pragma unroll
+    for (int s2 = 0; s2 < 7; ++s2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[s2][e] = (half_t)p[2 * s2][e];
+        pf[s2][4 + e] = (half_t)p[2 * s2 + 1][e];
+      }
+    }
+    floatx4 o5[5];
+    win_pv_mfma80(o5, pf, vaddr);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const floatx4 o = o5[dt];
+      if (inside) {
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[j] * inv);
+        *(half4_t*)(out + (long)(y * 64 + x) * D + head * HD80 + dt * 16 + fg * 4) = h;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias,
                              const void* relcat_f16, void* out_f16, int D, int nH, float scale) {
   CSAM_REQUIRE(qkv_f16 && qkv_bias && relcat_f16 && out_f16, "csam_win_attn: null pointer");
-  CSAM_REQUIRE(nH > 0 && D == nH * 64, "csam_win_attn: head_dim must be 64 (D=%d nH=%d)", D, nH);
+  CSAM_REQUIRE(nH > 0 && (D == nH * 64 || D == nH * 80), "csam_win_attn: head_dim must be 64 or 80 (D=%d nH=%d)", D, nH);
+  if (D == nH * 80) {                                   // ViT-H: relcat is [64, 80]
+    static bool set80 = false;
+    if (!set80) {
+      hipFuncSetAttribute((const void*)win_attn2_hd80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM80_BYTES);
+      set80 = true;
+    }
+    hipLaunchKernelGGL(win_attn2_hd80_kernel, dim3(25 * nH), dim3(64 * NW80), SMEM80_BYTES, (hipStream_t)stream,
+                       (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
+    CSAM_LAUNCH_CHECK("csam_win_attn");
+    return CSAM_OK;
+  }
   static int version = -1;
   if (version < 0) {
     const char* e = getenv("CSAM_WIN_ATTN");          // 1 = the round-1 kernel (A/B and debugging)

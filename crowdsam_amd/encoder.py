@@ -5,6 +5,8 @@ reference; all arithmetic runs in libcsam_hip.so.  Data layout in HBM: token-maj
 the whole encoder (NHWC of the 64x64 grid) -- no permutes, no window-partition copies.
 Residual stream fp32, GEMM operands fp16, fp32 MFMA accumulation.
 """
+import os
+
 import torch
 
 from . import hip
@@ -20,6 +22,8 @@ class EncoderPlan:
         # head_dim 64 (ViT-B/L) runs the fused flash / window kernels; any other head_dim <= 128 (ViT-H: 80) runs the
         # materialised gather / batched-GEMM / softmax route of csrc/attn_generic.hip
         self.fused_attn = hd == 64
+        # round 3: the windowed kernel also exists for head_dim 80 (28 of ViT-H's 32 blocks); its global blocks stay generic
+        self.fused_win = hd in (64, 80) and os.environ.get("CSAM_WIN_HD80", "1") != "0"
         assert hd <= 128 and hd % 8 == 0, "head_dim must be a multiple of 8, at most 128"
         assert D % 128 == 0, "GEMM tiles need embed_dim % 128 == 0"
         self.D, self.depth, self.heads, self.global_idx = D, depth, heads, tuple(global_idx)
@@ -54,6 +58,8 @@ class EncoderPlan:
             assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, hd), "rel-pos table must be (2S-1, head_dim) at 1024^2"
             if self.fused_attn:
                 bl["relcat"] = (hip.relcat_global if bl["is_global"] else hip.relcat_window)(bl["rel_h"], bl["rel_w"])
+            elif self.fused_win and not bl["is_global"]:
+                bl["relcat"] = hip.relcat_window(bl["rel_h"], bl["rel_w"])
             else:   # [256, 128]: rows 0..L-1 = rel_h, rows 128..128+L-1 = rel_w, head dims zero-padded to 128
                 rc = torch.zeros(256, 128, dtype=torch.float16, device=device)
                 rc[:L, :hd] = bl["rel_h"].to(torch.float16)
@@ -98,7 +104,9 @@ class EncoderPlan:
         for b in self.blocks:
             hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
             hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
-            if not self.fused_attn:
+            if not self.fused_attn and self.fused_win and not b["is_global"]:
+                hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
+            elif not self.fused_attn:
                 self._attn_generic(b)
             elif b["is_global"]:
                 hip.relpos_raw(ws["qkv"], b["relcat"], ws["traw"], nH)

@@ -324,8 +324,8 @@ def add_cast(a, b=None, b_row_stride=0, out16=None, out32=None):
 
 
 def relcat_window(rel_h, rel_w):
-    """[64,64] fp16 operand of the windowed kernel: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero."""
-    r = torch.zeros(64, 64, dtype=torch.float16, device=rel_h.device)
+    """[64, head_dim] fp16 operand of the windowed kernel: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero."""
+    r = torch.zeros(64, rel_h.shape[1], dtype=torch.float16, device=rel_h.device)
     r[:27] = rel_h.half()
     r[27:54] = rel_w.half()
     return r

@@ -111,8 +111,9 @@ int csam_u8hwc_to_f32chw(void* stream, const uint8_t* src_hwc, int h, int w, flo
 /* ---- attention */
 /* 14x14 windowed attention + decomposed rel-pos; window partition/unpartition folded into the
  * addressing; pad tokens are REAL keys whose q/k/v equal the qkv bias (image_encoder.py:224-289,
- * 325-361; SURVEY.md trap 4). qkv f16 [4096,3D] laid out [3][nH][64]; out f16 [4096,D]. */
-/* relcat_f16 [64,64]: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero (fp16 like the other weights) */
+ * 325-361; SURVEY.md trap 4). qkv f16 [4096,3D] laid out [3][nH][hd]; out f16 [4096,D]; head_dim hd = D / nH is 64
+ * (ViT-B / L) or 80 (ViT-H). */
+/* relcat_f16 [64,hd]: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero (fp16 like the other weights) */
 int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const void* relcat_f16, void* out_f16,
                   int D, int nH, float scale);
 /* generic head_dim (<= 128, multiple of 8; ViT-H: 80) attention = gather / batched GEMMs / softmax / scatter, the

@@ -85,17 +85,19 @@ def test_flash_relpos_repeatable_many_launches(cuda):
     assert not bad, "launches that differ from the first: %s" % bad[:10]
 
 
-def test_win_attn_repeatable_many_launches(cuda):
+@pytest.mark.parametrize("hd", [64, 80])
+def test_win_attn_repeatable_many_launches(cuda, hd):
     from crowdsam_amd import hip
     torch.manual_seed(5)
-    nH, D = 16, 1024
+    nH = 16
+    D = nH * hd
     qkv = torch.randn(4096, 3 * D, device=cuda).half()
     b = torch.randn(3 * D, device=cuda)
-    rc = hip.relcat_window(torch.randn(27, 64, device=cuda), torch.randn(27, 64, device=cuda))
+    rc = hip.relcat_window(torch.randn(27, hd, device=cuda), torch.randn(27, hd, device=cuda))
     outs = []
     for _ in range(250):
         o = torch.empty(4096, D, device=cuda, dtype=torch.float16)
-        hip.win_attn(qkv, b, rc, o, D, nH, 0.125)
+        hip.win_attn(qkv, b, rc, o, D, nH, hd ** -0.5)
         outs.append(o)
     torch.cuda.synchronize()
     bad = [i for i, o in enumerate(outs) if not _same(outs[0], o)]

@@ -54,31 +54,35 @@ def _rel_bias(q, rel_h, rel_w, S):
     # q [nH, S*S, 64] fp32 -> bias [nH, S*S, S*S]   (image_encoder.py:325-361)
     idx = torch.arange(S, device=q.device)[:, None] - torch.arange(S, device=q.device)[None, :] + (S - 1)
     Rh, Rw = rel_h[idx], rel_w[idx]
-    rq = q.reshape(q.shape[0], S, S, 64)
+    rq = q.reshape(q.shape[0], S, S, q.shape[-1])
     bh = torch.einsum("nhwc,hkc->nhwk", rq, Rh)
     bw = torch.einsum("nhwc,wkc->nhwk", rq, Rw)
     return (bh[:, :, :, :, None] + bw[:, :, :, None, :]).reshape(q.shape[0], S * S, S * S)
 
 
-def test_win_attn(cuda):
+@pytest.mark.parametrize("hd", [64, 80])
+def test_win_attn(cuda, hd):
+    """head_dim 64 (ViT-B / L) and 80 (ViT-H: 32 + 32 + 16 k-steps, five output tiles, eight waves per workgroup)."""
     from crowdsam_amd import hip
-    nH, D = 2, 128
+    nH = 2 if hd == 64 else 3
+    D = nH * hd
+    sc = hd ** -0.5
     g = torch.Generator().manual_seed(1)
     qkv = (torch.randn(4096, 3 * D, generator=g)).to(cuda).half()
     bias = torch.randn(3 * D, generator=g).to(cuda)
-    rel_h = (torch.randn(27, 64, generator=g) * 0.25).to(cuda)
-    rel_w = (torch.randn(27, 64, generator=g) * 0.25).to(cuda)
+    rel_h = (torch.randn(27, hd, generator=g) * 0.25).to(cuda)
+    rel_w = (torch.randn(27, hd, generator=g) * 0.25).to(cuda)
     out = torch.zeros(4096, D, device=cuda, dtype=torch.float16)
-    hip.win_attn(qkv, bias, hip.relcat_window(rel_h, rel_w), out, D, nH, 0.125)
+    hip.win_attn(qkv, bias, hip.relcat_window(rel_h, rel_w), out, D, nH, sc)
     rel_h, rel_w = rel_h.half().float(), rel_w.half().float()      # the kernel holds the tables in fp16
     # reference: pad with the bias (== qkv of a zero token), partition, attend, unpartition
     grid = bias.half().float().expand(70, 70, 3 * D).clone()
     grid[:64, :64] = qkv.float().view(64, 64, 3 * D)
-    win = grid.view(5, 14, 5, 14, 3 * D).permute(0, 2, 1, 3, 4).reshape(25, 196, 3, nH, 64)
+    win = grid.view(5, 14, 5, 14, 3 * D).permute(0, 2, 1, 3, 4).reshape(25, 196, 3, nH, hd)
     q, k, v = win[:, :, 0].transpose(1, 2), win[:, :, 1].transpose(1, 2), win[:, :, 2].transpose(1, 2)
-    ref = torch.empty(25, nH, 196, 64, device=cuda)
+    ref = torch.empty(25, nH, 196, hd, device=cuda)
     for w in range(25):
-        s = (q[w] * 0.125) @ k[w].transpose(-1, -2) + _rel_bias(q[w], rel_h, rel_w, 14)
+        s = (q[w] * sc) @ k[w].transpose(-1, -2) + _rel_bias(q[w], rel_h, rel_w, 14)
         ref[w] = s.softmax(-1) @ v[w]
     ref = ref.transpose(1, 2).reshape(5, 5, 14, 14, D).permute(0, 2, 1, 3, 4).reshape(70, 70, D)[:64, :64]
     err = (out.float().view(64, 64, D) - ref).abs().max().item()
