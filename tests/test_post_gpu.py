@@ -165,3 +165,45 @@ def test_rle_matches_oracle(cuda):
         counts = [] if not bool(masks[i, 0, 0]) else [0]
         counts.extend(np.diff(idx).tolist())
         assert counts == ref[i]["counts"]
+
+
+@pytest.mark.parametrize("downscale", [1.0, 2.0, 3.0, 1.5])
+def test_crop_edge_filter_at_the_20px_boundary(cuda, downscale):
+    """The in-kernel crop-edge filter of csam_post_finalize_compact (crowdsam/utils.py:213-223 through
+    uncrop_boxes_xyxy's tensor / Python-scalar division, which ATen evaluates as a multiply by the fp32 reciprocal) with box
+    sides placed 19 / 20 / 21 px (after un-scaling) from every crop edge and from the frame border: keep flags must equal
+    the oracle's `is_box_near_crop_edge` on the same boxes, also for downscales whose reciprocal is inexact."""
+    from crowdsam_amd import hip
+    from oracle import pipeline_oracle as po
+    crop = [300, 200, 1300, 900]                       # x0, y0, x1, y1 in the frame
+    orig = [0, 0, 1600, 900]                           # the crop's bottom edge IS the frame border (never "near a crop edge")
+    rows = []
+    for d in (19, 20, 21, 40):
+        for side in range(4):
+            # a box (crop-local, scaled by downscale) whose one side sits d frame pixels inside the corresponding crop edge
+            fx0, fy0, fx1, fy1 = 500.0, 400.0, 900.0, 700.0               # frame coordinates of a harmless interior box
+            f = [fx0, fy0, fx1, fy1]
+            f[side] = crop[side] + d if side < 2 else crop[side] - d
+            rows.append([round((f[0] - crop[0]) * downscale), round((f[1] - crop[1]) * downscale),
+                         round((f[2] - crop[0]) * downscale), round((f[3] - crop[1]) * downscale)])
+    box = torch.tensor(rows, dtype=torch.int32, device=cuda)
+    B = box.shape[0]
+    score = torch.full((B,), 0.9, device=cuda)
+    inter = torch.full((B,), 1000, dtype=torch.int32, device=cuda)
+    uni = torch.full((B,), 1000, dtype=torch.int32, device=cuda)
+    category = torch.zeros(B, dtype=torch.int32, device=cuda)
+    points = torch.zeros(B, 2, dtype=torch.int32, device=cuda)
+    keep = torch.empty(B, dtype=torch.uint8, device=cuda)
+    occ = torch.empty(B, dtype=torch.uint8, device=cuda)
+    slot = torch.empty(B, dtype=torch.int32, device=cuda)
+    cap = B + 4
+    e = lambda *s, dt: torch.zeros(*s, dtype=dt, device=cuda)
+    store = dict(score=e(cap, dt=torch.float32), stability=e(cap, dt=torch.float32), boxes=e(cap, 4, dt=torch.int32),
+                 category=e(cap, dt=torch.int32), points=e(cap, 2, dt=torch.int32), counter=e(1, dt=torch.int32))
+    hip.post_finalize_compact(score, inter, uni, box, category, points, 0.1, 0.5, 3.0e38, keep, occ, slot, store["counter"],
+                              store, B, edge=(crop, orig, downscale, 20.0))
+    near = po.is_box_near_crop_edge(box.cpu().float(), crop, orig, downscale, atol=20.0).numpy()
+    got = keep.cpu().numpy().astype(bool)
+    assert near.any() and (~near).any()
+    assert np.array_equal(got, ~near), (downscale, np.nonzero(got != ~near)[0].tolist())
+    assert int(store["counter"].item()) == int((~near).sum())
