@@ -35,7 +35,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h))
-                        for h in os.listdir(CSRC) if h.endswith(".h"))):
+                        for h in os.listdir(CSRC) if h.endswith((".h", ".inc")))):
             continue
         cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
                "-Wno-unused-result", "-Wno-unused-value"] + EXTRA_FLAGS.get(os.path.basename(src), []) + \

@@ -481,6 +481,264 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const hal
   }
 }
 
+
+// =====================================================================================================================
+// head_dim 80 (ViT-H global blocks, round 3).  Same kernel, three k-steps: dims 0..63 as above (the K tile keeps its 128-B
+// swizzled rows), dims 64..79 in a 2 KB EXTENSION tile of 32-B rows read as 8-byte fragments into a 16x16x16 MFMA -- no
+// padded dimension -- and five 16-dim output tiles (V^T tile of 80 rows).  Slot = K 8 KB | Kx 2 KB | V^T 10 KB; three slots
+// = 60 KB, two workgroups per CU.  q is scaled in the kernel (qmul), the rel-pos tables by bmul.
+// =====================================================================================================================
+#include "attn_flash80_asm.inc"
+
+constexpr int F80_KX = 8192, F80_VT = 10240, F80_SLOT = 20480;
+
+// vt[h][d][t] = qkv[t][v_off + h*80 + d], d < 80 (columns T..Tpad-1 stay zero)
+__global__ __launch_bounds__(256) void transpose_v80_kernel(const half_t* __restrict__ qkv, long ld, int v_off,
+                                                            half_t* __restrict__ vt, int T, int Tpad) {
+  __shared__ half_t tile[80][66];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < 640; c += 256) {             // token c / 10, dims (c % 10) * 8 .. +7
+    const int t = t0 + c / 10, ch = c % 10;
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < T) v = *(const half8_t*)(qkv + (long)t * ld + v_off + h * 80 + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[ch * 8 + e][c / 10] = v[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < 640; c += 256) {             // dim row c >> 3, tokens (c & 7) * 8 .. +7
+    const int d = c >> 3, tt = (c & 7) * 8;
+    half8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[d][tt + e];
+    *(half8_t*)(vt + ((long)h * 80 + d) * Tpad + t0 + tt) = v;
+  }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void flash_attn80_kernel(const half_t* __restrict__ qkv, long ld, int q_off, int k_off,
+                                                              const half_t* __restrict__ vt, int Tpad,
+                                                              const float* __restrict__ traw, half_t* __restrict__ out,
+                                                              long ldo, int T, float qmul, float bmul, int xcd_heads) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * F80_SLOT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fg = lane >> 4;
+  int head, qblk;
+  if (xcd_heads) {
+    const int b = blockIdx.x, x = b & 7, i = b >> 3, nqb = gridDim.x / (xcd_heads * 8);
+    head = x + 8 * (i / nqb);
+    qblk = i % nqb;
+  } else {
+    head = blockIdx.y;
+    qblk = blockIdx.x;
+  }
+  const int q0 = qblk * QPB + wave * QPW;
+  const half_t* qp = qkv + q_off + head * 80;
+  const half_t* kp = qkv + k_off + head * 80;
+  const half_t* vtp = vt + (long)head * 80 * Tpad;
+
+  half8_t qf[2][2];
+  half4_t qg[2];
+  int qrow[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    qrow[rt] = q0 + rt * 16 + fr;
+    const int qc = qrow[rt] < T ? qrow[rt] : T - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[rt][ks] = *(const half8_t*)(qp + (long)qc * ld + (ks * 4 + fg) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[rt][ks][e] = (half_t)((float)qf[rt][ks][e] * qmul);
+    }
+    qg[rt] = *(const half4_t*)(qp + (long)qc * ld + 64 + fg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qg[rt][e] = (half_t)((float)qg[rt][e] * qmul);
+  }
+  const int krow_in_step = 8 * (fr >> 2) + (fr & 3);
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  const unsigned kaddr0 = lds0 + krow_in_step * 128 + ((fg ^ kswz(krow_in_step)) << 4);
+  const unsigned kaddr1 = lds0 + krow_in_step * 128 + (((4 + fg) ^ kswz(krow_in_step)) << 4);
+  const unsigned kxaddr = lds0 + F80_KX + krow_in_step * 32 + fg * 8;
+  const unsigned vaddr0 = lds0 + F80_VT + fr * 128 + ((fg ^ (fr & 7)) << 4);
+  const unsigned vaddr1 = lds0 + F80_VT + fr * 128 + (((4 + fg) ^ (fr & 7)) << 4);
+  floatx4 twr[2][4];
+  const float* thp[2] = {nullptr, nullptr};
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int qc = qrow[rt] < T ? qrow[rt] : T - 1;
+      const float* tq = traw + ((long)head * T + qc) * 256;
+      thp[rt] = tq + (qc >> 6) + 63;
+      const float* twq = tq + 128 + (qc & 63) + 63;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int kw0 = (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) twr[rt][kt][j] = twq[-(kw0 + j)] * bmul;
+      }
+    }
+    // finished and pinned in the prologue: see flash_attn_kernel
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      asm volatile("" : "+v"(twr[rt][0]), "+v"(twr[rt][1]), "+v"(twr[rt][2]), "+v"(twr[rt][3]));
+  }
+  floatx4 o[2][5];
+  float mref[2], l[2];
+  const half8_t ones8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    mref[rt] = 0.f;
+    l[rt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) o[rt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nt = (T + KT - 1) / KT;
+  auto stage = [&](int buf, int t) {
+    char* slot = smem + buf * F80_SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                    // K rows (dims 0..63) and V^T rows 0..63: 512 pieces each
+      const int c = tid + i * 256;
+      const int row = c >> 3, sl = c & 7;
+      int key = t * KT + row;
+      key = key < T ? key : T - 1;
+      glds16(kp + (long)key * ld + ((sl ^ kswz(row)) * 8), slot + (c & ~63) * 16);
+      glds16(vtp + (long)row * Tpad + t * KT + ((sl ^ (row & 7)) * 8), slot + F80_VT + (c & ~63) * 16);
+    }
+    if (tid < 128) {                                 // waves 0, 1: V^T rows 64..79 and the K extension (dims 64..79)
+      const int c = tid;
+      const int row = 64 + (c >> 3), sl = c & 7;
+      glds16(vtp + (long)row * Tpad + t * KT + ((sl ^ (row & 7)) * 8), slot + F80_VT + 8192 + (c & ~63) * 16);
+      int key = t * KT + (c >> 1);
+      key = key < T ? key : T - 1;
+      glds16(kp + (long)key * ld + 64 + (c & 1) * 8, slot + F80_KX + (c & ~63) * 16);
+    }
+  };
+  float thn[2] = {0.f, 0.f};
+  if constexpr (BIAS) {
+    thn[0] = thp[0][0];
+    thn[1] = thp[1][0];
+  }
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) stage(cur == 0 ? 2 : cur - 1, t + 2);
+    const unsigned kbase = cur * F80_SLOT;
+    cur = cur + 1 == 3 ? 0 : cur + 1;
+
+    floatx4 s[2][4];
+    float thv[2] = {0.f, 0.f};
+    if constexpr (BIAS) {
+      thv[0] = thn[0] * bmul;
+      thv[1] = thn[1] * bmul;
+      if (t + 1 < nt) {
+        thn[0] = thp[0][-(t + 1)];
+        thn[1] = thp[1][-(t + 1)];
+      }
+    }
+    auto scores = [&]() {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float c0 = thv[rt] - mref[rt];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          if constexpr (BIAS) {
+            s[rt][kt] = twr[rt][kt] + c0;
+          } else {
+            s[rt][kt] = floatx4{c0, c0, c0, c0};
+          }
+        }
+      }
+      asm volatile("s_nop 1" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),
+                   "+v"(s[1][2]), "+v"(s[1][3]));      // VALU-written seeds -> MFMA SrcC
+      scores_mfma80(s, qf, qg, kaddr0 + kbase, kaddr1 + kbase, kxaddr + kbase);
+      if ((t + 1) * KT > T) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (t * KT + (kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j >= T) s[rt][kt][j] = -INFINITY;
+      }
+    };
+    half8_t pf[2][2];
+    floatx4 lt[2];
+    auto probs = [&]() {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[rt][kt][j] = csam_exp2(s[rt][kt][j]);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pf[rt][st][e] = (half_t)s[rt][2 * st][e];
+            pf[rt][st][4 + e] = (half_t)s[rt][2 * st + 1][e];
+          }
+      }
+      lt[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+      lt[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+      rowsum_mfma(lt, pf, ones8);
+    };
+    scores();
+    bool renorm = t == 0;
+    if (!renorm) {
+      probs();
+      renorm = __ballot(!(lt[0][0] < 1e30f) || !(lt[1][0] < 1e30f)) != 0ull;
+      if (renorm) scores();
+    }
+    if (renorm) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[rt][kt][j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+        mref[rt] += delta;
+        if (t > 0) {
+          const float a = csam_exp2(-delta);
+          l[rt] *= a;
+#pragma unroll
+          for (int dt = 0; dt < 5; ++dt) o[rt][dt] *= a;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[rt][kt] -= delta;
+      }
+      probs();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) l[rt] += lt[rt][0];
+    pv_mfma80(o, pf, vaddr0 + kbase, vaddr1 + kbase);
+  }
+  asm volatile("s_nop 7\n\ts_nop 3" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[0][3]), "+v"(o[0][4]), "+v"(o[1][0]),
+               "+v"(o[1][1]), "+v"(o[1][2]), "+v"(o[1][3]), "+v"(o[1][4]));
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const float inv = 1.0f / l[rt];
+    if (qrow[rt] < T) {
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) {
+        half4_t h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (half_t)(o[rt][dt][j] * inv);
+        *(half4_t*)(out + (long)qrow[rt] * ldo + head * 80 + dt * 16 + fg * 4) = h;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
@@ -524,5 +782,40 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
                        q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul,
                        xcd_heads);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
+  return CSAM_OK;
+}
+
+// head_dim 80 form (ViT-H): qkv heads are 80 wide, V^T workspace nH x 80 x Tpad fp16 (zero-initialised once); q is scaled
+// inside the kernel.  relpos_raw as for csam_flash_attn (T == 4096 only).
+extern "C" long csam_flash_attn80_workspace_bytes(int T, int nH) {
+  const long Tpad = (long)((T + 63) / 64) * 64;
+  return (long)nH * 80 * Tpad * 2;
+}
+
+extern "C" int csam_flash_attn80(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                                 const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
+                                 void* vt_workspace, long vt_workspace_bytes) {
+  CSAM_REQUIRE(qkv_f16 && out_f16 && vt_workspace && T > 0 && nH > 0, "csam_flash_attn80: bad args");
+  if (vt_workspace_bytes < csam_flash_attn80_workspace_bytes(T, nH)) {
+    csam_set_error("csam_flash_attn80: V^T workspace too small (must also be zero-initialised once)");
+    return CSAM_ERR_WORKSPACE;
+  }
+  const int Tpad = ((T + 63) / 64) * 64;
+  CSAM_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0,
+               "csam_flash_attn80: alignment");
+  CSAM_REQUIRE(!relpos_raw || T == 4096, "csam_flash_attn80: rel-pos bias needs the 64x64 token grid");
+  hipLaunchKernelGGL(transpose_v80_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
+                     v_off, (half_t*)vt_workspace, T, Tpad);
+  dim3 grid(csam_cdiv(T, QPB), nH), block(256);
+  const int xcd_heads = (nH % 8 == 0) ? nH / 8 : 0;
+  if (xcd_heads) grid = dim3(csam_cdiv(T, QPB) * nH);
+  const float log2e = 1.4426950408889634f;
+  if (relpos_raw)
+    hipLaunchKernelGGL(flash_attn80_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld, q_off, k_off,
+                       (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale * log2e, log2e, xcd_heads);
+  else
+    hipLaunchKernelGGL(flash_attn80_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld, q_off, k_off,
+                       (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, scale * log2e, log2e, xcd_heads);
+  CSAM_LAUNCH_CHECK("csam_flash_attn80");
   return CSAM_OK;
 }

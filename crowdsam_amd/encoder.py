@@ -60,6 +60,8 @@ class EncoderPlan:
                 bl["relcat"] = (hip.relcat_global if bl["is_global"] else hip.relcat_window)(bl["rel_h"], bl["rel_w"])
             elif self.fused_win and not bl["is_global"]:
                 bl["relcat"] = hip.relcat_window(bl["rel_h"], bl["rel_w"])
+            elif self.fused_win and hd == 80:
+                bl["relcat"] = hip.relcat_global80(bl["rel_h"], bl["rel_w"])
             else:   # [256, 128]: rows 0..L-1 = rel_h, rows 128..128+L-1 = rel_w, head dims zero-padded to 128
                 rc = torch.zeros(256, 128, dtype=torch.float16, device=device)
                 rc[:L, :hd] = bl["rel_h"].to(torch.float16)
@@ -106,6 +108,9 @@ class EncoderPlan:
             hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
             if not self.fused_attn and self.fused_win and not b["is_global"]:
                 hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
+            elif not self.fused_attn and self.fused_win and self.hd == 80:
+                hip.relpos_raw80(ws["qkv"], b["relcat"], ws["traw"], nH)
+                hip.flash_attn80(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"])
             elif not self.fused_attn:
                 self._attn_generic(b)
             elif b["is_global"]:

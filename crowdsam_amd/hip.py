@@ -31,6 +31,7 @@ SIGNATURES = {
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
     "csam_win_attn": [_P, _P, _P, _P, _P, _I, _I, _F],
     "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L, _I],
+    "csam_flash_attn80": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
     "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
@@ -101,6 +102,7 @@ LONG_RETURNS = {
     "csam_i2t_rank_workspace_bytes": [_I],
     "csam_i2t_rank_proj_workspace_bytes": [_I],
     "csam_i2t_t2i_workspace_bytes": [_I],
+    "csam_flash_attn80_workspace_bytes": [_I, _I],
 }
 
 _lib = None
@@ -372,6 +374,32 @@ def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None, q_prescaled=Fals
         vt = flash_vt_workspace(T, nH, qkv.device)
     call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out),
          out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2, int(bool(q_prescaled)))
+    return out
+
+
+def flash_attn80(qkv, out, T, nH, scale, D, relpos=None):
+    """head_dim 80: qkv f16 [T, 3*D] laid out [3][nH][80] per row -> out f16 [T, D]; relpos = relpos_raw80(...) or None."""
+    key = ("hd80", T, nH, str(qkv.device))
+    if key not in _vt_ws:
+        _vt_ws[key] = torch.zeros(lib().csam_flash_attn80_workspace_bytes(T, nH) // 2, dtype=torch.float16, device=qkv.device)
+    vt = _vt_ws[key]
+    call("csam_flash_attn80", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out), out.stride(0), T, nH,
+         float(scale), _ptr(vt), vt.numel() * 2)
+    return out
+
+
+def relcat_global80(rel_h, rel_w):
+    """[256,128] fp16 GEMM operand of the global blocks at head_dim 80: rows 0..126 rel_pos_h, 128..254 rel_pos_w, columns
+    80..127 zero (the GEMM's K is 128: the 48 extra q columns it reads belong to the next head and meet zeros)."""
+    r = torch.zeros(256, 128, dtype=torch.float16, device=rel_h.device)
+    r[:127, :80] = rel_h.half()
+    r[128:255, :80] = rel_w.half()
+    return r
+
+
+def relpos_raw80(qkv, relcat_g80, out, nH):
+    """out f32 [nH,4096,256] = q_h @ relcat^T for every head at head_dim 80 (one batched MFMA GEMM, K = 128 zero-padded)."""
+    gemm_f16_batched(qkv, qkv.stride(0), 80, relcat_g80, 128, 0, out, 256, 4096 * 256, 4096, 256, 128, nH)
     return out
 
 

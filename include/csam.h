@@ -136,6 +136,12 @@ long csam_flash_attn_workspace_bytes(int T, int nH); /* per-head V^T scratch; ze
 int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
                     const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
                     long vt_workspace_bytes, int q_prescaled);
+/* the same at head_dim 80 (ViT-H global blocks): qkv heads 80 wide, V^T scratch nH x 80 x Tpad, q scaled in-kernel; relpos_raw
+ * as above, from plain q (e.g. one batched GEMM with K = 128 over a [256,128] table whose columns 80.. are zero). */
+long csam_flash_attn80_workspace_bytes(int T, int nH);
+int csam_flash_attn80(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                      const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
+                      long vt_workspace_bytes);
 
 /* ---- prompt encoder + two-way decoder (all prompts of a batch at once) */
 /* prompt_encoder.py:75-93,189-218 + mask_decoder.py:153-155: tokens f32 [B,7,256] =

@@ -114,6 +114,49 @@ def test_flash_attn(cuda, T, bias):
     assert err < 6e-3, err
 
 
+@pytest.mark.parametrize("T,bias", [(4096, True), (4096, False), (1000, False), (200, False)])
+def test_flash_attn_head_dim_80(cuda, T, bias):
+    """csam_flash_attn80 (ViT-H global blocks): k-steps 32 + 32 + 16, five output tiles, 16 heads (the XCD-aware grid) and 3
+    heads (the plain grid), rel-pos tables through the zero-padded K = 128 batched GEMM; also a 60-octave score ramp through
+    the renormalisation path."""
+    from crowdsam_amd import hip
+    for nH in (3, 16):
+        D = nH * 80
+        sc = 80 ** -0.5
+        g = torch.Generator().manual_seed(T + nH)
+        qkv = torch.randn(T, 3 * D, generator=g).to(cuda).half()
+        if not bias and nH == 3:                     # ramp: key norms grow along the sequence, then drop
+            ramp = torch.cat([torch.linspace(0.2, 9.0, T // 2), torch.linspace(9.0, 0.5, T - T // 2)]).to(cuda)
+            qkv[:, D:2 * D] = (qkv[:, D:2 * D].float() * ramp[:, None]).half()
+        out = torch.zeros(T, D, device=cuda, dtype=torch.float16)
+        q = qkv[:, :D].float().view(T, nH, 80).transpose(0, 1)
+        k = qkv[:, D:2 * D].float().view(T, nH, 80).transpose(0, 1)
+        v = qkv[:, 2 * D:].float().view(T, nH, 80).transpose(0, 1)
+        s = (q * sc) @ k.transpose(-1, -2)
+        if bias:
+            rel_h = (torch.randn(127, 80, generator=g) * 0.25).to(cuda)
+            rel_w = (torch.randn(127, 80, generator=g) * 0.25).to(cuda)
+            traw = torch.empty(nH, 4096, 256, device=cuda)
+            hip.relpos_raw80(qkv, hip.relcat_global80(rel_h, rel_w), traw, nH)
+            hip.flash_attn80(qkv, out, T, nH, sc, D, relpos=traw)
+            s = s + _rel_bias(q, rel_h.half().float(), rel_w.half().float(), 64)
+        else:
+            hip.flash_attn80(qkv, out, T, nH, sc, D)
+        ref = (s.softmax(-1) @ v).transpose(0, 1).reshape(T, D)
+        assert torch.isfinite(out).all()
+        err = (out.float() - ref).abs()
+        if not bias and nH == 3:      # scores of ~40 nats: the fp16 rounding of the scaled q alone moves a probability by ~2 %
+            assert err.max().item() < 8e-2 and err.mean().item() < 6e-3, (nH, err.max().item(), err.mean().item())
+        else:
+            assert err.max().item() < 6e-3, (nH, err.max().item())
+        out2 = torch.zeros_like(out)
+        if bias:
+            hip.flash_attn80(qkv, out2, T, nH, sc, D, relpos=traw)
+        else:
+            hip.flash_attn80(qkv, out2, T, nH, sc, D)
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+
+
 @pytest.mark.parametrize("T,bias", [(4096, True), (5330, False), (333, False)])
 def test_flash_attn_renormalisation_and_prescaled_q(cuda, T, bias):
     """The kernel tracks no running maximum: its softmax reference moves only when a probability leaves fp16's range.
@@ -201,17 +244,22 @@ def test_encoder_vs_reference_golden(cuda):
     assert abs(float(y.double().abs().sum()) - float(g["abs_sum"])) < 2e-3 * float(g["abs_sum"])
 
 
-@pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16), (640, 8), (1280, 16)])
-def test_encoder_real_width_vs_oracle(cuda, D, heads):
+@pytest.mark.parametrize("D,heads,generic", [(768, 12, False), (1024, 16, False), (640, 8, False), (1280, 16, False),
+                                             (640, 8, True), (768, 8, True)])
+def test_encoder_real_width_vs_oracle(cuda, D, heads, generic, monkeypatch):
     """Two blocks (one windowed, one global) at the real ViT-B / ViT-L / ViT-H width against the CPU oracle: exercises
     the production GEMM shapes (256x256 ping-pong kernel for qkv / fc1, 64-row tiles for proj / fc2) end to end.
-    head_dim 80 (640/8, 1280/16 = ViT-H) takes the materialised attention route of csrc/attn_generic.hip."""
+    head_dim 80 (640/8, 1280/16 = ViT-H) runs the head_dim-80 window / flash kernels; ``generic`` forces the materialised
+    attention route of csrc/attn_generic.hip (head_dim 80 with the kernels switched off, and head_dim 96, which has none)."""
     from crowdsam_amd import synth
     from crowdsam_amd.encoder import EncoderPlan
     from oracle import sam_oracle as so
     specs = [s for s in synth.sam_param_specs(D, 2, heads, (1,)) if s[0].startswith("image_encoder.")]
     sd = synth.make_state_dict(specs, 5)
+    if generic:
+        monkeypatch.setenv("CSAM_WIN_HD80", "0")
     plan = EncoderPlan(sd, "image_encoder.", D, 2, heads, (1,), cuda)
+    assert plan.fused_attn == (D // heads == 64) and plan.fused_win == (D // heads in (64, 80) and not generic)
     x = torch.from_numpy(np.random.RandomState(1).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
     mean = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1)
     std = torch.tensor([58.395, 57.12, 57.375]).view(3, 1, 1)
