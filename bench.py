@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Crowd-SAM dense-prompt inference throughput on MI355X (contract in the task brief).
 
-One "step" = one synthetic 1024x1024 CROWDED frame (~340 masks kept, see --crowd-keep) through the whole hot path (SAM ViT-L encoder +
+One "step" = one synthetic 1024x1024 CROWDED frame (~310-330 masks kept, see --crowd-keep) through the whole hot path (SAM ViT-L encoder +
 DINOv2-L + dense sweep of a 64x64 prompt grid = 4096 prompts through the two-way decoder, PWD-Net
 selection, fused mask post-processing, NMS, small-region clean-up, RLE) -> final numpy result.
 Weights are synthetic (seeded, reference key layout): there are no checkpoints on the box.
@@ -209,7 +209,7 @@ def main():
                          "about half of the 4096 prompts, a crowded-scene-like survivor share.")
     ap.add_argument("--encoder-only", action="store_true",
                     help="BASELINE configs[1]: SAM image-encoder forward only on a random normalised 1024^2 tensor")
-    ap.add_argument("--crowd-keep", type=int, default=780,
+    ap.add_argument("--crowd-keep", type=int, default=720,
                     help="dense mode: the timed frames are CROWDED -- box NMS off and a predicted-IoU cut calibrated on a warm-up "
                          "frame let ~this many candidates through, ~320 masks per image then go through small-region clean-up "
                          "+ RLE; 0 = time the shipped thresholds (random-weight masks collapse to ~1 in NMS)")
