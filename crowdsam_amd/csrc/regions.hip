@@ -644,25 +644,23 @@ __global__ __launch_bounds__(256, 8) void cc2_scan_kernel(const uint8_t* __restr
     }
   }
   for (int i = 0; i < 16; ++i) {                      // north links: cc_tile_kernel's decision tree
+    // The tree has four union sites (NE behind a west neighbour | N | NW | NE); inlined one by one they are four divergent
+    // loop nests of dependent LDS round trips per row, each entered by the whole wave when any lane needs it -- on noisy
+    // masks nearly always.  A pixel makes at most two links, and the first one is exclusive across the branches: ONE
+    // union site for it, a second (rare: NW and NE both set, N clear) for the other.  42 % of the kernel's time on noise.
     const int r = wave * 16 + i;
     if (r == 0) continue;
     const unsigned long long cur = rowbits[r], up = rowbits[r - 1];
-    if (!((cur >> lane) & 1ull)) continue;
+    const bool wk = (cur >> lane) & 1ull;
     const bool w = lane > 0 && ((cur >> (lane - 1)) & 1ull);
-    const bool b = (up >> lane) & 1ull;
+    const bool bb = (up >> lane) & 1ull;
     const bool c = lane < 63 && ((up >> (lane + 1)) & 1ull);
+    const bool a_ = lane > 0 && ((up >> (lane - 1)) & 1ull);
     const int p = r * 64 + lane;
-    if (w) {
-      if (c && !b) lds_union(P, p, p - 63);
-      continue;
-    }
-    if (b) {
-      lds_union(P, p, p - 64);
-      continue;
-    }
-    const bool a = lane > 0 && ((up >> (lane - 1)) & 1ull);
-    if (a) lds_union(P, p, p - 65);
-    if (c) lds_union(P, p, p - 63);
+    const bool has1 = wk && (w ? (c && !bb) : (bb || a_ || c));
+    const int q1 = w ? p - 63 : bb ? p - 64 : a_ ? p - 65 : p - 63;
+    if (has1) lds_union(P, p, q1);
+    if (wk && !w && !bb && a_ && c) lds_union(P, p, p - 63);
   }
   __syncthreads();
   // run starts: the run's final root, two 16-bit values per register (0xffff: not a run start) -- the kernel must stay
