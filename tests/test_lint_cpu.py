@@ -39,3 +39,12 @@ _Z1kv:                                  ; @k
 """)
     kinds = sorted(x[0] for x in L.scan(str(isa)))
     assert kinds == ["inflight", "store"], kinds
+
+
+def test_generated_asm_blocks_are_up_to_date():
+    """crowdsam_amd/csrc/*_asm.inc are generated (tools/gen/*.py); the committed files must be what the generators print."""
+    for gen, inc in (("gen_attn_window_asm.py", "attn_window_asm.inc"), ("gen_attn_flash80_asm.py", "attn_flash80_asm.inc")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", gen)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        have = open(os.path.join(ROOT, "crowdsam_amd", "csrc", inc)).read()
+        assert r.stdout == have, "%s is stale: python tools/gen/%s > crowdsam_amd/csrc/%s" % (inc, gen, inc)
