@@ -93,6 +93,7 @@ class CrowdSAM:
         # Efficient Prompt Sampler state on the device (no host round trip per batch); CSAM_EPS_DEVICE=0 keeps the point
         # list on the host and synchronises after every batch, as the reference does
         self.eps_on_device = os.environ.get("CSAM_EPS_DEVICE", "1") != "0"
+        self.eps_trace = None       # set to a list to collect (prompt points, n_valid) of every EPS round (tests, debugging)
         self.crop_n_layers = t["crop_n_layers"]
         self.crop_nms_thresh = t["crop_nms_thresh"]
         self.crop_overlap_ratio = t["crop_overlap_ratio"]
@@ -113,6 +114,9 @@ class CrowdSAM:
             raise NotImplementedError("apply_box_offsets is off in the shipped config (the decoder has no offset head)")
         self.timings = {}
         self.last_candidates = 0
+        self._next_image = None      # depth-2 pipeline (generate(next_image=...)): see _prefetch
+        self._prefetched = None
+        self._pf_stream = None
 
     def load_sam_model(self, sam_model, sam_arch, sam_checkpoint, sam_adapter_checkpoint, dino_model, n_class,
                        sam_state_dict=None):
@@ -150,9 +154,32 @@ class CrowdSAM:
         return self._image_np
 
     @torch.no_grad()
-    def generate(self, image):
-        """image: HWC uint8 RGB ndarray (or PIL image) -> MaskData of numpy fields."""
-        return self._generate_masks(image)
+    def generate(self, image, next_image=None):
+        """image: HWC uint8 RGB ndarray (or PIL image) -> MaskData of numpy fields (crowdsam/model.py:133-190).
+
+        ``next_image`` (build extension, the per-image loop of tools/test.py:62-82 as a depth-2 pipeline): the frame the
+        caller will pass to the NEXT generate() call.  Its upload, resize, SAM encoder || DINOv2 and per-image decoder
+        constants are enqueued on a side stream as soon as this frame's prompt sweep is queued, so they run beside this
+        frame's tail (NMS, connected components, RLE -- latency chains that under-fill the chip) and its D2H / string
+        packing.  No random number is drawn before sample_prompts, so results are bit-identical to serial calls
+        (tests/test_pipelined_gpu.py).  Ignored with crop_n_layers > 0 (the crops of one frame share the buffers)."""
+        self._next_image = next_image if self.crop_n_layers == 0 else None
+        try:
+            return self._generate_masks(image)
+        finally:
+            self._next_image = None
+
+    def generate_stream(self, images):
+        """Iterator over generate(image) for an iterable of frames with one frame of look-ahead (depth-2 pipeline)."""
+        it = iter(images)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield self.generate(cur, next_image=nxt)
+            cur = nxt
+        yield self.generate(cur)
 
     def _generate_masks(self, image):
         img_size = np.array(image).shape[:2]
@@ -228,12 +255,52 @@ class CrowdSAM:
             self._store_key = key
         return self._store
 
+    _CROP_STATE = ("orig_image", "_frame_u8", "_frame_f32", "_image_np", "image_hw", "downscale")
+
+    def _prefetch(self, image):
+        """Depth-2 pipeline: crop_image + predictor.set_image of the NEXT frame on a side stream.  Called once the current
+        frame's sweep is queued (everything that reads the encoder features, the DINOv2 tokens and the decoder's per-image
+        constants -- the buffers set_image overwrites -- is ordered before it by the stream wait); the current frame's
+        tail only touches the mask store and its own records.  The crop state of the current frame is put back afterwards:
+        its tail still needs ``downscale`` & co."""
+        main = torch.cuda.current_stream()
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+        side = self._pf_stream
+        if not isinstance(image, np.ndarray):
+            image = np.array(image, dtype=np.uint8)
+        h, w = image.shape[:2]
+        saved = {k: getattr(self, k) for k in self._CROP_STATE}
+        with torch.cuda.stream(side):
+            # the one H2D of the frame and its resize write fresh tensors only: they go up WHILE the sweep runs ...
+            self.crop_image(image, [0, 0, w, h])
+            # ... the encoders and the decoder constants overwrite what the sweep reads: behind it
+            side.wait_stream(main)
+            self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
+        state = {k: getattr(self, k) for k in self._CROP_STATE}
+        for t in (state["_frame_u8"], state["_frame_f32"]):
+            if torch.is_tensor(t):
+                t.record_stream(main)           # allocated on the side stream, read on the main one later
+        self._prefetched = dict(shape=image.shape, crop_box=[0, 0, w, h], state=state)
+        for k, v in saved.items():
+            setattr(self, k, v)
+
     def _process_crop(self, image, crop_box):
         t0 = time.perf_counter()
-        self.crop_image(image, crop_box)
-        self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
+        pf, self._prefetched = self._prefetched, None
+        if self._pf_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._pf_stream)     # a prefetch (used or not) owns the shared buffers
+        img_np = image if isinstance(image, np.ndarray) else None
+        if (pf is not None and img_np is not None and pf["crop_box"] == list(crop_box) and pf["shape"] == img_np.shape
+                and pf["state"]["orig_image"] is img_np and self.predictor.is_image_set):
+            for k, v in pf["state"].items():                             # the frame was prefetched: adopt its state
+                setattr(self, k, v)
+        else:
+            self.crop_image(image, crop_box)
+            self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
         t0 = self._tick("set_image", t0)
         H, W = self.image_hw
+        downscale = self.downscale
         orig_h, orig_w = self.orig_image.shape[:2]
         dev = self.device
         prune = math.isfinite(self.filter_thresh)
@@ -285,6 +352,8 @@ class CrowdSAM:
             while count < self.max_prompts and n_batches < max_rounds:
                 tb = time.perf_counter()
                 hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
+                if self.eps_trace is not None:          # debugging / parity aid: the prompts of every round (async copies)
+                    self.eps_trace.append((pts_b.clone(), counts[:1].clone()))
                 bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
                                          device_batch=(pts_b, coords_b, counts[:1]))
                 if prune:
@@ -304,6 +373,8 @@ class CrowdSAM:
                 batch_size = min(len(alive), batch_size)
                 sel_idx, alive = alive[:batch_size], alive[batch_size:]
                 tb = time.perf_counter()
+                if self.eps_trace is not None:
+                    self.eps_trace.append((points[sel_idx].copy(), len(sel_idx)))
                 bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
                 tb = self._tick("eps.batch", tb)
                 if prune and len(alive) > 0:
@@ -320,7 +391,13 @@ class CrowdSAM:
                     self._tick("eps.prune", tb)
                 count += batch_size
                 n_batches += 1
-        self.predictor.reset_image()
+        if self._next_image is not None:
+            # the sweep is queued and nothing below reads the predictor: the next frame's set_image starts now, beside
+            # this frame's tail (it leaves the predictor set for that frame, hence no reset_image here)
+            self._prefetch(self._next_image)
+            self._next_image = None
+        else:
+            self.predictor.reset_image()
         t0 = self._tick("eps_sweep", t0)
         if n_batches == 0:
             return None
@@ -360,8 +437,8 @@ class CrowdSAM:
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
         del data["mask_slots"]
-        data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, self.downscale)
-        data["points"] = utils.uncrop_points(data["points"], crop_box, self.downscale)
+        data["boxes"] = utils.uncrop_boxes_xyxy(data["boxes"], crop_box, downscale)
+        data["points"] = utils.uncrop_points(data["points"], crop_box, downscale)
         data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["boxes"]))]).reshape(-1, 4)
         # build extension: the crop box of every mask survives the cross-crop NMS (the reference keeps only the
         # 2-entries-per-crop ``rles_info`` list, which cannot tell which crop frame an RLE lives in)
@@ -442,7 +519,8 @@ class CrowdSAM:
                                   keep, occ, slot, store["counter"], store, B, edge=edge, n_valid=n_valid)
         # pass 2: mask bytes of the survivors, straight into their store slots
         hip.mask_write(low, sel, keep, B, p.input_size, (H, W), p.model.mask_threshold, store["masks"], tmp, slot=slot)
-        return dict(occ=occ, slot=slot)
+        # keep / score / sel ride along for tests and tracing (device tensors that exist anyway: no extra work)
+        return dict(occ=occ, slot=slot, keep=keep, score=score, sel=sel, inter=inter, union=uni)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

@@ -629,11 +629,9 @@ extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv
   CSAM_REQUIRE(qkv_f16 && qkv_bias && relcat_f16 && out_f16, "csam_win_attn: null pointer");
   CSAM_REQUIRE(nH > 0 && (D == nH * 64 || D == nH * 80), "csam_win_attn: head_dim must be 64 or 80 (D=%d nH=%d)", D, nH);
   if (D == nH * 80) {                                   // ViT-H: relcat is [64, 80]
-    static bool set80 = false;
-    if (!set80) {
+    static csam_once_t set80;
+    if (csam_first_call(set80))
       hipFuncSetAttribute((const void*)win_attn2_hd80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM80_BYTES);
-      set80 = true;
-    }
     hipLaunchKernelGGL(win_attn2_hd80_kernel, dim3(25 * nH), dim3(64 * NW80), SMEM80_BYTES, (hipStream_t)stream,
                        (const half_t*)qkv_f16, qkv_bias, (const half_t*)relcat_f16, (half_t*)out_f16, D, nH, scale);
     CSAM_LAUNCH_CHECK("csam_win_attn");
@@ -643,6 +641,9 @@ extern "C" int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv
   if (version < 0) {
     const char* e = getenv("CSAM_WIN_ATTN");          // 1 = the round-1 kernel (A/B and debugging)
     version = e ? atoi(e) : 2;
+  }
+  static csam_once_t set64;
+  if (csam_first_call(set64)) {
     hipFuncSetAttribute((const void*)win_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipFuncSetAttribute((const void*)win_attn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
   }

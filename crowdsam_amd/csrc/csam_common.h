@@ -45,6 +45,30 @@ void csam_set_error(const char* fmt, ...);
 
 static inline int csam_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// One-time per-DEVICE setup (hipFuncSetAttribute(MaxDynamicSharedMemorySize), CU count): a process may drive more than
+// one GPU through the API (the bench is one process per GPU), so "once" is keyed by hipGetDevice(), not by process.
+//   static csam_once_t once;  if (csam_first_call(once)) hipFuncSetAttribute(...);
+//   const int n_cu = csam_cu_count();
+#define CSAM_MAX_DEVICES 64
+struct csam_once_t { bool done[CSAM_MAX_DEVICES]; };
+static inline bool csam_first_call(csam_once_t& o) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CSAM_MAX_DEVICES) return true;   // unknown: redo the (cheap) setup
+  if (o.done[d]) return false;
+  o.done[d] = true;
+  return true;
+}
+static inline int csam_cu_count() {
+  static int n_cu[CSAM_MAX_DEVICES];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CSAM_MAX_DEVICES) d = 0;
+  if (n_cu[d] == 0) {
+    hipDeviceProp_t prop;
+    n_cu[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n_cu[d];
+}
+
 // activation ids shared by the GEMM epilogues (include/csam.h: CSAM_ACT_*)
 #define CSAM_ACT_NONE 0
 #define CSAM_ACT_GELU 1

@@ -711,11 +711,9 @@ extern "C" int csam_pool_adjoint(void* stream, const float* masks, const float* 
                                  void* w_f16, long ldw, int rows) {
   CSAM_REQUIRE(masks && stats && taps_dev && w_f16 && rows > 0 && ldw >= 5329, "csam_pool_adjoint: bad args");
   const int smem = 256 * 73 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set))
     hipFuncSetAttribute((const void*)pool_adjoint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(pool_adjoint_kernel, dim3(rows), dim3(256), smem, (hipStream_t)stream, masks, stats,
                      (const AdjTaps*)taps_dev, (half_t*)w_f16, ldw);
   CSAM_LAUNCH_CHECK("csam_pool_adjoint");
@@ -727,11 +725,9 @@ extern "C" int csam_pool_adjoint_v2(void* stream, const float* masks, float* sta
                                     long ldw, int rows) {
   CSAM_REQUIRE(masks && stats && taps_dev && w_f16 && rows > 0 && ldw >= 5329, "csam_pool_adjoint_v2: bad args");
   const int smem = 256 * 73 * 4 + 4 * 256 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set))
     hipFuncSetAttribute((const void*)pool_adjoint_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(pool_adjoint_v2_kernel, dim3(rows), dim3(256), smem, (hipStream_t)stream, masks, stats,
                      (const AdjTaps*)taps_dev, (half_t*)w_f16, ldw);
   CSAM_LAUNCH_CHECK("csam_pool_adjoint_v2");

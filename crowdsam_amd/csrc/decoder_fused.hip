@@ -312,11 +312,10 @@ extern "C" int csam_i2t_fused(void* stream, const void* X_f16, long x_prompt_str
   a.kv_k = (const half_t*)k_f16; a.kv_v = (const half_t*)v_f16;
   a.Wo = (const half_t*)Wo_perm_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set)) {
     hipFuncSetAttribute((const void*)i2t_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
     hipFuncSetAttribute((const void*)i2t_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, I2T_SMEM);
-    attr_set = true;
   }
   dim3 grid(T / I2T_TOK, B);
   if (Wq_f16)
@@ -650,11 +649,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
 template <int QMODE, int NW, int MI_>
 static void i2t_stream_launch(const I2tArgs& a, int B, int n_cu, hipStream_t stream) {
   typedef I2S<NW, MI_> G;
-  static bool set = false;
-  if (!set) {
+  static csam_once_t set;
+  if (csam_first_call(set))
     hipFuncSetAttribute((const void*)i2t_stream_kernel<QMODE, NW, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
-    set = true;
-  }
   const int n_tiles = B * (a.T / G::TOK);
   const int slots = n_cu * (8 / NW);                  // resident workgroups
   const int per = csam_cdiv(n_tiles, slots);
@@ -677,12 +674,10 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
   a.kv_k = (const half_t*)k_scaled_f16; a.kv_v = (const half_t*)v_f16;
   a.Wo = (const half_t*)Wo_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
-  static int n_cu = 0, nw_q = 4, nw_p = 4;
-  if (!n_cu) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  const int n_cu = csam_cu_count();
+  static int nw_q = 0, nw_p = 4;
+  if (!nw_q) {
+    nw_q = 4;
     const char* e = getenv("CSAM_I2T_NW");            // "<hoisted-Q form><projected form>", e.g. 48
     if (e && (e[0] == '4' || e[0] == '8' || e[0] == '2')) nw_q = e[0] - '0';   // '2' = 4 waves, 32-token tiles
     if (e && e[0] && (e[1] == '4' || e[1] == '8')) nw_p = e[1] - '0';
@@ -985,12 +980,9 @@ extern "C" long csam_i2t_rank_workspace_bytes(int B) { return (long)B * 256 * 64
 extern "C" long csam_i2t_rank_proj_workspace_bytes(int B) { return (long)B * (IR_M_BYTES + IR_KP_BYTES); }
 
 static int ir_cus() {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static csam_once_t once;
+  const int n_cu = csam_cu_count();
+  if (csam_first_call(once)) {
     constexpr int s0 = IR<false, 4>::SMEM, s1 = IR<true, 8>::SMEM, s2 = IR<false, 8>::SMEM;
     (void)hipFuncSetAttribute((const void*)i2t_rank_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, s0);
     (void)hipFuncSetAttribute((const void*)i2t_rank_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, s2);
@@ -1380,6 +1372,22 @@ namespace {
 #ifndef CSAM_UP_XDEPTH
 #define CSAM_UP_XDEPTH 3
 #endif
+// developer A/B (CSAM_DEFS_decoder_fused=-DCSAM_UP_PRIO=n): wave priority by phase.  1: the MFMA groups (both convs) run at
+// s_setprio 2 and the LayerNorm / GELU streams at 0, so the co-resident wave's matrix work is issued the moment it is ready
+// and the VALU stream fills what is left; 2: the inverse.  Measured: profiles/r04_upscale_prio.txt
+#ifndef CSAM_UP_PRIO
+#define CSAM_UP_PRIO 0
+#endif
+#if CSAM_UP_PRIO == 1
+#define UP_PRIO_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(2); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define UP_PRIO_V() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif CSAM_UP_PRIO == 2
+#define UP_PRIO_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define UP_PRIO_V() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(2); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define UP_PRIO_M() do { } while (0)
+#define UP_PRIO_V() do { } while (0)
+#endif
 constexpr int US_TOK = 32;
 constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
 constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
@@ -1434,6 +1442,9 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
     for (int i = 0; i < 4; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
   };
 
+#if CSAM_UP_PRIO == 3   /* static priority by dispatch round: the two workgroups of a CU stop competing symmetrically */
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(2);
+#endif
   half8_t hhi, hlo;
   float pmax0 = -INFINITY, pmax1 = -INFINITY;        // running max of the planes this thread stores (l0, l0 + 2)
   issue_x(first, 0);
@@ -1478,6 +1489,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
 #ifndef CSAM_UP_NOG1
+      UP_PRIO_M();
       {
         constexpr int XD = CSAM_UP_XDEPTH;              // fragment sets in flight
         half8_t xf[XD];
@@ -1503,6 +1515,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
       asm volatile("" ::"v"(w1[0][0]), "v"(w1[3][7]), "v"(xb));
 #endif
 #endif
+      UP_PRIO_V();
       // LayerNorm2d statistics over the 64 channels of a pixel: in-lane partial sums (16 channels, packed), the
       // four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)
       float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
@@ -1555,6 +1568,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         a2[0][n2] = b2v;
         a2[1][n2] = b2v;
       }
+      UP_PRIO_M();
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -1565,6 +1579,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
           a2[1][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[1][s2], a2[1][n2], 0, 0, 0);
         }
       }
+      UP_PRIO_V();
 #pragma unroll
       for (int p2 = 0; p2 < 2; ++p2) {
         const int pos2 = ph * 2 + p2;
@@ -1662,6 +1677,9 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   if (abl < 0) {
     const char* e = getenv("CSAM_DBG");
     abl = e ? atoi(e) : 0;
+  }
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set)) {
     hipFuncSetAttribute((const void*)upscale_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
     hipFuncSetAttribute((const void*)upscale_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
     hipFuncSetAttribute((const void*)upscale_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
@@ -1682,14 +1700,10 @@ extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const voi
   a.X = (const half_t*)keys_f16; a.W1 = (const half_t*)W1_f16; a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta;
   a.eps = eps; a.W2 = (const half_t*)W2_perm_f16; a.b2 = b2; a.hyper = hyper; a.masks = masks;
   a.stats = stats_or_null;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static csam_once_t once;
+  const int n_cu = csam_cu_count();
+  if (csam_first_call(once))
     (void)hipFuncSetAttribute((const void*)upscale_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, US_SMEM);
-  }
   const int per = csam_cdiv(B, 2 * n_cu);
   hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
   CSAM_LAUNCH_CHECK("csam_upscale_stream");
@@ -2219,13 +2233,7 @@ extern "C" int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_
   T2sArgs a;
   a.X = (const half_t*)X_f16; a.Wkv = (const half_t*)Wkv_f16; a.kpe = kpe; a.bv = bv;
   a.q = (const half_t*)q_f16; a.out = (half_t*)out_f16; a.B = B; a.T = T;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = csam_cu_count();
   const int per = csam_cdiv(B, 2 * n_cu);           // whole prompts per workgroup, two workgroups per CU
   hipLaunchKernelGGL(t2i_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), T2S_SMEM, (hipStream_t)stream, a, per);
   CSAM_LAUNCH_CHECK("csam_t2i_stream");
@@ -2457,13 +2465,7 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
     csam_set_error("csam_t2i_rank: workspace too small (%ld < %ld)", workspace_bytes, (long)B * 64 * 256 * 2);
     return CSAM_ERR_WORKSPACE;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = csam_cu_count();
   hipLaunchKernelGGL(t2i_rank_prep_kernel, dim3(B < 2 * n_cu ? B : 2 * n_cu), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)qs_f16, (const half_t*)Wk_f16, (half_t*)Qp_workspace, B);
   T2rArgs a;
@@ -2911,12 +2913,9 @@ extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_strid
     csam_set_error("csam_i2t_t2i: workspace too small");
     return CSAM_ERR_WORKSPACE;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static csam_once_t once;
+  const int n_cu = csam_cu_count();
+  if (csam_first_call(once)) {
     (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<false>::SMEM);
     (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
   }
@@ -2964,11 +2963,10 @@ extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f
   a.X = (const half_t*)X_f16; a.Wkv = (const half_t*)Wkv_f16; a.kpe = kpe; a.bv = bv;
   a.K0 = (const half_t*)K0_f16; a.V0T = (const half_t*)V0T_f16; a.q = (const half_t*)q_f16;
   a.part = (float*)workspace;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set)) {
     hipFuncSetAttribute((const void*)t2i_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_SMEM);
     hipFuncSetAttribute((const void*)t2i_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_SMEM);
-    attr_set = true;
   }
   dim3 grid(T2I_PARTS, B);
   if (X_f16)

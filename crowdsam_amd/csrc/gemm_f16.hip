@@ -466,8 +466,10 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   if (use256 < 0) {
     const char* e = getenv("CSAM_GEMM_256");
     use256 = e ? atoi(e) : 1;
-    hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
   }
+  static csam_once_t set256;
+  if (csam_first_call(set256))
+    hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
   if (use256 && batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 &&
       (N / 256) * csam_cdiv(M, 256) <= 256 && K >= 64) {
     dim3 g256((N / 256) * csam_cdiv(M, 256));
@@ -481,12 +483,10 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
     constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
     constexpr int SM = SM_RING > SM_OUT ? SM_RING : SM_OUT;                                                    \
-    static bool set = false;                                                                                   \
+    static csam_once_t set;                                                                                    \
     auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
-    if (!set) {                                                                                                \
+    if (csam_first_call(set))                                                                                  \
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
-      set = true;                                                                                              \
-    }                                                                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
   }
   if (mid) {

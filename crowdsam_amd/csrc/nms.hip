@@ -337,11 +337,10 @@ extern "C" int csam_box_nms(void* stream, const float* boxes, const float* score
   while (NP < N) NP <<= 1;
   uint64_t* mask = (uint64_t*)workspace;
   int* order = (int*)((char*)workspace + (long)N * nw * sizeof(uint64_t));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set)) {
     hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX * 8);
     hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
-    attr_set = true;
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), NP * 8, s, scores, N, NP, order);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s, boxes, order, N, nw, thr, mask);
@@ -374,11 +373,10 @@ extern "C" int csam_mask_nms(void* stream, const void* masks_u8, const float* sc
   w += (long)N * nw * 8;
   int* order = (int*)w;
   int* area = order + N;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static csam_once_t attr_set;
+  if (csam_first_call(attr_set)) {
     hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX * 8);
     hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 8);
-    attr_set = true;
   }
   hipLaunchKernelGGL(mask_pack_kernel, dim3(N), dim3(256), 0, s, (const uint8_t*)masks_u8, H, W, packed, area);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), NP * 8, s, scores, N, NP, order);

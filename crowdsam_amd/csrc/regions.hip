@@ -1083,11 +1083,10 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
   unsigned short* R16 = (unsigned short*)w; w += align256((long)n * tiles * 4096 * 2);
   RegionMeta* meta = (RegionMeta*)w; w += align256((long)2 * n * sizeof(RegionMeta));
   int* ext = (int*)w;
-  static bool attr = false;
-  if (!attr) {
+  static csam_once_t attr;
+  if (csam_first_call(attr)) {
     (void)hipFuncSetAttribute((const void*)cc2_scan_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
     (void)hipFuncSetAttribute((const void*)cc2_scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
-    attr = true;
   }
   const dim3 block(256), tgrid(tiles, n), bgrid(csam_cdiv(2 * tiles, 4), n), sgrid((unsigned)csam_cdiv(slots, 256));
   const dim3 mgrid(std::min(16, std::max(1, tiles / 4)), n);

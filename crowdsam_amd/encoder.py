@@ -79,7 +79,9 @@ class EncoderPlan:
             n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
             col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32),
             img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32))
-        if not self.fused_attn:
+        # workspaces of the materialised route: only when a block can actually take it (head_dim 80 runs the two
+        # head_dim-80 kernels unless CSAM_WIN_HD80=0; ~1.6 GB for ViT-H otherwise never touched)
+        if not self.fused_attn and not (self.fused_win and hd == 80):
             gmax = max(heads * 25 * 256, heads * 4096 if self.global_idx else 0)        # group rows, windowed vs global
             smax = max(heads * 25 * 256 * 256, heads * 4096 * 4096 if self.global_idx else 0)
             self.ws.update(gq=e(gmax, 128), gk=e(gmax, 128), gvt=e(gmax * 128), go=e(gmax, 128),

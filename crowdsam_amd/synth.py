@@ -173,6 +173,24 @@ def make_sam_state_dict(arch="vit_l", n_class=1, seed=0):
     return make_state_dict(sam_param_specs(D, depth, heads, gidx, n_class), seed)
 
 
+def shipped_scale_heads(sd, logit_gain=30.0, iou_shift=-0.2, cls_shift=2.0):
+    """Seeded random weights whose decision values straddle the SHIPPED thresholds of configs/crowdhuman.yaml:43-58.
+    With plain random weights the shipped test block is degenerate (stability 0.001-0.4 against 0.8: no mask survives;
+    fused scores 0.3-0.6 against filter_thresh 0.7: nothing prunes).  Three head constants are moved IN PLACE so that every
+    shipped threshold is an active decision boundary on the same architecture: the last layer of the four used
+    hyper-MLPs x logit_gain (mask logits x 30 -> stability 0.80-0.97), the IoU head's output bias + iou_shift and the
+    point classifier's output bias + cls_shift (fused scores 0.45-0.95 around 0.7; the FG prior moves with the
+    classifier, 0.28-0.99 around pos_sim_thresh 0.5).  Used by the shipped-scale EPS golden
+    (oracle/make_goldens.py::golden_pipeline_eps_shipped) and its GPU test; returns sd."""
+    M = "mask_decoder."
+    for i in range(4):
+        sd[f"{M}output_hypernetworks_mlps.{i}.layers.2.weight"] *= logit_gain
+        sd[f"{M}output_hypernetworks_mlps.{i}.layers.2.bias"] *= logit_gain
+    sd[M + "iou_prediction_head.layers.2.bias"] += iou_shift
+    sd[M + "point_classifier.layers.1.bias"] += cls_shift
+    return sd
+
+
 def make_dino_state_dict(embed_dim=1024, depth=24, seed=1):
     return make_state_dict(dino_param_specs(embed_dim, depth), seed)
 

@@ -312,7 +312,8 @@ int csam_box_nms(void* stream, const float* boxes, const float* scores, int N, f
 long csam_mask_nms_workspace_bytes(int N);
 int csam_mask_nms(void* stream, const void* masks_u8, const float* scores, int N, int H, int W, float thr,
                   long* out_keep, int* out_count, void* workspace, long workspace_bytes);
-/* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes */
+/* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes.  masks_u8 must hold strict 0 / 1 bytes
+ * (what csam_mask_write produces and what a torch.bool tensor is): the W % 4 == 0 kernels compare bit 0 of packed bytes. */
 int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals);
 int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
                    const long* mask_offsets, uint32_t* out_positions);

@@ -295,6 +295,117 @@ def golden_pipeline(fuse=False):
     print("pipeline", name, {k: v.shape for k, v in res.items()}, out["scores"][:5])
 
 
+EPS_SHIPPED_FRAGILE = 1.0      # |max logit over the passing masks at a list point| below this goes into the fragile list
+
+
+def golden_pipeline_eps_shipped():
+    """The reference's own CrowdSAM.generate with the SHIPPED test block (configs/crowdhuman.yaml:33-58 unchanged: grid
+    192, max_prompts 500, 32 prompts per batch, filter_thresh 0.7, pos_sim_thresh 0.5, stability 0.8 / offset 1,
+    pred_iou 0.1, box NMS 0.65, min region 100) on the vit_test128 encoder: 16 sequential pruned batches
+    (crowdsam/model.py:226-248).  Random weights make those thresholds degenerate, so the decoder heads are the
+    calibrated seeded variant synth.shipped_scale_heads (documented there); nothing else differs from a shipped run.
+    The reference is instrumented from outside (np.random.shuffle, predictor.predict_torch and the instance's
+    _process_batch are wrapped; no reference source is edited) to record, per batch: the prompt list, every prompt's
+    PWD-Net choice / fused score / top-2 margin / stability, who survives the filters, who feeds the occupancy mask, the
+    occupancy decision of EVERY point of the shuffled list and -- sparse -- the decision margins (max logit over the
+    feeding masks at the point) below EPS_SHIPPED_FRAGILE.  The chain is re-simulated from those records and asserted to
+    reproduce the reference's own batches before anything is written."""
+    import importlib
+    _install_shims()
+    _, build, amg = ref_import.load_modeling()
+    predictor_mod = importlib.import_module("segment_anything_cs.predictor")
+    sys.path.insert(0, ref_import.REF)
+    model_mod = importlib.import_module("crowdsam.model")
+    sys.path.remove(ref_import.REF)
+    D, depth, heads, gidx = synth.SAM_CONFIGS[TEST_ARCH]
+    sam = build._build_sam(D, depth, heads, 1, list(gidx))
+    sam.load_state_dict(synth.shipped_scale_heads(synth.make_sam_state_dict(TEST_ARCH)), strict=True)
+    sam.eval()
+    predictor = predictor_mod.SamPredictor(sam, StandInDino())
+    cs = object.__new__(model_mod.CrowdSAM)
+    cfg = dict(po.DEFAULT_TEST_CFG)            # == the shipped test: block
+    cs.device, cs.train_free, cs.predictor = torch.device("cpu"), False, predictor
+    for k, v in cfg.items():
+        setattr(cs, k, v)
+    rec = {"batches": []}
+    orig_shuffle, orig_predict = np.random.shuffle, predictor.predict_torch
+
+    def shuffle(a):
+        orig_shuffle(a)
+        rec["list"] = a.copy()
+
+    def predict_torch(*a, **k):
+        out = orig_predict(*a, **k)
+        rec["cur"] = out[:3]
+        return out
+
+    def process_batch(points, im_size, crop_box):
+        data = model_mod.CrowdSAM._process_batch(cs, points, im_size, crop_box)
+        masks, iou, cls = rec.pop("cur")
+        L = rec["list"]
+        B = len(points)
+        fused = torch.clamp(iou, 0.) * cls.squeeze(2).sigmoid()
+        srt = fused.sort(dim=-1, descending=True)[0]
+        sel = fused.max(dim=-1)[1]
+        sl = masks[torch.arange(B), sel]                                   # [B, H, W] logits of the chosen candidates
+        inter = (sl > 1.0).flatten(1).sum(-1).int()
+        union = (sl > -1.0).flatten(1).sum(-1).int()
+        surv_pts = {tuple(int(v) for v in p) for p in data["points"].numpy()}
+        assert len({tuple(p) for p in points.tolist()}) == B              # prompts of a batch are distinct pixels
+        survive = np.array([tuple(int(v) for v in p) in surv_pts for p in points], dtype=bool)
+        score = fused[torch.arange(B), sel]
+        feeds = torch.as_tensor(survive) & (score > cs.filter_thresh)
+        G = sl[:, L[:, 1], L[:, 0]]                                        # [B, P] chosen-candidate logits at every list point
+        m = G[feeds].max(0)[0] if bool(feeds.any()) else torch.full((len(L),), -1e30)
+        occ = (m > 0).numpy()
+        ref_occ = (data["masks"][data["iou_preds"] > cs.filter_thresh]).any(0)[L[:, 1], L[:, 0]].numpy()   # :246
+        assert np.array_equal(occ, ref_occ)
+        assert int(survive.sum()) == len(data["points"]) and int(feeds.sum()) == int((data["iou_preds"] > cs.filter_thresh).sum())
+        rec["batches"].append(dict(points=np.array(points), sel=sel.numpy(), score=score.numpy(),
+                                   top2=(srt[:, 0] - srt[:, 1]).numpy(), inter=inter.numpy(), union=union.numpy(),
+                                   survive=survive, feeds=feeds.numpy(), occ=occ, margin=m.numpy()))
+        print("  batch %2d: %2d survive, %2d feed the occupancy (%.3f of the list points)"
+              % (len(rec["batches"]), survive.sum(), int(feeds.sum()), occ.mean()), flush=True)
+        return data
+
+    np.random.shuffle, predictor.predict_torch, cs._process_batch = shuffle, predict_torch, process_batch
+    np.random.seed(42)
+    try:
+        with torch.no_grad():
+            out = cs.generate(pipeline_image())
+    finally:
+        np.random.shuffle = orig_shuffle
+    L, bt = rec["list"], rec["batches"]
+    # re-simulate the sampler from the records: must reproduce the reference's own batches (crowdsam/model.py:229-240)
+    alive, alive_after, last_pos = np.arange(len(L)), [], 0
+    for b in bt:
+        n = len(b["points"])
+        assert np.array_equal(L[alive[:n]], b["points"])
+        last_pos = int(alive[n - 1])
+        alive = alive[n:]
+        alive = alive[~b["occ"][alive]]
+        alive_after.append(len(alive))
+    nb = len(bt)
+    assert nb == 16 and all(len(b["points"]) == 32 for b in bt), [len(b["points"]) for b in bt]
+    fb, fp, fm = [], [], []
+    for i, b in enumerate(bt):
+        idx = np.nonzero(np.abs(b["margin"]) < EPS_SHIPPED_FRAGILE)[0]
+        fb.append(np.full(len(idx), i, np.int8)), fp.append(idx.astype(np.int32)), fm.append(b["margin"][idx].astype(np.float32))
+    st = lambda k, dt: np.stack([b[k] for b in bt]).astype(dt)
+    res = {k: out[k] for k in ("boxes", "scores", "categories", "points", "stability_score")}
+    np.savez_compressed(
+        os.path.join(OUT, "pipeline_eps_shipped.npz"), list=L.astype(np.int16), batch_points=st("points", np.int16),
+        sel=st("sel", np.int8), score=st("score", np.float32), top2=st("top2", np.float32), inter=st("inter", np.int32),
+        union=st("union", np.int32), survive=st("survive", np.uint8), feeds=st("feeds", np.uint8),
+        occ_bits=np.stack([np.packbits(b["occ"]) for b in bt]), alive_after=np.array(alive_after, np.int32),
+        last_pos=np.int32(last_pos), fragile_batch=np.concatenate(fb), fragile_point=np.concatenate(fp),
+        fragile_margin=np.concatenate(fm), fragile_below=np.float32(EPS_SHIPPED_FRAGILE),
+        rle_counts=np.array([r["counts"] for r in out["rles"]], dtype=object), **res)
+    print("pipeline_eps_shipped: %d list points, alive after each batch %s, last list position consumed %d, %d fragile "
+          "records, kept %s" % (len(L), alive_after, last_pos, sum(len(x) for x in fp), res["boxes"].shape))
+
+
+
 VITB_CFG = dict(grid_size=8, pos_sim_thresh=-1.0, points_per_batch=32, max_prompts=500, pred_iou_thresh=-1e9,
                 stability_score_thresh=0.0, min_mask_region_area=0, box_nms_thresh=1.0, crop_nms_thresh=1.0)
 
@@ -331,6 +442,8 @@ def golden_pipeline_vitb():
     # random-weight ViT-B masks are noise-like (1e4+ runs each): keep the run COUNT and the mask area per mask only
     dec = [po.coco_rle_decode(r["counts"], *r["size"]) for r in out["rles"]]
     res["mask_area"] = np.array([int(d.sum()) for d in dec], dtype=np.int64)
+    # ... and every 8th pixel of every 8th row of each mask (128 x 128 bits per mask): a pixel-level sample of the masks
+    res["mask_sample"] = np.packbits(np.stack([np.asarray(d)[::8, ::8].astype(bool) for d in dec]))
     np.savez_compressed(os.path.join(OUT, "pipeline_vit_b_512.npz"), **res)
     print("pipeline_vitb", {k: v.shape for k, v in res.items()}, out["scores"][:8], out["boxes"][:3])
 

@@ -161,7 +161,14 @@ def mask_to_rle_arrays(tensor, idx=None):
     if b == 0:
         return []
     if tensor.is_cuda:
-        m8 = (tensor.view(torch.uint8) if tensor.dtype == torch.bool else tensor.to(torch.uint8)).contiguous()
+        # the kernels require strict 0 / 1 bytes (include/csam.h): a bool tensor is that already, as is the driver's uint8
+        # mask store (written by csam_mask_write); anything else is normalised with != 0 first
+        if tensor.dtype == torch.bool:
+            m8 = tensor.view(torch.uint8).contiguous()
+        elif tensor.dtype == torch.uint8 and idx is not None:
+            m8 = tensor.contiguous()
+        else:
+            m8 = (tensor != 0).view(torch.uint8).contiguous()
         pos, offs = hip.rle_encode(m8, idx)
         pos = pos.cpu().numpy().astype(np.int64)
         first = (m8[:, 0, 0] if idx is None else m8[idx.long(), 0, 0]).cpu().numpy().astype(bool)

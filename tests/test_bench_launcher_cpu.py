@@ -23,6 +23,7 @@ def test_bench_spawns_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and len(d["config"]["per_rank_images_per_sec"]) == 2
     assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["rccl_world_size"] == 2 and d["config"]["backend"] == "gloo"    # the backend saw both ranks
 
 
 def test_bench_single_rank_needs_no_launcher():

@@ -1,0 +1,159 @@
+"""The Efficient Prompt Sampler at the SHIPPED scale against the reference's own run (crowdsam/model.py:226-248 with
+configs/crowdhuman.yaml:33-58 unchanged: grid 192, max_prompts 500, 32 prompts per batch, filter_thresh 0.7 -- 16
+sequential pruned batches; fixture tests/golden/pipeline_eps_shipped.npz from oracle/make_goldens.py, weights =
+synth.shipped_scale_heads so the shipped thresholds are live decision boundaries).
+
+Two views of the same chain:
+* teacher-forced: every batch gets the REFERENCE's prompt list, so one flipped pixel cannot snowball; the per-prompt choices
+  and the occupancy decision of every one of the 27 418 list points are compared per batch, and every disagreement must
+  sit inside the recorded decision margin;
+* free-running: CrowdSAM.generate with the device-resident sampler, per-batch prompt lists (eps_trace) against the
+  reference's; the first divergent batch is reported and must be explained by a recorded fragile decision."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+# tolerances = measured on MI355X (printed by the test) x 2.5
+SCORE_ATOL = 1.35e-2       # fused score at logits x 30 (the softmax-pooled classifier input is peaked): measured 5.4e-3
+STAB_ATOL = 2.5e-3         # stability = inter / union of a 768 x 1024 mask: measured 9.9e-4
+MARGIN_TOL = 0.15          # |max logit over the feeding masks| below which an occupancy flip is legitimate: measured 0.058
+                           # mean |logit| ~ 8, fp16-operand error of the low-res logits ~ 0.1 % of that, x 4 bilinear)
+
+
+def _model(cuda):
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.pipeline_oracle import DEFAULT_TEST_CFG
+    from tests.test_pipeline_gpu import ARCH, GpuStandInDino, _config
+    sd = synth.shipped_scale_heads(synth.make_sam_state_dict(ARCH))
+    return CrowdSAM(_config(dict(DEFAULT_TEST_CFG)), sam_state_dict=sd, dino_model=GpuStandInDino(cuda))
+
+
+def test_shipped_chain_teacher_forced_vs_reference_golden(cuda):
+    from crowdsam_amd import hip
+    from oracle.make_goldens import pipeline_image
+    g = np.load(os.path.join(G, "pipeline_eps_shipped.npz"), allow_pickle=True)
+    m = _model(cuda)
+    img = pipeline_image()
+    H0, W0 = img.shape[:2]
+    crop_box = [0, 0, W0, H0]
+    m.crop_image(img, crop_box)
+    m.predictor.set_image(m._frame_u8 if m._frame_f32 is None else (m._frame_u8, m._frame_f32))
+    H, W = m.image_hw
+    # the FG prior's point set at pos_sim_thresh 0.5 (crowdsam/model.py:196-223): the reference's list as a set
+    L = g["list"].astype(np.int64)
+    pts = m.sample_prompts(on_device=False).astype("int")
+    a = {tuple(p) for p in pts.tolist()}
+    b = {tuple(p) for p in L.tolist()}
+    print("FG prior points: hip %d, reference %d, symmetric difference %d" % (len(a), len(b), len(a ^ b)))
+    assert len(a ^ b) <= 0.002 * len(b)                  # prior values within fp16 tolerance of 0.5 may fall either way
+    store = m._result_store(*m.predictor.original_size)
+    store["counter"].zero_()
+    all_pts = torch.as_tensor(L, dtype=torch.int32).to(cuda)
+    bits = torch.empty(len(L), dtype=torch.uint8, device=cuda)
+    fb, fp, fm = g["fragile_batch"], g["fragile_point"], g["fragile_margin"]
+    nb = len(g["batch_points"])
+    worst = dict(score=0.0, stab=0.0, margin=0.0)
+    bad = []                 # violations are collected so that one run prints every measurement; asserted at the end
+    tot_flip = tot_sel = tot_surv = tot_feed = 0
+    for bi in range(nb):
+        P = g["batch_points"][bi].astype(np.int64)
+        bd = m._process_batch(P, m.predictor.original_size, crop_box, store)
+        hip.occupancy_lookup(all_pts, store["masks"], bd["occ"], len(P), H, W, bits, slot=bd["slot"])
+        occ = bits.cpu().numpy().astype(bool)
+        sel, score = bd["sel"].cpu().numpy(), bd["score"].cpu().numpy()
+        keep, feeds = bd["keep"].cpu().numpy().astype(bool), bd["occ"].cpu().numpy().astype(bool)
+        inter, union = bd["inter"].cpu().numpy(), bd["union"].cpu().numpy()
+        # PWD-Net choice: equal wherever the reference's top-2 margin exceeds twice the score tolerance
+        clear = g["top2"][bi] > 2 * SCORE_ATOL
+        if not np.array_equal(sel[clear], g["sel"][bi][clear]):
+            bad.append("batch %d: PWD-Net choice differs outside the top-2 margin" % bi)
+        same = sel == g["sel"][bi]
+        tot_sel += int((~same).sum())
+        worst["score"] = max(worst["score"], float(np.abs(score - g["score"][bi])[same].max()))
+        if np.abs(score - g["score"][bi])[same].max() > SCORE_ATOL:
+            bad.append("batch %d: score error %.3e" % (bi, np.abs(score - g["score"][bi])[same].max()))
+        rstab = g["inter"][bi] / np.maximum(g["union"][bi], 1)
+        # survivors of the predicted-IoU + stability filters, occupancy feeders: equal outside the margins
+        stab = inter / np.maximum(union, 1)
+        live = same & (score > m.pred_iou_thresh)        # statistics exist only for prompts past the score filter
+        worst["stab"] = max(worst["stab"], float(np.abs(stab - rstab)[live].max()))
+        if np.abs(stab - rstab)[live].max() > STAB_ATOL:
+            bad.append("batch %d: stability error %.3e" % (bi, np.abs(stab - rstab)[live].max()))
+        firm = same & (np.abs(rstab - m.stability_score_thresh) > STAB_ATOL) & \
+            (np.abs(g["score"][bi] - m.pred_iou_thresh) > SCORE_ATOL)
+        if not np.array_equal(keep[firm], g["survive"][bi].astype(bool)[firm]):
+            bad.append("batch %d: survivors differ outside the margins" % bi)
+        firm_f = firm & (np.abs(g["score"][bi] - m.filter_thresh) > SCORE_ATOL)
+        if not np.array_equal(feeds[firm_f], g["feeds"][bi].astype(bool)[firm_f]):
+            bad.append("batch %d: occupancy feeders differ outside the margins" % bi)
+        tot_surv += int((keep != g["survive"][bi].astype(bool)).sum())
+        tot_feed += int((feeds != g["feeds"][bi].astype(bool)).sum())
+        # occupancy decision of EVERY list point (crowdsam/model.py:238-246)
+        ref_occ = np.unpackbits(g["occ_bits"][bi])[: len(L)].astype(bool)
+        diff = np.nonzero(occ != ref_occ)[0]
+        tot_flip += len(diff)
+        if np.array_equal(feeds, g["feeds"][bi].astype(bool)):
+            # same feeding masks: a flipped point must be a recorded fragile one, inside the margin tolerance
+            rec = {int(p): float(v) for p, v in zip(fp[fb == bi], fm[fb == bi])}
+            marg = [abs(rec.get(int(p), 1e9)) for p in diff]
+            if marg:
+                worst["margin"] = max(worst["margin"], max(marg))
+            if not all(v < MARGIN_TOL for v in marg):
+                bad.append("batch %d: occupancy flips outside the margin tolerance: %s" % (bi, sorted(marg)[-3:]))
+        print("batch %2d: %d choice / %d survivor / %d feeder differences (all inside their margins), %d of %d occupancy "
+              "decisions flipped" % (bi + 1, int((~same).sum()), int((keep != g["survive"][bi].astype(bool)).sum()),
+                                     int((feeds != g["feeds"][bi].astype(bool)).sum()), len(diff), len(L)))
+    print("teacher-forced chain: worst score error %.2e, stability error %.2e, largest margin of a flipped occupancy "
+          "decision %.3f; totals: %d choices, %d survivors, %d feeders, %d occupancy bits of %d"
+          % (worst["score"], worst["stab"], worst["margin"], tot_sel, tot_surv, tot_feed, tot_flip, nb * len(L)))
+    assert not bad, bad
+    assert tot_flip <= 2e-3 * nb * len(L)
+
+
+def test_shipped_chain_free_running_vs_reference_golden(cuda):
+    from oracle.make_goldens import pipeline_image
+    g = np.load(os.path.join(G, "pipeline_eps_shipped.npz"), allow_pickle=True)
+    m = _model(cuda)
+    assert m.eps_on_device
+    m.eps_trace = []
+    np.random.seed(42)
+    out = m.generate(pipeline_image())
+    trace = [(p.cpu().numpy().astype(np.int64), int(n.item())) for p, n in m.eps_trace]
+    m.eps_trace = None
+    L = g["list"].astype(np.int64)
+    pos = {tuple(p): i for i, p in enumerate(L.tolist())}
+    fb, fp, fm = g["fragile_batch"], g["fragile_point"], g["fragile_margin"]
+    nb = len(g["batch_points"])
+    assert len(trace) == nb, (len(trace), nb)
+    first = None
+    for bi in range(nb):
+        pts, nv = trace[bi]
+        ref = g["batch_points"][bi].astype(np.int64)
+        if nv == len(ref) and np.array_equal(pts[:nv], ref):
+            continue
+        first = bi
+        # the first list entry one side prompts and the other does not: its pruning decision flipped in an earlier batch
+        k = next(i for i in range(min(nv, len(ref))) if not np.array_equal(pts[i], ref[i]))
+        qa, qb = pos.get(tuple(pts[k].tolist())), pos[tuple(ref[k].tolist())]
+        q = min(x for x in (qa, qb) if x is not None)
+        hit = (fp == q) & (fb < bi) & (np.abs(fm) < MARGIN_TOL)
+        near_score = [float(np.abs(g["score"][j] - 0.7).min()) for j in range(bi)]
+        print("first divergent batch %d of %d at slot %d: list position %d; fragile records of that point in earlier "
+              "batches: %s; smallest |score - filter_thresh| of earlier batches %.2e"
+              % (bi + 1, nb, k, q, list(zip(fb[hit].tolist(), fm[hit].tolist())), min(near_score)))
+        assert hit.any() or min(near_score) < SCORE_ATOL, "divergence not explained by a recorded fragile decision"
+        break
+    if first is None:
+        print("all %d batches prompt the reference's points in the reference's order" % nb)
+        # then the frame-level result is the reference's too
+        assert out["boxes"].shape == g["boxes"].shape
+        np.testing.assert_array_equal(out["points"], g["points"])
+        np.testing.assert_allclose(out["scores"], g["scores"], rtol=0, atol=SCORE_ATOL)
+    # the chain before the divergence is the reference's, prompt for prompt
+    assert first is None or first >= 1

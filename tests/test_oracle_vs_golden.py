@@ -121,6 +121,27 @@ def test_full_pipeline_fuse_simmap_matches_reference(sd):
     np.testing.assert_allclose(out["scores"], g["scores"], rtol=1e-5, atol=1e-6)
 
 
+def test_shipped_scale_eps_chain_matches_reference():
+    """The first 4 of the 16 pruned batches of the reference's shipped-scale run (tests/golden/pipeline_eps_shipped.npz;
+    crowdsam/model.py:226-248, grid 192, 32 prompts per batch, filter_thresh 0.7): the oracle prompts the same points in
+    the same order, i.e. its FG prior set, shuffle, selection, filters and occupancy pruning are the reference's."""
+    from oracle.make_goldens import StandInDino, pipeline_image
+    g = _load("pipeline_eps_shipped.npz")
+    D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
+    sd2 = synth.shipped_scale_heads(synth.make_sam_state_dict(ARCH))
+    rec = {}
+    np.random.seed(42)
+    o = po.OracleCrowdSAM(sd2, (depth, heads, gidx), StandInDino(), dict(max_prompts=128), rng=np.random, record=rec)
+    with torch.no_grad():
+        o.generate(pipeline_image())
+    assert len(rec["batches"]) == 4
+    for i, b in enumerate(rec["batches"]):
+        np.testing.assert_array_equal(b["points"], g["batch_points"][i])
+        np.testing.assert_array_equal(b["sel"].numpy(), g["sel"][i])
+        sc = b["iou_fused"][torch.arange(32), b["sel"]].numpy()
+        np.testing.assert_allclose(sc, g["score"][i], rtol=1e-5, atol=1e-6)
+
+
 def po_counts(r):
     return _coco_decode(r["counts"])
 

@@ -7,6 +7,10 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# Mask-level bounds: measured on MI355X (the tests print the measurement) x 2.5.  Random-weight masks
+# are noise-like, so a large share of their pixels sits near the threshold; XOR is quoted relative to the mask area.
+MASK_IOU_MIN = 0.97
+MASK_XOR_MAX = 0.03
 G = os.path.join(os.path.dirname(__file__), "golden")
 ARCH = "vit_test128"
 
@@ -23,6 +27,26 @@ class GpuStandInDino:
     def forward_features(self, x):
         p = torch.nn.functional.avg_pool2d(x, 14, 14)
         return {"x_norm_patchtokens": p.flatten(2).transpose(1, 2) @ self.w + self.b}
+
+
+def mask_agreement(rles_hip, masks_ref, label=""):
+    """Per-mask IoU and XOR pixel count between the HIP path's COCO RLE strings and reference / oracle masks (RLE dicts or
+    arrays), aligned index by index.  Prints the worst of each and returns (min IoU, max XOR fraction of the mask area)."""
+    import crowdsam.utils as cu
+    ious, xors, fr = [], [], []
+    for r, mref in zip(rles_hip, masks_ref):
+        a = cu.coco_decode_rle(r).astype(bool)
+        b = (cu.coco_decode_rle(mref) if isinstance(mref, dict) else np.asarray(mref)).astype(bool)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        x = int((a ^ b).sum())
+        u = int((a | b).sum())
+        ious.append(1.0 if u == 0 else 1.0 - x / u)
+        xors.append(x)
+        fr.append(x / max(int(b.sum()), 1))
+    if ious:
+        print("%s mask agreement over %d masks: min IoU %.6f, max XOR %d px (%.2e of the mask area), mean XOR %.1f px"
+              % (label, len(ious), min(ious), max(xors), max(fr), float(np.mean(xors))))
+    return (min(ious), max(fr)) if ious else (1.0, 0.0)
 
 
 def _config(test_cfg):
@@ -60,6 +84,10 @@ def test_generate_matches_reference_golden(model):
     np.testing.assert_allclose(out["stability_score"], g["stability_score"], rtol=0.08, atol=2e-3)
     assert len(out["rles"]) == len(g["rle_counts"])
     assert all(isinstance(r["counts"], str) and r["size"] == [768, 1024] for r in out["rles"])
+    # the masks themselves: decode both RLE sets (the reference's strings are in the fixture), per-mask IoU and XOR count
+    ref_rles = [{"size": [768, 1024], "counts": str(c)} for c in g["rle_counts"]]
+    min_iou, max_xor = mask_agreement(out["rles"], ref_rles, "reference golden (vit_test128, 3 x 8 EPS)")
+    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
 
 
 def test_generate_dense_sweep_matches_oracle(model, cuda):
@@ -93,6 +121,8 @@ def test_generate_dense_sweep_matches_oracle(model, cuda):
     np.testing.assert_allclose(out["scores"][ka], ref["scores"][kb], rtol=0, atol=5e-3)
     assert np.abs(out["boxes"][ka] - ref["boxes"][kb]).max() <= 3
     assert np.all(np.diff(out["scores"]) <= 0)
+    min_iou, max_xor = mask_agreement([out["rles"][i] for i in ka], [ref["rles"][i] for i in kb], "dense sweep vs oracle")
+    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
 
 
 def test_generate_fuse_simmap_matches_reference_golden(cuda):
@@ -156,6 +186,13 @@ def test_generate_vit_b_512_matches_reference_golden(cuda):
     import crowdsam.utils as cu
     area = np.array([int(cu.coco_decode_rle(r).sum()) for r in out["rles"]])
     np.testing.assert_allclose(area[ka], g["mask_area"][kb], rtol=5e-3)      # RLE strings decode to the reference's masks
+    # pixel level: the fixture holds every 8th pixel of every 8th row of the reference's 64 masks
+    mine = np.stack([cu.coco_decode_rle(out["rles"][i])[::8, ::8].astype(bool) for i in ka])
+    theirs = np.unpackbits(g["mask_sample"])[: 64 * 128 * 128].reshape(64, 128, 128).astype(bool)[kb]
+    xor = (mine ^ theirs).reshape(64, -1).sum(1)
+    iou = 1.0 - xor / np.maximum((mine | theirs).reshape(64, -1).sum(1), 1)
+    print("ViT-B 512: sampled mask agreement, min IoU %.5f, max XOR %d of %d sampled pixels" % (iou.min(), xor.max(), 128 * 128))
+    assert iou.min() >= MASK_IOU_MIN
 
 
 @pytest.mark.parametrize("frame", ["768x1024", "700x1366"])
@@ -186,6 +223,8 @@ def test_generate_multi_crop_matches_oracle(cuda, frame):
     np.testing.assert_allclose(out["scores"], ref["scores"], rtol=0, atol=5e-3)
     assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / min(1.0, 1024.0 / max(img.shape[:2]))
     np.testing.assert_array_equal(out["rles_crop"], ref["rles_crop"])        # per-mask crop box (build's sane rles_info)
+    min_iou, max_xor = mask_agreement(out["rles"], ref["rles"], "multi-crop " + frame)
+    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
     assert "crop_boxes" not in out and len(out["rles"]) == len(ref["rles"])
 
 
@@ -286,8 +325,5 @@ def test_generate_max_size_1536_matches_oracle(cuda):
     np.testing.assert_allclose(out["scores"], ref["scores"], rtol=0, atol=5e-3)
     assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / 1.5
     assert all(r["size"] == [1152, 1536] for r in out["rles"])
-    import crowdsam.utils as cu
-    for i in range(0, len(out["rles"]), max(1, len(out["rles"]) // 4)):
-        a, b = cu.coco_decode_rle(out["rles"][i]), cu.coco_decode_rle(ref["rles"][i])
-        assert a.shape == b.shape == (1152, 1536)
-        assert (a != b).sum() <= 0.01 * max(int(b.sum()), 1)
+    min_iou, max_xor = mask_agreement(out["rles"], ref["rles"], "max_size 1536")
+    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX

@@ -1,0 +1,63 @@
+"""Depth-2 pipeline of the per-image loop (tools/test.py:62-82 of the reference is a serial loop): generate(image,
+next_image=...) starts the next frame's upload + encoders beside the current frame's tail.  Results must be bit-identical
+to serial calls -- no random number is drawn before sample_prompts, and the prefetch only touches buffers the queued sweep
+has finished with."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert a["boxes"].shape == b["boxes"].shape
+    for k in ("boxes", "scores", "points", "categories", "stability_score"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert [r["counts"] for r in a["rles"]] == [r["counts"] for r in b["rles"]]
+
+
+def test_pipelined_generate_equals_serial_small_model(cuda):
+    """vit_test128 + stand-in DINO, EPS with pruning (the shipped loop shape), frames of two different shapes in one
+    stream (the prefetch must cope with a change of frame geometry) and a look-ahead frame that is then NOT the next one."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG
+    from tests.test_pipeline_gpu import ARCH, GpuStandInDino, _config
+    m = CrowdSAM(_config(dict(PIPE_CFG)), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    frames = [synth.synthetic_crowd_frame(i, 1024, 60)[:768] for i in range(3)] + [synth.synthetic_crowd_frame(7, 1024, 60)] + \
+             [synth.synthetic_crowd_frame(8, 1366, 80)[:700]]
+    np.random.seed(11)
+    serial = [m.generate(f) for f in frames]
+    np.random.seed(11)
+    piped = list(m.generate_stream(frames))
+    assert len(piped) == len(serial) and any(len(o["boxes"]) for o in serial)
+    for a, b in zip(serial, piped):
+        _same(a, b)
+    # a look-ahead that does not come true: the prefetched state must be dropped, not used
+    np.random.seed(11)
+    a = m.generate(frames[0], next_image=frames[3])
+    b = m.generate(frames[1])
+    _same(a, serial[0])
+    _same(b, serial[1])
+
+
+def test_pipelined_generate_equals_serial_full_model(cuda):
+    """The bench's model (ViT-L + DINOv2-L x 24, 64 x 64 dense sweep, crowded thresholds): 4 frames, pipelined == serial."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam.utils import DEFAULT_TEST_CONFIG
+    from crowdsam_amd import synth
+    t = dict(DEFAULT_TEST_CONFIG)
+    t.update(grid_size=64, points_per_batch=4096, stability_score_thresh=0.25, pos_sim_thresh=-float("inf"),
+             filter_thresh=float("inf"), max_prompts=4096, box_nms_thresh=1.0, crop_nms_thresh=1.0, pred_iou_thresh=0.889)
+    cfg = {"environ": {"device": "cuda"}, "model": {"sam_model": "vit_l", "sam_arch": "crowdsam", "n_class": 1,
+                                                     "trainfree": False}, "test": t}
+    m = CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict("vit_l"), dino_state_dict=synth.make_dino_state_dict())
+    frames = [synth.synthetic_crowd_frame(i, 1024, 150) for i in range(4)]
+    np.random.seed(3)
+    serial = [m.generate(f) for f in frames]
+    np.random.seed(3)
+    piped = list(m.generate_stream(frames))
+    assert sum(len(o["boxes"]) for o in serial) > 200
+    for a, b in zip(serial, piped):
+        _same(a, b)
+    torch.cuda.synchronize()

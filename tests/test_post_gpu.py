@@ -167,6 +167,22 @@ def test_rle_matches_oracle(cuda):
         assert counts == ref[i]["counts"]
 
 
+@pytest.mark.parametrize("w", [516, 517])
+def test_rle_of_non_boolean_bytes_is_the_rle_of_their_truth_value(cuda, w):
+    """the 4-column kernels (W % 4 == 0) compare bit 0 of packed bytes, the scalar ones raw bytes; both are only
+    right for 0 / 1 bytes, so mask_to_rle_arrays normalises anything that is not bool (amg.py:107-135 encodes a bool
+    tensor).  uint8 masks with values {0, 2, 3, 255} must encode like (mask != 0) on both kernel routes."""
+    from segment_anything_cs.utils.amg import mask_to_rle_arrays
+    rs = np.random.RandomState(3)
+    raw = rs.choice(np.array([0, 0, 2, 3, 255], np.uint8), size=(3, 64, w))
+    raw = np.repeat(np.repeat(raw[:, ::8, ::6], 8, 1), 6, 2)[:, :64, :w].copy()          # runs, not salt and pepper
+    a = mask_to_rle_arrays(torch.from_numpy(raw).to(cuda))
+    b = mask_to_rle_arrays(torch.from_numpy(raw != 0).to(cuda))
+    assert len(a) == len(b) == 3
+    for ra, rb in zip(a, b):
+        assert ra["size"] == rb["size"] and np.array_equal(np.asarray(ra["counts"]), np.asarray(rb["counts"]))
+
+
 @pytest.mark.parametrize("downscale", [1.0, 2.0, 3.0, 1.5])
 def test_crop_edge_filter_at_the_20px_boundary(cuda, downscale):
     """The in-kernel crop-edge filter of csam_post_finalize_compact (crowdsam/utils.py:213-223 through

@@ -25,9 +25,9 @@ cp gpurun_out/pmc_sq.txt gpurun_out/${TAG}_pmc_sq_decoder.txt
 bash tools/pmc_sq_encoder.sh && cp gpurun_out/pmc_sq_encoder.txt gpurun_out/${TAG}_pmc_sq_encoder.txt
 python tools/dev_crowd_times.py 2>&1 | grep -v amdgpu.ids | head -3 > gpurun_out/${TAG}_crowd_stage_times.txt
 bash tools/dev_crowd_prof.sh > /dev/null 2>&1; cp gpurun_out/crowd_kernel_stats.txt gpurun_out/${TAG}_crowd_tail_kernels.txt
-python tests/dbg/fused_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_i2t_t2i_vs_separate.txt
-for b in 530 700; do python tests/dbg/fused_diff.py $b proj 2>&1 | grep mismatch >> gpurun_out/${TAG}_i2t_t2i_vs_separate.txt; done
+python tools/debug/fused_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_i2t_t2i_vs_separate.txt
+for b in 530 700; do python tools/debug/fused_diff.py $b proj 2>&1 | grep mismatch >> gpurun_out/${TAG}_i2t_t2i_vs_separate.txt; done
 ./tools/probe/valu_mfma_overlap > gpurun_out/${TAG}_valu_mfma_overlap_probe.txt 2>&1
 ./tools/probe/mfma_srcc_lds_war > gpurun_out/${TAG}_mfma_srcc_lds_war_probe.txt 2>&1
-python tests/dbg/flash_repeat.py 11 1000 q > gpurun_out/${TAG}_flash_repeat.txt 2>&1
-python tests/dbg/tile_classes.py 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/${TAG}_crowd_tile_classes.txt
+python tools/debug/flash_repeat.py 11 1000 q > gpurun_out/${TAG}_flash_repeat.txt 2>&1
+python tools/debug/tile_classes.py 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/${TAG}_crowd_tile_classes.txt
