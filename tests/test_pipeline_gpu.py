@@ -9,8 +9,13 @@ import torch
 pytestmark = pytest.mark.gpu
 # Mask-level bounds: measured on MI355X (the tests print the measurement) x 2.5.  Random-weight masks
 # are noise-like, so a large share of their pixels sits near the threshold; XOR is quoted relative to the mask area.
-MASK_IOU_MIN = 0.97
-MASK_XOR_MAX = 0.03
+#   case                                  measured min IoU / max XOR share      bound (2.5 x the measured defect)
+MASK_BOUNDS = {"golden": (0.9867, 0.0133),      # 0.994707 / 5.30e-3  (reference's own 3 x 8 EPS run, 11 masks)
+               "dense": (0.9941, 0.0059),       # 0.997647 / 2.35e-3  (24 masks vs oracle)
+               "multicrop": (0.9967, 0.0033),   # 0.998705 / 1.30e-3
+               "max_size": (0.9953, 0.0047),    # 0.998123 / 1.88e-3
+               "vit_b_sample": (0.958, None)}   # 0.98324 on every 8th pixel of every 8th row (noise masks, 64 of them)
+BOX_PX, STAB_RTOL, STAB_ATOL = 3, 0.08, 2e-3      # reference golden run: provisional, see the printout
 G = os.path.join(os.path.dirname(__file__), "golden")
 ARCH = "vit_test128"
 
@@ -80,14 +85,18 @@ def test_generate_matches_reference_golden(model):
     np.testing.assert_array_equal(out["categories"], g["categories"])
     # values: fp16 operand tolerance on scores; boxes come from thresholded masks -> a few pixels
     np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=5e-3)
-    assert np.abs(boxes - g["boxes"]).max() <= 3
-    np.testing.assert_allclose(out["stability_score"], g["stability_score"], rtol=0.08, atol=2e-3)
+    sd_ = np.abs(out["stability_score"] - g["stability_score"])
+    print("reference golden: max |score| error %.2e, max box difference %.1f px, stability error max abs %.2e / max rel %.2e"
+          % (np.abs(scores - g["scores"]).max(), np.abs(boxes - g["boxes"]).max(), sd_.max(),
+             (sd_ / np.maximum(g["stability_score"], 1e-9)).max()))
+    assert np.abs(boxes - g["boxes"]).max() <= BOX_PX
+    np.testing.assert_allclose(out["stability_score"], g["stability_score"], rtol=STAB_RTOL, atol=STAB_ATOL)
     assert len(out["rles"]) == len(g["rle_counts"])
     assert all(isinstance(r["counts"], str) and r["size"] == [768, 1024] for r in out["rles"])
     # the masks themselves: decode both RLE sets (the reference's strings are in the fixture), per-mask IoU and XOR count
     ref_rles = [{"size": [768, 1024], "counts": str(c)} for c in g["rle_counts"]]
     min_iou, max_xor = mask_agreement(out["rles"], ref_rles, "reference golden (vit_test128, 3 x 8 EPS)")
-    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
+    assert min_iou >= MASK_BOUNDS["golden"][0] and max_xor <= MASK_BOUNDS["golden"][1]
 
 
 def test_generate_dense_sweep_matches_oracle(model, cuda):
@@ -122,7 +131,7 @@ def test_generate_dense_sweep_matches_oracle(model, cuda):
     assert np.abs(out["boxes"][ka] - ref["boxes"][kb]).max() <= 3
     assert np.all(np.diff(out["scores"]) <= 0)
     min_iou, max_xor = mask_agreement([out["rles"][i] for i in ka], [ref["rles"][i] for i in kb], "dense sweep vs oracle")
-    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
+    assert min_iou >= MASK_BOUNDS["dense"][0] and max_xor <= MASK_BOUNDS["dense"][1]
 
 
 def test_generate_fuse_simmap_matches_reference_golden(cuda):
@@ -192,7 +201,7 @@ def test_generate_vit_b_512_matches_reference_golden(cuda):
     xor = (mine ^ theirs).reshape(64, -1).sum(1)
     iou = 1.0 - xor / np.maximum((mine | theirs).reshape(64, -1).sum(1), 1)
     print("ViT-B 512: sampled mask agreement, min IoU %.5f, max XOR %d of %d sampled pixels" % (iou.min(), xor.max(), 128 * 128))
-    assert iou.min() >= MASK_IOU_MIN
+    assert iou.min() >= MASK_BOUNDS["vit_b_sample"][0]
 
 
 @pytest.mark.parametrize("frame", ["768x1024", "700x1366"])
@@ -224,7 +233,7 @@ def test_generate_multi_crop_matches_oracle(cuda, frame):
     assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / min(1.0, 1024.0 / max(img.shape[:2]))
     np.testing.assert_array_equal(out["rles_crop"], ref["rles_crop"])        # per-mask crop box (build's sane rles_info)
     min_iou, max_xor = mask_agreement(out["rles"], ref["rles"], "multi-crop " + frame)
-    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
+    assert min_iou >= MASK_BOUNDS["multicrop"][0] and max_xor <= MASK_BOUNDS["multicrop"][1]
     assert "crop_boxes" not in out and len(out["rles"]) == len(ref["rles"])
 
 
@@ -326,4 +335,4 @@ def test_generate_max_size_1536_matches_oracle(cuda):
     assert np.abs(out["boxes"] - ref["boxes"]).max() <= 3.0 / 1.5
     assert all(r["size"] == [1152, 1536] for r in out["rles"])
     min_iou, max_xor = mask_agreement(out["rles"], ref["rles"], "max_size 1536")
-    assert min_iou >= MASK_IOU_MIN and max_xor <= MASK_XOR_MAX
+    assert min_iou >= MASK_BOUNDS["max_size"][0] and max_xor <= MASK_BOUNDS["max_size"][1]

@@ -1,0 +1,124 @@
+"""Developer probe: why do the encoder's GEMMs run 25-30 % below their back-to-back micro-benchmark
+rate inside the encoder?  For every distinct GEMM call of one SAM ViT-L encoder forward (shape + epilogue):
+  in-sequence  : HIP-event time of the call inside the real op sequence (LayerNorm / attention between the GEMMs, operands
+                 produced by the previous kernel, weights cold), averaged over the blocks and 5 forwards;
+  isolated cold: 20 back-to-back launches of the same call after the GPU idled for 0.5 s;
+  isolated hot : the same 20 launches right after 2 s of sustained GEMM load;
+and the shader clock (s_memtime / s_memrealtime in a one-wave probe kernel on a second stream) in each regime."""
+import ctypes
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from crowdsam_amd import hip, synth
+from segment_anything_cs import sam_model_registry
+
+dev = torch.device("cuda:0")
+probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libclock_probe.so"))
+probe.clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+side = torch.cuda.Stream()
+clk_buf = torch.zeros(3, dtype=torch.int64, device=dev)
+
+
+def clock_mhz(spin=200000):
+    """core clock while whatever is queued on the main stream runs (the probe wave sits on a second stream)"""
+    with torch.cuda.stream(side):
+        probe.clock_probe(ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(clk_buf.data_ptr()), spin)
+    side.synchronize()
+    c, r = clk_buf[0].item(), clk_buf[1].item()
+    return 100.0 * c / max(r, 1)
+
+
+sam = sam_model_registry["vit_l"](n_class=1)
+sam.load_state_dict(synth.make_sam_state_dict("vit_l"), strict=False)
+sam = sam.to(dev)
+enc = sam.image_encoder
+x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
+raw = (x[0] * sam.pixel_std.cpu() + sam.pixel_mean.cpu()).to(dev).contiguous()
+plan = enc.plan()
+hip.GRAPHS_ENABLED = False
+for _ in range(2):
+    plan.forward(raw)
+torch.cuda.synchronize()
+
+# ---- in-sequence timing: wrap hip.gemm_f16
+records = {}
+orig = hip.gemm_f16
+calls = []
+
+
+def timed_gemm(a, w, out=None, bias=None, act=hip.ACT_NONE, residual=None, colscale=None, out_dtype=torch.float16, M=None):
+    m = a.shape[0] if M is None else M
+    key = (m, w.shape[0], a.shape[1], "f32+res" if residual is not None else ("gelu" if act == hip.ACT_GELU else "f16"))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = orig(a, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+    e1.record()
+    calls.append((key, e0, e1, (a, w, out, bias, act, residual, colscale, out_dtype, M)))
+    return r
+
+
+hip.gemm_f16 = timed_gemm
+import crowdsam_amd.encoder as _enc
+NF = 5
+t_seq0 = time.perf_counter()
+for _ in range(NF):
+    plan.forward(raw)
+clk_seq = clock_mhz()
+torch.cuda.synchronize()
+hip.gemm_f16 = orig
+args_by_key = {}
+for key, e0, e1, a in calls:
+    records.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)
+    args_by_key.setdefault(key, a)
+print("SAM ViT-L encoder, eager op sequence, %d forwards; shader clock during the sequence %.0f MHz" % (NF, clk_seq))
+
+
+def iso(a, n=20):
+    aa, w, out, bias, act, residual, colscale, out_dtype, M = a
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+    e0.record()
+    for _ in range(n):
+        orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def load(seconds, a):
+    aa, w, out, bias, act, residual, colscale, out_dtype, M = a
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(200):
+            orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+        torch.cuda.synchronize()
+
+
+print("%-28s %6s | %9s %7s | %9s %7s %5s | %9s %7s %5s" % ("M x N x K epilogue", "calls", "in-seq us", "TF/s", "cold us", "TF/s", "MHz", "hot us", "TF/s", "MHz"))
+tot_seq = tot_cold = tot_hot = 0.0
+for key, ts in sorted(records.items(), key=lambda kv: -sum(kv[1])):
+    m, n, k, ep = key
+    fl = 2.0 * m * n * k
+    t_seq = float(np.mean(ts))
+    a = args_by_key[key]
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    t_cold = iso(a)
+    load(0.05, a)
+    clk_cold = clock_mhz(20000)
+    time.sleep(0.5)
+    load(2.0, a)
+    # clock while the hot launches are in flight
+    aa, w, out, bias, act, residual, colscale, out_dtype, M = a
+    for _ in range(300):
+        orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+    clk_hot = clock_mhz()
+    t_hot = iso(a)
+    per_fwd = len(ts) / NF
+    tot_seq += t_seq * per_fwd; tot_cold += t_cold * per_fwd; tot_hot += t_hot * per_fwd
+    print("%5d x %4d x %4d %-8s %6d | %9.1f %7.0f | %9.1f %7.0f %5.0f | %9.1f %7.0f %5.0f"
+          % (m, n, k, ep, per_fwd, t_seq, fl / t_seq / 1e6, t_cold, fl / t_cold / 1e6, clk_cold, t_hot, fl / t_hot / 1e6, clk_hot))
+print("GEMM time per forward: in-sequence %.0f us, isolated cold %.0f us, isolated hot %.0f us" % (tot_seq, tot_cold, tot_hot))
