@@ -1651,6 +1651,312 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
   }
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// upscale_ws_kernel (round 4): csam_upscale_stream with SPECIALISED waves.  PMC / ablations of upscale_stream_kernel:
+// VALU-pipe-bound on the two polynomial GELUs, the MFMA time of its two mixed waves per SIMD is not hidden (every
+// component costs its own pipe time).  Here ONE 8-wave workgroup per CU: waves 0-3 are the MATRIX waves (the stream
+// kernel's wave: first-conv position, W1 slice in registers, both convs, LayerNorm2d + the first GELU, hyper product),
+// waves 4-7 are VALU waves that evaluate the SECOND GELU (2/3 of the evaluations) for the matrix wave on their SIMD.
+// Hand-over = a lane-private LDS mailbox: matrix lane L writes its 64 second-conv outputs of a 32-token tile as fp16
+// (8 x 16 B, conflict-free), VALU lane L turns them into GELU values IN PLACE, matrix lane L reads back exactly the fp16
+// B fragments of the hyper product.  No layout change, no exchange between lanes; 2 x 32 KB of mailbox for tiles t, t+1.
+// Software pipeline per step s (one workgroup barrier pair per 32-token tile, as before):
+//     matrix wave:  conv2(s) -> mailbox[s&1] | conv1 + LayerNorm2d + GELU(s+1) | hyper product(s-1) <- mailbox[(s-1)&1]
+//     VALU wave  :  GELU of mailbox[(s-1)&1] (tile s-1), then its done-flag
+// so the VALU wave always works on data that was complete at the step's first barrier and has the matrix wave's whole
+// step to finish; the matrix wave polls the done-flag before it reads back (normally long set).  The second conv's
+// output crosses the mailbox as fp16 (one more rounding before the GELU, which rounds to fp16 anyway).
+// -----------------------------------------------------------------------------------------------------
+constexpr int UW_W2S = 2 * US_BUF;                 // W2' 16 KB
+constexpr int UW_OUT = UW_W2S + 16 * 1024;         // [16 rows][128 px] fp32 = 8 KB
+constexpr int UW_PAR = UW_OUT + 8 * 1024;          // b2 [128] | b1 [256] | ln_g [64] | ln_b [64] fp32 = 2 KB
+constexpr int UW_WMX = UW_PAR + 2048;              // [4 waves][2]
+constexpr int UW_FLG = UW_WMX + 64;                // int [2 regions][4 positions]: tile whose GELU is complete
+constexpr int UW_MBX = UW_FLG + 64;                // mailbox [2 regions][4 positions][8 chunks][64 lanes][16 B]
+constexpr int UW_SMEM = UW_MBX + 2 * 4 * 8192;
+
+__global__ __launch_bounds__(512, 1) void upscale_ws_kernel(UpArgs p, int B, int prompts_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_m = wave < 4;
+  const int pos = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int TPP = 4096 / US_TOK;                 // 128 tiles per prompt
+  const int b_first = blockIdx.x * prompts_per_wg;
+  const int b_last = min(b_first + prompts_per_wg, B);
+  if (b_first >= b_last) return;
+  const int first = b_first * TPP, last = b_last * TPP;
+  volatile int* flags = (volatile int*)(smem + UW_FLG);
+  if (tid < 8) flags[tid] = -1;
+  char* mbx = smem + UW_MBX + pos * 8192 + lane * 16;          // + region * 32768 + chunk * 1024
+
+  if (!is_m) {
+    // ================================ VALU wave: second GELU of tile s-1, in place =================================
+    for (int s = first - 1; s <= last; ++s) {
+      I2S_BARRIER();                                            // (a)
+      const int t = s - 1;
+      if (t >= first && t < last) {
+        char* mb = mbx + (t & 1) * 32768;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {                        // two chunks (8 channel pairs) in flight
+          half8_t h0 = *(const half8_t*)(mb + j * 1024);
+          half8_t h1 = *(const half8_t*)(mb + (j + 1) * 1024);
+          float2_t z0[4], z1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            z0[q] = float2_t{(float)h0[2 * q], (float)h0[2 * q + 1]};
+            z1[q] = float2_t{(float)h1[2 * q], (float)h1[2 * q + 1]};
+          }
+#if !defined(CSAM_WS_ABL) || CSAM_WS_ABL != 1   /* developer ablation 1: the VALU waves only move the bytes */
+          CSAM_UP_GELU4(z0);
+          CSAM_UP_GELU4(z1);
+#endif
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            h0[2 * q] = (half_t)z0[q][0];
+            h0[2 * q + 1] = (half_t)z0[q][1];
+            h1[2 * q] = (half_t)z1[q][0];
+            h1[2 * q + 1] = (half_t)z1[q][1];
+          }
+          *(half8_t*)(mb + j * 1024) = h0;
+          *(half8_t*)(mb + (j + 1) * 1024) = h1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flags[(t & 1) * 4 + pos] = t;
+      }
+      I2S_BARRIER();                                            // (b)
+      if (t >= first && p.stats && (t % TPP) == TPP - 1) I2S_BARRIER();   // the matrix waves' per-prompt max exchange
+    }
+    return;
+  }
+
+  // ===================================== matrix wave (first-conv position pos) ====================================
+  const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
+  constexpr int PIECE = 256 * 16;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  half8_t w1[4][8];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      w1[ni][ks] = *(const half8_t*)(p.W1 + (long)(pos * 64 + ni * 16 + fr) * 256 + ks * 32 + fg * 8);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                   // W2': 128 rows x 8 slots, 128-B rows, slot ^= row & 7
+    const int cc = tid + it * 256;
+    const int row = cc >> 3, sl = cc & 7;
+    glds16(p.W2 + (long)row * 64 + ((sl ^ (row & 7)) * 8), smem + UW_W2S + (cc & ~63) * 16);
+  }
+  float* par = (float*)(smem + UW_PAR);
+  if (tid < 128) par[tid] = p.b2[tid];
+  par[128 + tid] = p.b1[tid];
+  if (tid < 64) {
+    par[384 + tid] = p.ln_g[tid];
+    par[448 + tid] = p.ln_b[tid];
+  }
+  float* outs = (float*)(smem + UW_OUT);
+  float* wmx = (float*)(smem + UW_WMX);
+
+  auto issue_x = [&](int t, int buf) {
+    const char* src = (const char*)(p.X + (long)t * US_TOK * 256);
+    const unsigned dst = lds0 + buf * US_BUF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
+  };
+
+  half8_t hhi = {0, 0, 0, 0, 0, 0, 0, 0}, hlo = hhi;
+  half8_t xf2[2][2];
+  float pmax0 = -INFINITY, pmax1 = -INFINITY;        // running max of the planes this thread stores (l0, l0 + 2)
+  issue_x(first, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int s = first - 1; s <= last; ++s) {
+    // (a) tile s+1 landed (retired before barrier (b) of the previous step); outs and mailbox[s&1] are free again
+    I2S_BARRIER();
+    if (s + 2 < last) issue_x(s + 2, (s + 2 - first) & 1);
+
+    // ---- (1) second conv of tile s (its fp16 activations xf2 were made in the previous step) -> mailbox[s&1]
+    if (s >= first && s < last) {
+      char* mb = mbx + (s & 1) * 32768;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        floatx4 a2[2][4];                                 // seeded with the second conv's bias
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+          const floatx4 b2v = *(const floatx4*)(par + (ph * 4 + n2) * 16 + fg * 4);
+          a2[0][n2] = b2v;
+          a2[1][n2] = b2v;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int n2 = 0; n2 < 4; ++n2) {
+            const int row = (ph * 4 + n2) * 16 + fr;
+            const half8_t wf = *(const half8_t*)(smem + UW_W2S + row * 128 + (((s2 * 4 + fg) ^ (row & 7)) << 4));
+            a2[0][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[0][s2], a2[0][n2], 0, 0, 0);
+            a2[1][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[1][s2], a2[1][n2], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            half8_t hv;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[h2 * 4 + e] = (half_t)a2[mi][p2 * 2 + h2][e];
+            *(half8_t*)(mb + (ph * 4 + p2 * 2 + mi) * 1024) = hv;
+          }
+      }
+    }
+
+    // ---- (2) first conv + LayerNorm2d + GELU of tile s+1 -> xf2 (registers)
+#if defined(CSAM_WS_ABL) && CSAM_WS_ABL == 2      /* developer ablation 2: no first conv / LayerNorm / first GELU */
+    if (s + 1 < last) {
+      xf2[0][0] = w1[0][0]; xf2[0][1] = w1[1][1]; xf2[1][0] = w1[2][2]; xf2[1][1] = w1[3][3];
+    } else
+#endif
+    if (s + 1 < last) {
+      const char* xb = smem + ((s + 1 - first) & 1) * US_BUF;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        floatx4 a1[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
+        {
+          constexpr int XD = CSAM_UP_XDEPTH;              // fragment sets in flight
+          half8_t xf[XD];
+#pragma unroll
+          for (int ks = 0; ks < XD - 1; ++ks) xf[ks] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            if (ks + XD - 1 < 8)
+              xf[(ks + XD - 1) % XD] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + XD - 1) * 4 + fg) ^ fr) << 4));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
+            asm volatile("" ::: "memory");
+          }
+        }
+        float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const float2_t lo = {a1[ni][0], a1[ni][1]}, hi = {a1[ni][2], a1[ni][3]};
+          s2 += lo;
+          q2 = __builtin_elementwise_fma(lo, lo, q2);
+          s2 += hi;
+          q2 = __builtin_elementwise_fma(hi, hi, q2);
+        }
+        const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float mean = ssum[0] * (1.f / 64.f);
+        const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time
+          float2_t z[4];
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) {
+            const int ni = nh * 2 + n2;
+            const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
+            const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const float2_t av = {a1[ni][e], a1[ni][e + 1]};
+              const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
+              const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
+              z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
+            }
+          }
+          CSAM_UP_GELU4(z);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
+            xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
+            xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
+          }
+        }
+      }
+    }
+
+    // ---- (3) hyper product of tile s-1 from the mailbox the VALU wave has turned into GELU values
+    const int th = s - 1;
+    const int bh = th / TPP, tph = th - bh * TPP;
+    if (th >= first) {
+      if (th == first || tph == 0) {                 // new prompt: hyper-network A fragments (hi / lo fp16 split)
+        half8_t hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fr < 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cch = ((e >= 4) ? 16 : 0) + fg * 4 + (e & 3);
+            const float h = p.hyper[((long)bh * 4 + fr) * 32 + cch];
+            hi[e] = (half_t)h;
+            lo[e] = (half_t)(h - (float)hi[e]);
+          }
+        }
+        hhi = hi;
+        hlo = lo;
+      }
+#if !defined(CSAM_WS_ABL) || CSAM_WS_ABL != 3   /* developer ablation 3: the matrix wave does not wait for the VALU wave */
+      while (flags[(th & 1) * 4 + pos] != th) __builtin_amdgcn_s_sleep(1);
+#endif
+      const char* mb = mbx + (th & 1) * 32768;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          const int pos2 = ph * 2 + p2;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const half8_t ub = *(const half8_t*)(mb + (ph * 4 + p2 * 2 + mi) * 1024);
+            floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
+            if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
+              const int yy = (pos >> 1) * 2 + (pos2 >> 1);
+              const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+#pragma unroll
+              for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
+            }
+          }
+        }
+    }
+    // (b) output half-rows complete; also retires the LDS-DMA of tile s+2 BEFORE this step's stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (th >= first) {
+      const int i0 = tph >> 1, half = tph & 1;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rowid = it * 8 + (tid >> 5), x4 = tid & 31;      // rowid = l*4 + yy
+        const floatx4 v = *(const floatx4*)(outs + rowid * 128 + x4 * 4);
+        const int l = rowid >> 2, yy = rowid & 3;
+        char* dst = (char*)(p.masks + (((long)bh * 4 * 256) + 4 * i0) * 256 + half * 128);    // uniform base
+        const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");   // see i2s_store16
+        const float mxv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (it == 0) pmax0 = fmaxf(pmax0, mxv);
+        else pmax1 = fmaxf(pmax1, mxv);
+      }
+      if (tph == TPP - 1 && p.stats) {               // prompt complete: per-plane max (planes l0 = tid>>7 and l0 + 2)
+        const float m0 = csam_wave_max(pmax0), m1 = csam_wave_max(pmax1);
+        if (lane == 0) {
+          wmx[wave * 2] = m0;
+          wmx[wave * 2 + 1] = m1;
+        }
+        I2S_BARRIER();
+        if (tid < 4) {   // plane tid: waves (tid & 1) * 2 and +1 hold it, slot tid >> 1
+          const int w0 = (tid & 1) * 2, sl = tid >> 1;
+          const float m = fmaxf(wmx[w0 * 2 + sl], wmx[(w0 + 1) * 2 + sl]);
+          p.stats[((long)bh * 4 + tid) * 2] = m;
+          p.stats[((long)bh * 4 + tid) * 2 + 1] = 0.f;
+        }
+        pmax0 = -INFINITY;
+        pmax1 = -INFINITY;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 __global__ void stats_init_kernel(float* stats, int rows) {
@@ -1702,10 +2008,22 @@ extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const voi
   a.stats = stats_or_null;
   static csam_once_t once;
   const int n_cu = csam_cu_count();
-  if (csam_first_call(once))
+  if (csam_first_call(once)) {
     (void)hipFuncSetAttribute((const void*)upscale_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, US_SMEM);
-  const int per = csam_cdiv(B, 2 * n_cu);
-  hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
+    (void)hipFuncSetAttribute((const void*)upscale_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UW_SMEM);
+  }
+  static int ws = -1;                                 // CSAM_UP_WS=1: the wave-specialised kernel (round-4 experiment, measured
+  if (ws < 0) {                                       // slower: profiles/r04_upscale_wave_specialised.txt); default = mixed waves
+    const char* e = getenv("CSAM_UP_WS");
+    ws = e ? atoi(e) : 0;
+  }
+  if (ws) {
+    const int per = csam_cdiv(B, n_cu);               // ONE 8-wave workgroup per CU (4 matrix + 4 VALU waves)
+    hipLaunchKernelGGL(upscale_ws_kernel, dim3(csam_cdiv(B, per)), dim3(512), UW_SMEM, (hipStream_t)stream, a, B, per);
+  } else {
+    const int per = csam_cdiv(B, 2 * n_cu);
+    hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
+  }
   CSAM_LAUNCH_CHECK("csam_upscale_stream");
   return CSAM_OK;
 }
