@@ -128,6 +128,42 @@ def test_decoder_batch_repeatable(cuda):
                 assert _same(ref[n], cur[n]), n
 
 
+def test_decoder_batch_4096_soak_250_launches(cuda):
+    """250 launches of the FULL production decoder batch (4096 prompts -- csam_i2t_t2i, csam_upscale_stream,
+    the pooled PWD-Net heads; 8.6 GB of key state, never cache resident) must agree bit for bit.  Every launch is reduced to
+    integer checksums of the bit patterns of the low-res logits, IoU and class outputs on the device (an exact comparison
+    of 1 GB per launch without keeping 250 copies)."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    B = 4096
+    sd = synth.make_state_dict(list(synth.sam_param_specs(128, 4, 2, (1, 3))), 0)
+    plan = DecoderPlan(sd, cuda, 1, B)
+    torch.manual_seed(2)
+    feat = torch.randn(4096, 256, device=cuda)
+    dtok = torch.zeros(5376, 1024, dtype=torch.float16, device=cuda)
+    dtok[:5329] = torch.randn(5329, 1024, device=cuda).half()
+    plan.set_image(feat, dtok)
+    coords = torch.rand(B, 2, device=cuda) * 1023
+    w = torch.arange(1, 1 + 4 * 256 * 256, device=cuda, dtype=torch.int64) % 1021 + 1       # position-dependent weights
+
+    def checksum():
+        out = []
+        for n in ("masks", "iou", "cls"):
+            t = plan.ws[n][: (B if n in ("masks", "iou") else B * 4)].contiguous().view(-1).view(torch.int32).to(torch.int64)
+            k = t.numel()
+            out.append((t * w[:k] if k <= w.numel() else t.view(B, -1) * w[None, : t.numel() // B]).sum())
+        return torch.stack(out)
+
+    sums = []
+    for _ in range(250):
+        plan.run_batch(coords)
+        sums.append(checksum())
+    torch.cuda.synchronize()
+    sums = torch.stack(sums).cpu()
+    bad = [i for i in range(len(sums)) if not torch.equal(sums[i], sums[0])]
+    assert not bad, "launches whose outputs differ from the first: %s" % bad[:10]
+
+
 def test_flash_attn80_relpos_repeatable_many_launches(cuda):
     """head_dim 80 (ViT-H global blocks): 250 launches of the rel-pos variant on one set of operands must agree bit for bit
     (the head_dim-64 kernel's intermittent seed error, DESIGN.md 4.2b, was only visible this way)."""
