@@ -38,7 +38,27 @@ struct GemmArgs {
   int act;
   int M, N, K;
   long sA, sW, sC, sB;  // batch strides in elements (grid.z); sB: bias stride
+  // LayerNorm folded into the GEMMs around it (csam_gemm_f16_ln; common.py:38-43 between image_encoder.py:166-182):
+  //   producer (fp32 residual output): also writes C16 = fp16(C) and, per row and 128-column tile, (sum, sum of squares)
+  //   consumer: C = act(rstd[m] * (A W'^T - mean[m] * colsum[n]) + bias[n]), mean / rstd from the producer's partials
+  half_t* C16; long ldc16;
+  float* st_out;
+  const float* st_in; int st_np; float eps;
+  const float* colsum;
 };
+
+// mean and 1/std of a row from its st_np (sum, sum of squares) partials, summed in tile order (deterministic)
+__device__ __forceinline__ float2_t ln_row_stats(const float* st, int np, float eps) {
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < np; ++i) {
+    s += st[2 * i];
+    q += st[2 * i + 1];
+  }
+  const float inv = 1.0f / (float)(np * 128);
+  const float mean = s * inv;
+  const float var = fmaxf(q * inv - mean * mean, 0.f);
+  return float2_t{mean, rsqrtf(var + eps)};
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -174,6 +194,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
+  float* stab = (float*)(smem + TBM * 512);            // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
+  if (p.st_in) {
+    for (int r = tid; r < TBM; r += NT) {
+      const int m = min(bm0 + r, p.M - 1);
+      const float2_t ms = ln_row_stats(p.st_in + (long)m * p.st_np * 2, p.st_np, p.eps);
+      stab[2 * r] = ms[0];
+      stab[2 * r + 1] = ms[1];
+    }
+    __syncthreads();
+  }
 
   // ---- epilogue.  Lane holds C[m = fr][n = fg*4 + j] of each 16x16 tile: stored straight from the
   // accumulators that is 8/16-byte pieces in 32/64-B segments (store-issue bound, measured).  Instead the
@@ -189,6 +219,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       const int col = wn * NI * 16 + ni * 16 + fg * 4;    // column inside the 128-col tile
       const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
+      if (p.st_in) {                                      // folded LayerNorm: rstd * (acc - mean * colsum)
+        const float mean = stab[2 * row], rstd = stab[2 * row + 1];
+        const floatx4 cs = *(const floatx4*)(p.colsum + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rstd * (v[j] - mean * cs[j]);
+      }
       if (p.bias) v += *(const floatx4*)(p.bias + n);
       if (p.act == CSAM_ACT_GELU && p.c_dt == CSAM_DT_F16) {
         // fp16-bound output: packed polynomial GELU (13 instructions per pair).  With the erf form the activation
@@ -229,14 +265,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       const int c = tid + it * NT;                     // TBM*32 16-B pieces: row c>>5, LDS slot c&31
       const int row = c >> 5, sl = c & 31;
       const int m = bm0 + row;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < p.M) {
         const int n = bn0 + ((sl ^ (row & 31)) << 2);
-        floatx4 v = *(const floatx4*)(smem + c * 16);
+        v = *(const floatx4*)(smem + c * 16);
         if (res_late) {
           const int mr = p.res_mod > 0 ? m % p.res_mod : m;
           v += *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
         }
         *(floatx4*)((float*)p.C + (long)m * p.ldc + n) = v;
+        if (p.C16) {                                   // the next projection's fp16 operand (the LayerNorm is folded into it)
+          half4_t h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
+          *(half4_t*)(p.C16 + (long)m * p.ldc16 + n) = h;
+        }
+      }
+      if (p.st_out) {                                  // 32 consecutive lanes hold one row's 128 columns
+        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+        float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sm += __shfl_xor(sm, o, 64);
+          sq += __shfl_xor(sq, o, 64);
+        }
+        if ((c & 31) == 0 && m < p.M) {
+          float* d = p.st_out + ((long)m * (p.N / BN) + bn0 / BN) * 2;
+          d[0] = sm;
+          d[1] = sq;
+        }
       }
     }
   } else {
@@ -267,6 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int G2_STAGE = 2 * 256 * 64;                  // A 256 rows + W 256 rows, 64 B each
 constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB ring; the 256x256 fp16 output tile reuses it
+constexpr int G2_SMEM_ALL = G2_SMEM + 2048;             // + the [256][2] LayerNorm table of csam_gemm_f16_ln
 
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -313,6 +371,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     bz[j] = p.bias ? *(const floatx4*)(p.bias + bn0 + (wave & 3) * 64 + j * 16 + (lane >> 4) * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+  // folded LayerNorm (consumer): the column sums of the wave's 16 columns and -- for thread r < 256 -- the (sum, sum of
+  // squares) partials of tile row r are fetched here too; mean / rstd go through a 2 KB table behind the output tile
+  floatx4 cz[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    cz[j] = p.st_in ? *(const floatx4*)(p.colsum + bn0 + (wave & 3) * 64 + j * 16 + (lane >> 4) * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+  floatx4 pr[5];                                                  // st_np <= 10 partials of (sum, sum of squares), st_np even
+#pragma unroll
+  for (int i = 0; i < 5; ++i) pr[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (p.st_in && tid < 256) {
+    const floatx4* s4 = (const floatx4*)(p.st_in + (long)min(bm0 + tid, p.M - 1) * p.st_np * 2);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (2 * i < p.st_np) pr[i] = s4[i];
+  }
   const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
   const int a_base = (wr * 128 + fr) * 64 + coff;                 // + i * 1024 per 16-row tile
   const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
@@ -382,15 +455,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
   }
   __syncthreads();
+  float* stab = (float*)(smem + G2_SMEM);                         // [256][2] mean, rstd
+  if (p.st_in) {
+    if (tid < 256) {                                              // same summation order as ln_row_stats
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        sm += pr[i][0];
+        sq += pr[i][1];
+        sm += pr[i][2];
+        sq += pr[i][3];
+      }
+      const float inv = 1.0f / (float)(p.st_np * 128);
+      const float mean = sm * inv;
+      stab[2 * tid] = mean;
+      stab[2 * tid + 1] = rsqrtf(fmaxf(sq * inv - mean * mean, 0.f) + p.eps);
+    }
+    __syncthreads();
+  }
 
   // ---- epilogue (fp16 out, bias + activation): tile staged in LDS [256 rows][512 B], 32 slots of 16 B, slot ^= row & 31
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = wr * 128 + i * 16 + fr;
+    const float mean = p.st_in ? stab[2 * row] : 0.f, rstd = p.st_in ? stab[2 * row + 1] : 1.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = wc * 64 + j * 16 + fg * 4;
-      floatx4 v = acc[i][j] + bz[j];
+      floatx4 v = acc[i][j];
+      if (p.st_in) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * cz[j][e]);
+      }
+      v += bz[j];
       if (p.act == CSAM_ACT_GELU) {
         const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
         v = floatx4{g0[0], g0[1], g1[0], g1[1]};
@@ -423,7 +520,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 static int gemm_launch(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                        int c_dtype, const float* bias, const float* colscale, const void* residual,
                        long ldr, int r_dtype, int res_mod, int act, int M, int N, int K, int batch, long sA,
-                       long sW, long sC, long sB = 0) {
+                       long sW, long sC, long sB = 0, void* C16 = nullptr, long ldc16 = 0, float* st_out = nullptr,
+                       const float* st_in = nullptr, int st_np = 0, float eps = 0.f, const float* colsum = nullptr) {
   CSAM_REQUIRE(A && W && C, "csam_gemm_f16: null operand");
   CSAM_REQUIRE(M > 0 && N > 0 && K > 0, "csam_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
   CSAM_REQUIRE(N % BN == 0, "csam_gemm_f16: N=%d must be a multiple of %d", N, BN);
@@ -440,6 +538,11 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   p.res_mod = res_mod;
   p.act = act; p.M = M; p.N = N; p.K = K;
   p.sA = sA; p.sW = sW; p.sC = sC; p.sB = sB;
+  p.C16 = (half_t*)C16; p.ldc16 = ldc16; p.st_out = st_out; p.st_in = st_in; p.st_np = st_np; p.eps = eps; p.colsum = colsum;
+  CSAM_REQUIRE(!(C16 || st_out) || (c_dtype == CSAM_DT_F32 && batch == 1 && (!C16 || ldc16 % 4 == 0)),
+               "csam_gemm_f16_ln: the fp16 copy / row statistics come with the fp32 output only");
+  CSAM_REQUIRE(!st_in || (colsum && st_np > 0 && st_np * BN == K && batch == 1),
+               "csam_gemm_f16_ln: row statistics must cover K = %d features in 128-column partials (got %d)", K, st_np);
   CSAM_REQUIRE(batch >= 1 && (batch == 1 || !residual), "csam_gemm_f16: batched call takes no residual");
   // 64-row tiles when 128-row tiles would leave CUs without a workgroup (measured: pays at <= 256 tiles,
   // loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU)
@@ -469,11 +572,11 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   }
   static csam_once_t set256;
   if (csam_first_call(set256))
-    hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM);
+    hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_ALL);
   if (use256 && batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 &&
-      (N / 256) * csam_cdiv(M, 256) <= 256 && K >= 64) {
+      (N / 256) * csam_cdiv(M, 256) <= 256 && K >= 64 && (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
     dim3 g256((N / 256) * csam_cdiv(M, 256));
-    hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM_ALL, (hipStream_t)stream, p);
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }
@@ -482,7 +585,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
     constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
-    constexpr int SM = SM_RING > SM_OUT ? SM_RING : SM_OUT;                                                    \
+    constexpr int SM = (SM_RING > SM_OUT + 2048 ? SM_RING : SM_OUT + 2048);  /* + [TBM][2] LayerNorm table */  \
     static csam_once_t set;                                                                                    \
     auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
     if (csam_first_call(set))                                                                                  \
@@ -510,6 +613,15 @@ extern "C" int csam_gemm_f16(void* stream, const void* A, long lda, const void* 
                              int act, int M, int N, int K) {
   return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, colscale, residual, ldr, r_dtype, 0, act,
                      M, N, K, 1, 0, 0, 0);
+}
+
+// LayerNorm folded into the two GEMMs around it (include/csam.h).
+extern "C" int csam_gemm_f16_ln(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc, int c_dtype,
+                                const float* bias, const float* colscale, const void* residual, long ldr, int r_dtype,
+                                int act, int M, int N, int K, void* C16_out, long ldc16, float* rowstats_out,
+                                const float* rowstats_in, int n_partials, float eps, const float* colsum) {
+  return gemm_launch(stream, A, lda, W, ldw, C, ldc, c_dtype, bias, colscale, residual, ldr, r_dtype, 0, act, M, N, K, 1,
+                     0, 0, 0, 0, C16_out, ldc16, rowstats_out, rowstats_in, n_partials, eps, colsum);
 }
 
 // residual row index taken modulo res_mod: adds a per-image [res_mod, N] constant to every prompt's

@@ -7,6 +7,7 @@ cls token, learned 37x37 pos-embed bicubic-resized to 73x73, 24 pre-LN blocks wi
 GELU MLP, final LayerNorm.  Sequence = 1 + 5329 tokens, rows padded to 5376 in HBM.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -63,11 +64,22 @@ class DinoPlan:
                 fc1_w=f16(sd[B + "mlp.fc1.weight"]), fc1_b=f32(sd[B + "mlp.fc1.bias"]),
                 fc2_w=f16(sd[B + "mlp.fc2.weight"]), fc2_b=f32(sd[B + "mlp.fc2.bias"]),
                 ls2=f32(sd[B + "ls2.gamma"])))
+        # round 4: LayerNorm folded into the qkv / fc1 projections (csam_gemm_f16_ln); block 0's first LayerNorm stays a
+        # kernel (its input's cls row comes from a copy, not from a projection)
+        self.ln_fold = os.environ.get("CSAM_LN_FOLD", "1") != "0"
+        if self.ln_fold:
+            for i, bl in enumerate(self.blocks):
+                B = f"blocks.{i}."
+                bl["qkv_wf"], bl["qkv_bf"], bl["qkv_cs"] = hip.fold_layernorm(
+                    f32(sd[B + "attn.qkv.weight"].detach().float().cpu() * qfold), bl["qkv_b"], bl["ln1_g"], bl["ln1_b"])
+                bl["fc1_wf"], bl["fc1_bf"], bl["fc1_cs"] = hip.fold_layernorm(f32(sd[B + "mlp.fc1.weight"]), bl["fc1_b"],
+                                                                               bl["ln2_g"], bl["ln2_b"])
         self.norm_g, self.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
         TP = 5376
         self.ws = dict(col=e(5329, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
-                       attn=e(TP, D), mlp=e(TP, 4 * D), img=e(3 * 1024 * 1024, dt=torch.float32))
+                       attn=e(TP, D), mlp=e(TP, 4 * D), img=e(3 * 1024 * 1024, dt=torch.float32),
+                       x16=e(TP, D), st=e(TP, D // 128, 2, dt=torch.float32))
         self.graphs = hip.GraphCache()
 
     def forward_static(self, img_chw_f32, out):
@@ -86,14 +98,27 @@ class DinoPlan:
         hip.dino_im2col(img_chw_f32, ws["col"], normalized_1022)
         x[0:1].copy_(self.cls_row)
         hip.gemm_f16(ws["col"], self.patch_w, out=x[1:], bias=self.patch_b, residual=self.pos[1:], M=5329)
-        for b in self.blocks:
-            hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"], M=T)
-            hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"], M=T)
+        fold = self.ln_fold
+        x16, st = ws["x16"], ws["st"]
+        for i, b in enumerate(self.blocks):
+            if fold and i > 0:
+                hip.gemm_f16_ln(x16, b["qkv_wf"], ws["qkv"], bias=b["qkv_bf"], M=T, stats_in=st, colsum=b["qkv_cs"], eps=1e-6)
+            else:
+                hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"], M=T)
+                hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"], M=T)
             hip.flash_attn(ws["qkv"], ws["attn"], T, nH, scale, D, q_prescaled=True)
-            hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T)
-            hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"], M=T)
-            hip.gemm_f16(ws["h"], b["fc1_w"], out=ws["mlp"], bias=b["fc1_b"], act=hip.ACT_GELU, M=T)
-            hip.gemm_f16(ws["mlp"], b["fc2_w"], out=x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T)
+            if fold:
+                hip.gemm_f16_ln(ws["attn"], b["proj_w"], x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T, out16=x16,
+                                stats_out=st)
+                hip.gemm_f16_ln(x16, b["fc1_wf"], ws["mlp"], bias=b["fc1_bf"], act=hip.ACT_GELU, M=T, stats_in=st,
+                                colsum=b["fc1_cs"], eps=1e-6)
+                hip.gemm_f16_ln(ws["mlp"], b["fc2_w"], x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T, out16=x16,
+                                stats_out=st)
+            else:
+                hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T)
+                hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"], M=T)
+                hip.gemm_f16(ws["h"], b["fc1_w"], out=ws["mlp"], bias=b["fc1_b"], act=hip.ACT_GELU, M=T)
+                hip.gemm_f16(ws["mlp"], b["fc2_w"], out=x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T)
         if out is None:
             out = torch.empty(5329, D, dtype=torch.float16, device=self.device)
         hip.layernorm(x[1:], self.norm_g, self.norm_b, 1e-6, out=out, M=5329)

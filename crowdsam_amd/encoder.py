@@ -24,6 +24,8 @@ class EncoderPlan:
         self.fused_attn = hd == 64
         # round 3: the windowed kernel also exists for head_dim 80 (28 of ViT-H's 32 blocks); its global blocks stay generic
         self.fused_win = hd in (64, 80) and os.environ.get("CSAM_WIN_HD80", "1") != "0"
+        # round 4: the 2 x depth LayerNorm launches are folded into the GEMMs around them (CSAM_LN_FOLD=0: separate kernels)
+        self.ln_fold = os.environ.get("CSAM_LN_FOLD", "1") != "0"
         assert hd <= 128 and hd % 8 == 0, "head_dim must be a multiple of 8, at most 128"
         assert D % 128 == 0, "GEMM tiles need embed_dim % 128 == 0"
         self.D, self.depth, self.heads, self.global_idx = D, depth, heads, tuple(global_idx)
@@ -54,6 +56,12 @@ class EncoderPlan:
                 lin2_w=f16(sd[B + "mlp.lin2.weight"]), lin2_b=f32(sd[B + "mlp.lin2.bias"]),
                 is_global=i in self.global_idx))
             bl = self.blocks[-1]
+            if self.ln_fold:
+                # LayerNorm folded into the projection that consumes it (hip.fold_layernorm / csam_gemm_f16_ln); the
+                # windowed kernel keeps the ORIGINAL qkv bias for its pad tokens (their LayerNorm output is 0, not beta)
+                bl["qkv_wf"], bl["qkv_bf"], bl["qkv_cs"] = hip.fold_layernorm(f32(qkv_w), bl["qkv_b"], bl["ln1_g"], bl["ln1_b"])
+                bl["lin1_wf"], bl["lin1_bf"], bl["lin1_cs"] = hip.fold_layernorm(f32(sd[B + "mlp.lin1.weight"]), bl["lin1_b"],
+                                                                                 bl["ln2_g"], bl["ln2_b"])
             L = 127 if i in self.global_idx else 27
             assert tuple(sd[B + "attn.rel_pos_h"].shape) == (L, hd), "rel-pos table must be (2S-1, head_dim) at 1024^2"
             if self.fused_attn:
@@ -78,7 +86,8 @@ class EncoderPlan:
             attn=e(4096, D), mlp=e(4096, 4 * D), traw=e(heads, 4096, 256, dt=torch.float32),
             n0=e(4096, 256, dt=torch.float32), n1=e(4096, 256),
             col3=e(4096, 2304), n2=e(4096, 256, dt=torch.float32),
-            img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32))
+            img=e(3 * 1024 * 1024, dt=torch.float32), feat=e(4096, 256, dt=torch.float32),
+            x16=e(4096, D), st=e(4096, D // 128, 2, dt=torch.float32))
         # workspaces of the materialised route: only when a block can actually take it (head_dim 80 runs the two
         # head_dim-80 kernels unless CSAM_WIN_HD80=0; ~1.6 GB for ViT-H otherwise never touched)
         if not self.fused_attn and not (self.fused_win and hd == 80):
@@ -104,10 +113,18 @@ class EncoderPlan:
         scale = self.hd ** -0.5
         if not skip_im2col:
             hip.sam_im2col(img_chw_f32, ws["col"])
-        x = hip.gemm_f16(ws["col"], self.patch_w, out=ws["x"], bias=self.patch_b, residual=self.pos)
+        fold = self.ln_fold
+        x16, st = ws["x16"], ws["st"]
+        if fold:     # every projection that writes the residual stream also leaves its fp16 copy + row statistics
+            x = hip.gemm_f16_ln(ws["col"], self.patch_w, ws["x"], bias=self.patch_b, residual=self.pos, out16=x16, stats_out=st)
+        else:
+            x = hip.gemm_f16(ws["col"], self.patch_w, out=ws["x"], bias=self.patch_b, residual=self.pos)
         for b in self.blocks:
-            hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
-            hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
+            if fold:
+                hip.gemm_f16_ln(x16, b["qkv_wf"], ws["qkv"], bias=b["qkv_bf"], stats_in=st, colsum=b["qkv_cs"], eps=1e-6)
+            else:
+                hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"])
+                hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"])
             if not self.fused_attn and self.fused_win and not b["is_global"]:
                 hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
             elif not self.fused_attn and self.fused_win and self.hd == 80:
@@ -120,12 +137,21 @@ class EncoderPlan:
                 hip.flash_attn(ws["qkv"], ws["attn"], 4096, nH, scale, D, relpos=ws["traw"], q_prescaled=True)
             else:
                 hip.win_attn(ws["qkv"], b["qkv_b"], b["relcat"], ws["attn"], D, nH, scale)
-            hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)
-            hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"])
-            hip.gemm_f16(ws["h"], b["lin1_w"], out=ws["mlp"], bias=b["lin1_b"], act=hip.ACT_GELU)
-            hip.gemm_f16(ws["mlp"], b["lin2_w"], out=x, bias=b["lin2_b"], residual=x)
-        hip.add_cast(x, out16=ws["h"])
-        hip.gemm_f16(ws["h"], self.neck0_w, out=ws["n0"])
+            if fold:
+                hip.gemm_f16_ln(ws["attn"], b["proj_w"], x, bias=b["proj_b"], residual=x, out16=x16, stats_out=st)
+                hip.gemm_f16_ln(x16, b["lin1_wf"], ws["mlp"], bias=b["lin1_bf"], act=hip.ACT_GELU, stats_in=st,
+                                colsum=b["lin1_cs"], eps=1e-6)
+                hip.gemm_f16_ln(ws["mlp"], b["lin2_w"], x, bias=b["lin2_b"], residual=x, out16=x16, stats_out=st)
+            else:
+                hip.gemm_f16(ws["attn"], b["proj_w"], out=x, bias=b["proj_b"], residual=x)
+                hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"])
+                hip.gemm_f16(ws["h"], b["lin1_w"], out=ws["mlp"], bias=b["lin1_b"], act=hip.ACT_GELU)
+                hip.gemm_f16(ws["mlp"], b["lin2_w"], out=x, bias=b["lin2_b"], residual=x)
+        if fold:
+            hip.gemm_f16(x16, self.neck0_w, out=ws["n0"])          # the last block's fp16 copy IS the neck's operand
+        else:
+            hip.add_cast(x, out16=ws["h"])
+            hip.gemm_f16(ws["h"], self.neck0_w, out=ws["n0"])
         hip.layernorm(ws["n0"], self.neck1_g, self.neck1_b, 1e-6, out=ws["n1"])
         hip.im2col3x3(ws["n1"], ws["col3"], 256)
         hip.gemm_f16(ws["col3"], self.neck2_w, out=ws["n2"])

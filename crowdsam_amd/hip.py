@@ -23,6 +23,7 @@ _P, _I, _L, _F, _D = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_double
 # name -> argtypes (all return int).  Must match include/csam.h line by line.
 SIGNATURES = {
     "csam_gemm_f16": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I],
+    "csam_gemm_f16_ln": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _P, _I, _F, _P],
     "csam_layernorm": [_P, _P, _L, _I, _P, _L, _I, _P, _P, _I, _I, _F],
     "csam_layernorm_cast": [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P],
     "csam_sam_im2col": [_P, _P, _I, _I, _P, _P, _P],
@@ -255,6 +256,40 @@ def gemm_f16(a, w, out=None, bias=None, act=ACT_NONE, residual=None, colscale=No
          _ptr(residual), 0 if residual is None else residual.stride(0),
          DT_F16 if residual is None else _dt(residual.dtype), act, M, N, K)
     return out
+
+
+def gemm_f16_ln(a, w, out, bias=None, act=ACT_NONE, residual=None, colscale=None, M=None, out16=None, stats_out=None,
+                stats_in=None, eps=1e-6, colsum=None):
+    """csam_gemm_f16 with the LayerNorm that follows / precedes it folded in (include/csam.h: csam_gemm_f16_ln).
+    Producer: ``out`` fp32, ``out16`` [M,N] fp16 copy, ``stats_out`` f32 [M, N/128, 2].  Consumer: ``stats_in`` f32
+    [M, K/128, 2] of the rows of ``a``, ``colsum`` f32 [N] of the gamma-folded fp16 weight ``w``."""
+    assert a.dtype == torch.float16 and w.dtype == torch.float16 and a.stride(-1) == 1 and w.stride(-1) == 1
+    if M is None:
+        M = a.shape[0]
+    K, N = a.shape[1], w.shape[0]
+    assert w.shape[1] == K and out.stride(-1) == 1
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= M * (N // 128) * 2
+    n_part = 0
+    if stats_in is not None:
+        n_part = K // 128
+        assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.numel() >= M * n_part * 2
+        assert colsum is not None and colsum.dtype == torch.float32 and colsum.numel() == N
+    call("csam_gemm_f16_ln", _stream(), _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _dt(out.dtype),
+         _ptr(bias), _ptr(colscale), _ptr(residual), 0 if residual is None else residual.stride(0),
+         DT_F16 if residual is None else _dt(residual.dtype), act, M, N, K, _ptr(out16),
+         0 if out16 is None else out16.stride(0), _ptr(stats_out), _ptr(stats_in), n_part, float(eps), _ptr(colsum))
+    return out
+
+
+def fold_layernorm(w, b, gamma, beta):
+    """(W', b', colsum) of LN(x) W^T + b = rstd (x W'^T - mean colsum) + b':  W' = fp16(W * gamma), colsum = row sums of
+    the fp16 values actually multiplied (so the mean term cancels what the MFMA accumulated), b' = b + W beta (fp32)."""
+    w32 = w.detach().float()
+    wf = (w32 * gamma.detach().float()[None, :]).to(torch.float16).contiguous()
+    colsum = wf.float().sum(1).contiguous()
+    bf = (b.detach().float() + w32 @ beta.detach().float()).contiguous()
+    return wf, bf, colsum
 
 
 # ----------------------------------------------------------------------------------------------

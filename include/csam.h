@@ -48,6 +48,18 @@ const char* csam_last_error(void);
 int csam_gemm_f16(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc,
                   int c_dtype, const float* bias, const float* colscale, const void* residual, long ldr,
                   int r_dtype, int act, int M, int N, int K);
+/* LayerNorm FOLDED into the two GEMMs around it (common.py:38-43 LayerNorm between the residual projections and the
+ * qkv / mlp.lin1 projections of image_encoder.py:166-182, and the same pattern in DINOv2's blocks):
+ *   LN(x) W^T + b = rstd * (x (gamma (.) W)^T - mean * colsum(gamma (.) W)) + (W beta + b)
+ * PRODUCER call (the projection that writes the fp32 residual stream x, c_dtype CSAM_DT_F32): C16_out receives fp16(x),
+ * rowstats_out [M][N/128][2] the (sum, sum of squares) of every row's 128-column slices -- no atomics, deterministic.
+ * CONSUMER call (A_f16 = that fp16 copy, W_f16 = gamma-folded weight, bias = W beta + b): rowstats_in = the producer's
+ * partials with n_partials = K / 128, colsum [N] fp32 = column sums of the fp16 weight actually multiplied, eps as in
+ * the LayerNorm.  Either side may be NULL; with all of them NULL this is csam_gemm_f16. */
+int csam_gemm_f16_ln(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc, int c_dtype,
+                     const float* bias, const float* colscale, const void* residual, long ldr, int r_dtype, int act,
+                     int M, int N, int K, void* C16_out, long ldc16, float* rowstats_out, const float* rowstats_in,
+                     int n_partials, float eps, const float* colsum);
 /* residual row = m % res_mod: adds a per-image [res_mod,N] constant to every prompt's slab of a
  * prompt-stacked GEMM ((keys + key_pe) W = keys W + key_pe W, transformer.py:173-175,186-188). */
 int csam_gemm_f16_resmod(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc,

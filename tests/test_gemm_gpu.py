@@ -111,3 +111,47 @@ def test_linear_f32_small_heads(cuda, M, N, K):
             ref = ref + res.double()
         err = (out.double() - ref).abs().max().item()
         assert err < 2e-5 * max(1.0, ref.abs().max().item()), (M, N, K, err)
+
+
+@pytest.mark.parametrize("M,D,N2", [(4096, 1024, 3072), (5330, 1024, 4096), (4096, 1280, 3840), (777, 128, 384), (4096, 768, 2304)])
+def test_gemm_ln_fold_matches_layernorm_then_gemm(cuda, M, D, N2):
+    """csam_gemm_f16_ln: a residual projection that also emits the fp16 copy + per-row (sum, sum of squares) partials, followed
+    by a projection with the LayerNorm folded in, against fp32 LayerNorm + matmul (common.py:38-43, image_encoder.py:166-182).
+    Shapes: SAM ViT-L qkv (ping-pong kernel), DINOv2 fc1 (tile kernel, ragged M), ViT-H (10 partials), the test encoder
+    (1 partial, odd), ViT-B (6 partials)."""
+    from crowdsam_amd import hip
+    torch.manual_seed(M + D)
+    K1 = 256
+    a = torch.randn(M, K1, device=cuda).half()
+    w1 = (torch.randn(D, K1, device=cuda) * 0.1).half()
+    b1 = torch.randn(D, device=cuda)
+    res = torch.randn(M, D, device=cuda) * 2 + 0.7                   # a row mean that is not small against the spread
+    x = res.clone()
+    x16 = torch.empty(M, D, dtype=torch.float16, device=cuda)
+    st = torch.zeros(M, D // 128, 2, device=cuda)
+    hip.gemm_f16_ln(a, w1, x, bias=b1, residual=x, out16=x16, stats_out=st)
+    x_ref = res + a.float() @ w1.float().t() + b1
+    assert (x - x_ref).abs().max().item() < 2e-3
+    assert torch.equal(x16, x.half())
+    part = x.view(M, D // 128, 128)
+    torch.testing.assert_close(st[..., 0], part.sum(-1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[..., 1], (part * part).sum(-1), rtol=1e-5, atol=1e-2)
+    # consumer
+    g, be = torch.rand(D, device=cuda) + 0.5, torch.randn(D, device=cuda) * 0.3
+    w2, b2 = torch.randn(N2, D, device=cuda) * 0.05, torch.randn(N2, device=cuda)
+    wf, bf, cs = hip.fold_layernorm(w2, b2, g, be)
+    out = torch.empty(M, N2, dtype=torch.float16, device=cuda)
+    hip.gemm_f16_ln(x16, wf, out, bias=bf, stats_in=st, colsum=cs, eps=1e-6)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, be, 1e-6) @ w2.t() + b2
+    err = (out.float() - ref).abs()
+    # the separate-kernel path this replaces, for scale: fp16 LayerNorm output, fp16 weight
+    h = hip.layernorm(x, g, be, 1e-6)
+    old = hip.gemm_f16(h, w2.half(), bias=b2)
+    err_old = (old.float() - ref).abs()
+    print("M=%d D=%d N=%d: folded max %.3e mean %.3e | LayerNorm kernel + GEMM max %.3e mean %.3e | |ref| mean %.3f"
+          % (M, D, N2, err.max().item(), err.mean().item(), err_old.max().item(), err_old.mean().item(), ref.abs().mean().item()))
+    assert err.mean().item() < 2.5 * err_old.mean().item() + 1e-4 and err.max().item() < 2.5 * err_old.max().item() + 1e-3
+    # bitwise repeatable (no atomics anywhere)
+    out2 = torch.empty_like(out)
+    hip.gemm_f16_ln(x16, wf, out2, bias=bf, stats_in=st, colsum=cs, eps=1e-6)
+    assert torch.equal(out, out2)
