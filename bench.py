@@ -377,6 +377,56 @@ def main():
                      "ms_per_step": 1e3 * tc / args.steps, "images_per_sec": args.steps / tc,
                      "kept_masks_per_image": kept_c / args.steps}
         model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = keep_crowd
+    # third leg (rank 0): the tail alone on PERSON-SHAPED masks.  The random-weight masks of the timed
+    # frames are noise-like blobs (worst case for connected components: every 64 x 64 tile is mixed); a real crowd frame keeps
+    # compact person silhouettes.  The same number of kept masks as the timed frames, drawn as filled ellipses with a few
+    # small holes and islands each, go through the same three tail stages: small-region clean-up (connected components x 2 +
+    # NMS), run-length encoding, COCO string packing.  Reported next to the tail of the timed (noise) frames.
+    tail_person = None
+    if crowded and rank == 0:
+        from crowdsam.model import CrowdSAM as _CS
+        from segment_anything_cs.utils.amg import MaskData, coco_encode_rles, mask_to_rle_arrays
+        n_m = max(1, int(round(n_kept / args.steps)))
+        rs = np.random.RandomState(7)
+        Hh = Ww = 1024 if args.frame <= 1024 else args.frame
+        store = torch.zeros(n_m, Hh, Ww, dtype=torch.uint8, device=dev)
+        yy = torch.arange(Hh, device=dev, dtype=torch.float32)[:, None]
+        xx = torch.arange(Ww, device=dev, dtype=torch.float32)[None, :]
+        for i in range(n_m):                       # a standing person: ~35 x 90 px half-axes, 3 pinholes, 2 specks
+            cy, cx = rs.uniform(100, Hh - 100), rs.uniform(50, Ww - 50)
+            ay, ax = rs.uniform(50, 130), rs.uniform(18, 50)
+            m = ((yy - cy) / ay) ** 2 + ((xx - cx) / ax) ** 2 <= 1.0
+            for _ in range(3):
+                hy, hx = int(cy + rs.uniform(-0.5, 0.5) * ay), int(cx + rs.uniform(-0.4, 0.4) * ax)
+                m[hy:hy + 3, hx:hx + 3] = False
+            for _ in range(2):
+                sy, sx = int(rs.uniform(0, Hh - 6)), int(rs.uniform(0, Ww - 6))
+                m[sy:sy + 4, sx:sx + 4] = True
+            store[i] = m
+        ref_store = store.clone()
+
+        def tail_once():
+            store.copy_(ref_store)
+            data = MaskData(mask_slots=torch.arange(n_m, dtype=torch.int32, device=dev),
+                            boxes=torch.zeros(n_m, 4, dtype=torch.long, device=dev),
+                            iou_preds=torch.linspace(1.0, 0.5, n_m, device=dev))
+            data = _CS.postprocess_small_regions(data, model.min_mask_region_area, 1.0, mask_store=store)
+            rl = mask_to_rle_arrays(store, idx=data["mask_slots"].contiguous())
+            return len(coco_encode_rles(rl))
+
+        tail_once()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        kept_t = 0
+        for _ in range(args.steps):
+            kept_t += tail_once()
+        torch.cuda.synchronize()
+        tt = time.perf_counter() - tt
+        tail_person = {"what": "small-region clean-up + RLE + COCO strings ALONE on %d person-shaped masks per image (filled "
+                               "ellipses with pinholes and specks, 1024^2) -- the tail of a real crowd frame; the timed frames' "
+                               "noise-like random-weight masks are the connected-components worst case" % n_m,
+                       "ms_per_image": 1e3 * tt / args.steps, "masks": kept_t / args.steps,
+                       "includes": "one device copy of the mask stack per repeat (restores the masks the clean-up edits in place)"}
     # roofline leg: the same K steps once more with HIP events around every launch of the dominant kernel
     # (the timed region above replays hipGraphs, inside which per-launch events cannot be recorded).
     timer = None
@@ -429,6 +479,8 @@ def main():
                                                  n_kept / args.steps))
         if collapsed is not None:
             res["config"]["nms_collapsed_leg"] = collapsed
+        if tail_person is not None:
+            res["config"]["tail_on_person_shaped_masks"] = tail_person
         if timer is not None:
             full = timer.summary()
             summ = {k: v for k, v in full.items() if k in GEMM_NAMES}

@@ -67,6 +67,7 @@ class DinoPlan:
         # round 4: LayerNorm folded into the qkv / fc1 projections (csam_gemm_f16_ln); block 0's first LayerNorm stays a
         # kernel (its input's cls row comes from a copy, not from a projection)
         self.ln_fold = os.environ.get("CSAM_LN_FOLD", "1") != "0"
+        self.fc1_split = 4096 if os.environ.get("CSAM_DINO_FC1_SPLIT", "0") == "1" else 1 << 30      # A/B: no end-to-end gain measured
         if self.ln_fold:
             for i, bl in enumerate(self.blocks):
                 B = f"blocks.{i}."
@@ -110,8 +111,15 @@ class DinoPlan:
             if fold:
                 hip.gemm_f16_ln(ws["attn"], b["proj_w"], x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T, out16=x16,
                                 stats_out=st)
-                hip.gemm_f16_ln(x16, b["fc1_wf"], ws["mlp"], bias=b["fc1_bf"], act=hip.ACT_GELU, M=T, stats_in=st,
+                # fc1 in two row ranges: 4096 rows are exactly ONE round of the 256 x 256 ping-pong kernel (16 x 16 tiles on
+                # 256 CUs, as in the SAM encoder); all 5330 rows would be 336 tiles = 1.3 rounds and fall back to the
+                # 128 x 128 kernel (77 us at 580 TFLOP/s).  The remaining 1234 rows take that kernel alone.
+                S = min(self.fc1_split, T)
+                hip.gemm_f16_ln(x16[:S], b["fc1_wf"], ws["mlp"][:S], bias=b["fc1_bf"], act=hip.ACT_GELU, M=S, stats_in=st[:S],
                                 colsum=b["fc1_cs"], eps=1e-6)
+                if T > S:
+                    hip.gemm_f16_ln(x16[S:], b["fc1_wf"], ws["mlp"][S:], bias=b["fc1_bf"], act=hip.ACT_GELU, M=T - S,
+                                    stats_in=st[S:], colsum=b["fc1_cs"], eps=1e-6)
                 hip.gemm_f16_ln(ws["mlp"], b["fc2_w"], x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T, out16=x16,
                                 stats_out=st)
             else:
