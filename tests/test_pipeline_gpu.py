@@ -15,7 +15,9 @@ MASK_BOUNDS = {"golden": (0.9867, 0.0133),      # 0.994707 / 5.30e-3  (reference
                "multicrop": (0.9967, 0.0033),   # 0.998705 / 1.30e-3
                "max_size": (0.9953, 0.0047),    # 0.998123 / 1.88e-3
                "vit_b_sample": (0.958, None)}   # 0.98324 on every 8th pixel of every 8th row (noise masks, 64 of them)
-BOX_PX, STAB_RTOL, STAB_ATOL = 3, 0.08, 2e-3      # reference golden run: provisional, see the printout
+# reference golden run (3 x 8 EPS): measured score error 3.6e-4, box difference 0 px, stability 2.4e-4 abs / 8.8e-3 rel -> x 2.5
+# (a box side moves by whole pixels: one pixel is the smallest non-zero bound)
+GOLD_SCORE_ATOL, BOX_PX, STAB_RTOL, STAB_ATOL = 1e-3, 1, 0.022, 6e-4
 G = os.path.join(os.path.dirname(__file__), "golden")
 ARCH = "vit_test128"
 
@@ -84,7 +86,7 @@ def test_generate_matches_reference_golden(model):
     np.testing.assert_array_equal(points, g["points"])
     np.testing.assert_array_equal(out["categories"], g["categories"])
     # values: fp16 operand tolerance on scores; boxes come from thresholded masks -> a few pixels
-    np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=GOLD_SCORE_ATOL)
     sd_ = np.abs(out["stability_score"] - g["stability_score"])
     print("reference golden: max |score| error %.2e, max box difference %.1f px, stability error max abs %.2e / max rel %.2e"
           % (np.abs(scores - g["scores"]).max(), np.abs(boxes - g["boxes"]).max(), sd_.max(),
