@@ -313,6 +313,11 @@ def main():
     def timed_leg(collect_rows):
         kept = pre = 0
         rws = [np.zeros((0, 6), np.float32)]
+        if not args.serial:
+            # one-time setup of the depth-2 pipeline, outside every timed region: the decoder keeps per-image constants in
+            # two slots, each with its own captured hipGraphs -- this pair of calls captures the second slot's
+            model.generate(frames[0], next_image=frames[0])
+            model.generate(frames[0])
         for i in range(args.warmup):
             model.generate(frames[i])            # no look-ahead: nothing of a timed frame may run outside the timed region
         barrier()

@@ -15,6 +15,7 @@ re-designed for the GPU:
 * when pruning is impossible (``filter_thresh`` = inf: the dense-sweep benchmark mode) the whole
   sweep is queued without any host synchronisation.
 """
+import contextlib
 import logging
 import math
 import os
@@ -117,6 +118,7 @@ class CrowdSAM:
         self._next_image = None      # depth-2 pipeline (generate(next_image=...)): see _prefetch
         self._prefetched = None
         self._pf_stream = None
+        self._hi_stream = None
 
     def load_sam_model(self, sam_model, sam_arch, sam_checkpoint, sam_adapter_checkpoint, dino_model, n_class,
                        sam_state_dict=None):
@@ -257,12 +259,13 @@ class CrowdSAM:
 
     _CROP_STATE = ("orig_image", "_frame_u8", "_frame_f32", "_image_np", "image_hw", "downscale")
 
-    def _prefetch(self, image):
-        """Depth-2 pipeline: crop_image + predictor.set_image of the NEXT frame on a side stream.  Called once the current
-        frame's sweep is queued (everything that reads the encoder features, the DINOv2 tokens and the decoder's per-image
-        constants -- the buffers set_image overwrites -- is ordered before it by the stream wait); the current frame's
-        tail only touches the mask store and its own records.  The crop state of the current frame is put back afterwards:
-        its tail still needs ``downscale`` & co."""
+    def _prefetch(self, image, early):
+        """Depth-2 pipeline: upload + resize + SAM encoder || DINOv2 + the decoder's per-image constants of the NEXT frame on
+        a side stream, into the decoder plan's inactive slot (SamPredictor.prefetch_image), without touching anything the
+        current frame still reads.  ``early`` (EPS sweeps: 16 small, latency-bound prompt batches that leave the GPU mostly
+        idle): called BEFORE the sweep is queued, so the encoders run beside the whole sweep; otherwise (dense sweep: the
+        persistent decoder kernels own every CU) AFTER the sweep is queued, beside the tail only.  The crop state of the
+        current frame is put back afterwards: its tail still needs ``downscale`` & co."""
         main = torch.cuda.current_stream()
         if self._pf_stream is None:
             self._pf_stream = torch.cuda.Stream(device=self.device)
@@ -272,16 +275,17 @@ class CrowdSAM:
         h, w = image.shape[:2]
         saved = {k: getattr(self, k) for k in self._CROP_STATE}
         with torch.cuda.stream(side):
-            # the one H2D of the frame and its resize write fresh tensors only: they go up WHILE the sweep runs ...
+            # the one H2D of the frame and its resize write fresh tensors only: they go up first ...
             self.crop_image(image, [0, 0, w, h])
-            # ... the encoders and the decoder constants overwrite what the sweep reads: behind it
+            # ... the encoders' workspaces were last used by this stream (the previous prefetch) or by the main stream's
+            # set_image before this point; the inactive decoder slot was last read by the frame before the current one
             side.wait_stream(main)
-            self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
+            bundle = self.predictor.prefetch_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
         state = {k: getattr(self, k) for k in self._CROP_STATE}
         for t in (state["_frame_u8"], state["_frame_f32"]):
             if torch.is_tensor(t):
                 t.record_stream(main)           # allocated on the side stream, read on the main one later
-        self._prefetched = dict(shape=image.shape, crop_box=[0, 0, w, h], state=state)
+        self._prefetched = None if bundle is None else dict(shape=image.shape, crop_box=[0, 0, w, h], state=state, bundle=bundle)
         for k, v in saved.items():
             setattr(self, k, v)
 
@@ -292,9 +296,10 @@ class CrowdSAM:
             torch.cuda.current_stream().wait_stream(self._pf_stream)     # a prefetch (used or not) owns the shared buffers
         img_np = image if isinstance(image, np.ndarray) else None
         if (pf is not None and img_np is not None and pf["crop_box"] == list(crop_box) and pf["shape"] == img_np.shape
-                and pf["state"]["orig_image"] is img_np and self.predictor.is_image_set):
+                and pf["state"]["orig_image"] is img_np):
             for k, v in pf["state"].items():                             # the frame was prefetched: adopt its state
                 setattr(self, k, v)
+            self.predictor.adopt_prefetched(pf["bundle"])
         else:
             self.crop_image(image, crop_box)
             self.predictor.set_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
@@ -311,6 +316,11 @@ class CrowdSAM:
         t0 = self._tick("sample_prompts", t0)
         store = self._result_store(*self.predictor.original_size)
         store["counter"].zero_()
+        early = self._next_image is not None and (prune or self.points_per_batch < 256)
+        if early:
+            # EPS sweep: small prompt batches with the GPU mostly idle -> the next frame's encoders run beside the whole sweep
+            self._prefetch(self._next_image, early=True)
+            self._next_image = None
 
         # :230 truncation (already done, on the device, for the device-resident sampler)
         points = points_for_image if dev_sampler else points_for_image.astype("int")
@@ -331,6 +341,16 @@ class CrowdSAM:
         count = 0
         n_batches = 0
         batch_size = self.points_per_batch
+        # With the next frame's encoders running beside it (early prefetch), the EPS sweep -- a chain of ~60 short kernels per
+        # batch, each waiting for the one before -- goes onto a HIGH-priority stream: its workgroups are dispatched ahead of the
+        # encoder GEMMs' whenever a CU frees up, so the chain's latency stays close to what it is on an idle GPU
+        sweep_ctx = contextlib.ExitStack()
+        if early:
+            if self._hi_stream is None:
+                self._hi_stream = torch.cuda.Stream(device=dev, priority=-1)
+            self._hi_stream.wait_stream(torch.cuda.current_stream())
+            main_stream = torch.cuda.current_stream()
+            sweep_ctx.enter_context(torch.cuda.stream(self._hi_stream))
         if dev_sampler and len(points) > 0:
             # Device-resident sampler (csam_eps_select / csam_occupancy_prune): the list and one alive flag per point stay
             # on the GPU; a round takes the first batch_size alive points in list order -- the reference's
@@ -391,13 +411,15 @@ class CrowdSAM:
                     self._tick("eps.prune", tb)
                 count += batch_size
                 n_batches += 1
+        sweep_ctx.close()
+        if early:
+            main_stream.wait_stream(self._hi_stream)
+        self.predictor.reset_image()
         if self._next_image is not None:
-            # the sweep is queued and nothing below reads the predictor: the next frame's set_image starts now, beside
-            # this frame's tail (it leaves the predictor set for that frame, hence no reset_image here)
-            self._prefetch(self._next_image)
+            # dense sweep: it is queued and nothing below reads the predictor -- the next frame's encoders start now, beside
+            # this frame's tail
+            self._prefetch(self._next_image, early=False)
             self._next_image = None
-        else:
-            self.predictor.reset_image()
         t0 = self._tick("eps_sweep", t0)
         if n_batches == 0:
             return None

@@ -216,6 +216,11 @@ class DecoderPlan:
         self.dino_proj_b = f32(sd[M + "dino_proj.bias"])
         self.taps = _adjoint_taps().to(device)
         self.adj_tables = _adjoint_mfma_tables().to(device)
+        # Per-image constants live in one of TWO slots (round 4): the depth-2 image pipeline builds frame i+1's constants
+        # (slot 1 - k) while the prompt batches of frame i still read slot k.  ``self.state`` is the ACTIVE slot's dict.
+        self.states = [None, None]
+        self.state_graphs = [None, None]
+        self.slot = 0
         self.state = None
         self.batch_graphs = hip.GraphCache()
         self._alloc(max_batch)
@@ -267,22 +272,31 @@ class DecoderPlan:
         self.batch_graphs.clear()
 
     # ------------------------------------------------------------------------------------------
-    def _alloc_state(self):
+    def _alloc_state(self, slot=0):
         dev = self.device
         e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=dev)
         f = torch.float32
-        self.state = dict(src16=e(T_IMG, 256), srcpe16=e(T_IMG, 256), src32=e(T_IMG, 256, dt=f), kv0=e(T_IMG, 256),
+        self.states[slot] = dict(src16=e(T_IMG, 256), srcpe16=e(T_IMG, 256), src32=e(T_IMG, 256, dt=f), kv0=e(T_IMG, 256),
                           qi0=e(T_IMG, 128), k0=e(T_IMG, 128), v0t=e(128, T_IMG), k0h=e(8, 256, 16, 16), v0h=e(8, 256, 16, 16), G=e(N_DINO, 256, dt=f),
                           GT=e(256, N_DINO_PAD), g16=e(N_DINO, 256), fgh=e(N_DINO, 256, dt=f),
                           fg=e(N_DINO, self.n_class, dt=f), feat=e(T_IMG, 256, dt=f), dtok=e(N_DINO_PAD, 1024))
-        self.state_graph = hip.GraphCache()
+        self.state_graphs[slot] = hip.GraphCache()
 
-    def set_image(self, feat_tok, dino_tok16):
+    def activate(self, slot):
+        """Make ``slot`` the image the prompt batches decode against (its constants were built by set_image(..., slot))."""
+        assert self.states[slot] is not None
+        self.slot, self.state = slot, self.states[slot]
+
+    def set_image(self, feat_tok, dino_tok16, slot=None, activate=True):
         """feat_tok f32 [4096,256] (encoder output, token-major); dino_tok16 f16 [5376,1024] (rows >= 5329 zero).
-        Builds the per-image constants into STATIC buffers (graph-replayable; valid until the next image)."""
-        if self.state is None:
-            self._alloc_state()
-        st = self.state
+        Builds the per-image constants into STATIC buffers (graph-replayable; valid until the slot's next image).
+        ``slot`` None: the active slot.  ``activate`` False: build only (the look-ahead frame of the image pipeline)."""
+        slot = self.slot if slot is None else slot
+        if self.states[slot] is None:
+            self._alloc_state(slot)
+        st = self.states[slot]
+        if activate:
+            self.activate(slot)
         L0 = self.layers[0]
         # the per-image graph reads the plan's OWN operand buffers, and every call copies its inputs into them (4 MB +
         # 11 MB device-to-device, a few microseconds) before the replay: a graph that captured the first caller's
@@ -316,7 +330,7 @@ class DecoderPlan:
             hip.linear_f32(st["fgh"], w2, b2, out=st["fg"])
             return st
 
-        return self.state_graph.run("image", launch)
+        return self.state_graphs[slot].run("image", launch)
 
     def fg_logits(self):
         """[5329, n_class] fp32 FG-prior logits on the 73x73 grid (computed by set_image)."""
@@ -331,7 +345,7 @@ class DecoderPlan:
             self._alloc(B)
         c = self.ws["coords"][:B]
         c.copy_(coords_f32)
-        return self.batch_graphs.run(B, lambda: self._run_batch(c))
+        return self.batch_graphs.run((B, self.slot), lambda: self._run_batch(c))     # the graph holds the slot's pointers
 
     def _run_batch(self, coords_f32):
         B = coords_f32.shape[0]

@@ -79,37 +79,82 @@ class SamPredictor:
             f"set_torch_image input must be BCHW with long side {size}."
         if cal_image:
             self.reset_image()
-            self.original_size = tuple(original_image_size)
-            self.input_size = tuple(transformed_image.shape[-2:])
-            raw = transformed_image[0].to(self.device).float().contiguous()      # [3,h,w], 0..255
-            if self._dtok16 is None or self._dtok16.device != raw.device:
-                self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
-            if isinstance(self.dino_model, DinoV2) and not _TWO_STREAMS:
-                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
-                self.dino_model.patch_tokens16(raw, self._dtok16)
-            elif isinstance(self.dino_model, DinoV2):
-                # the two backbones are independent until the decoder: DINOv2 runs on a side stream next to the SAM
-                # encoder, so one's under-filled launches (N = 1024 GEMMs, LayerNorms, the 2.6-workgroups-per-CU
-                # attention grid) fill the other's idle CUs
-                main = torch.cuda.current_stream()
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=raw.device)
-                side = self._side_stream
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.dino_model.patch_tokens16(raw, self._dtok16)
-                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
-                main.wait_stream(side)
-            else:   # third-party DINO object: feed it the reference's tensor (predictor.py:104-106)
-                self._feat_tok = self.model.image_encoder.forward_tokens(raw)
-                x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
-                tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
-                self._dtok16[:N_DINO].copy_(tok.reshape(N_DINO, -1))
-            self._plan = self.model.decoder_plan()
-            self._plan.set_image(self._feat_tok, self._dtok16)
-            self.is_image_set = True
+            self._adopt(self._encode(transformed_image, original_image_size, prefetch=False))
         if transformed_mask is not None:
             return self.model.preprocess(transformed_mask)
+
+    def _encode(self, transformed_image, original_image_size, prefetch):
+        """SAM encoder || DINOv2 + the decoder's per-image constants for one frame -> a bundle for _adopt().
+        ``prefetch``: the constants go into the decoder plan's INACTIVE slot and nothing of the predictor's current image
+        is touched (the look-ahead frame of CrowdSAM's depth-2 pipeline: the current frame's prompt batches keep decoding
+        against the active slot while this runs on another stream)."""
+        raw = transformed_image[0].to(self.device).float().contiguous()      # [3,h,w], 0..255
+        if self._dtok16 is None or self._dtok16.device != raw.device:
+            self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
+        if isinstance(self.dino_model, DinoV2) and not _TWO_STREAMS:
+            feat = self.model.image_encoder.forward_tokens(raw)
+            self.dino_model.patch_tokens16(raw, self._dtok16)
+        elif isinstance(self.dino_model, DinoV2):
+            # the two backbones are independent until the decoder: DINOv2 runs on a side stream next to the SAM
+            # encoder, so one's under-filled launches (N = 1024 GEMMs, LayerNorms, the 2.6-workgroups-per-CU
+            # attention grid) fill the other's idle CUs
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=raw.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.dino_model.patch_tokens16(raw, self._dtok16)
+            feat = self.model.image_encoder.forward_tokens(raw)
+            main.wait_stream(side)
+        else:   # third-party DINO object: feed it the reference's tensor (predictor.py:104-106)
+            feat = self.model.image_encoder.forward_tokens(raw)
+            x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
+            tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
+            self._dtok16[:N_DINO].copy_(tok.reshape(N_DINO, -1))
+        plan = self.model.decoder_plan()
+        slot = (1 - plan.slot) if prefetch else plan.slot
+        plan.set_image(feat, self._dtok16, slot=slot, activate=not prefetch)      # copies both into the slot's own buffers
+        return dict(original_size=tuple(original_image_size), input_size=tuple(transformed_image.shape[-2:]), feat=feat,
+                    plan=plan, slot=slot)
+
+    def _adopt(self, b):
+        """Make an _encode() bundle the predictor's current image."""
+        self.original_size, self.input_size = b["original_size"], b["input_size"]
+        self._feat_tok, self._plan = b["feat"], b["plan"]
+        self._plan.activate(b["slot"])
+        self.is_image_set = True
+
+    @torch.no_grad()
+    def prefetch_image(self, image):
+        """Build extension (depth-2 image pipeline): encode a frame that is already on the device -- uint8 HWC tensor or the
+        (uint8, fp32 CHW) pair of crowdsam.utils.resize_frame_device -- WITHOUT making it the current image.  Returns a
+        bundle for adopt_prefetched(), or None when the frame needs the general set_image route (then nothing is done).
+        The encoder's own output buffer is shared, so ``features`` of the current image is not meaningful afterwards; the
+        decoder reads its per-slot copies."""
+        f32 = None
+        if isinstance(image, tuple):
+            image, f32 = image
+        if not torch.is_tensor(image) or not image.is_cuda:
+            return None
+        h, w = image.shape[:2]
+        size = self.model.image_encoder.img_size
+        if max(h, w) == size:
+            if f32 is None:
+                f32 = hip.u8hwc_to_f32chw(image)
+        elif max(h, w) <= 3.5 * size:
+            from crowdsam_amd.resize import pil_bilinear_tables_device
+            th, tw = self.transform.get_preprocess_shape(h, w, size)
+            dev = str(image.device)
+            _, f32 = hip.pil_resize_bilinear_u8(image.contiguous(), (th, tw), pil_bilinear_tables_device(w, tw, dev),
+                                                pil_bilinear_tables_device(h, th, dev))
+        else:
+            return None
+        return self._encode(f32[None], (h, w), prefetch=True)
+
+    def adopt_prefetched(self, bundle):
+        self.reset_image()
+        self._adopt(bundle)
 
     # lazily materialised API views of the resident state
     @property
