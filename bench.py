@@ -38,9 +38,8 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
     needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", "r0%d_pmc_traffic.json" % r) for r in (4, 3, 2)) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     try:
         d = json.load(open(path))
         rows = [v for k, v in d["kernels"].items() if k.startswith(kernel_prefix)]
@@ -91,7 +90,7 @@ def encoder_only(args, rank, world, dev, sam_sd):
     # per-kernel-family split on an instrumented (eager, event-bracketed) repeat
     names = ["csam_gemm_f16", "csam_win_attn", "csam_flash_attn", "csam_layernorm", "csam_sam_im2col", "csam_im2col3x3",
              "csam_add_cast", "csam_gemm_f16_batched", "csam_head_gather", "csam_softmax_relpos", "csam_head_scatter",
-             "csam_ln_gemm_f16"]
+             "csam_gemm_f16_ln"]
     timer = hip.KernelTimer(names)
     hip.set_timer(timer)
     for _ in range(min(args.steps, 5)):
@@ -441,7 +440,7 @@ def main():
         import segment_anything_cs.predictor as _pred
         two = _pred._TWO_STREAMS
         _pred._TWO_STREAMS = False
-        GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
+        GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_ln", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
         SWEEP_NAMES = ["csam_i2t_t2i", "csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_i2t_rank_proj", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_shared",
                        "csam_upscale_fused", "csam_upscale_stream",
                        "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_post_scored", "csam_mask_write"]

@@ -170,6 +170,9 @@ class KernelTimer:
         if name == "csam_gemm_f16_batched":
             M, N, K, batch = args[-4:]
             return 2.0 * M * N * K * batch
+        if name == "csam_gemm_f16_ln":        # (..., act, M, N, K, C16_out, ldc16, rowstats_out, rowstats_in, n_partials, eps, colsum)
+            M, N, K = args[14:17]
+            return 2.0 * M * N * K
         M, N, K = args[-3:]
         return 2.0 * M * N * K
 

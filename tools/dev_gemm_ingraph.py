@@ -61,6 +61,28 @@ def timed_gemm(a, w, out=None, bias=None, act=hip.ACT_NONE, residual=None, colsc
 
 
 hip.gemm_f16 = timed_gemm
+orig_ln = hip.gemm_f16_ln
+calls_ln = []
+
+
+def timed_gemm_ln(a, w, out, bias=None, act=hip.ACT_NONE, residual=None, colscale=None, M=None, out16=None, stats_out=None,
+                  stats_in=None, eps=1e-6, colsum=None):
+    m = a.shape[0] if M is None else M
+    ep = ("f32+res" if residual is not None else ("gelu" if act == hip.ACT_GELU else "f16")) + \
+        (" ln-out" if stats_out is not None else "") + (" ln-in" if stats_in is not None else "")
+    key = (m, w.shape[0], a.shape[1], ep)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = orig_ln(a, w, out, bias=bias, act=act, residual=residual, colscale=colscale, M=M, out16=out16, stats_out=stats_out,
+                stats_in=stats_in, eps=eps, colsum=colsum)
+    e1.record()
+    kw = dict(bias=bias, act=act, residual=residual, colscale=colscale, M=M, out16=out16, stats_out=stats_out, stats_in=stats_in,
+              eps=eps, colsum=colsum)
+    calls.append((key, e0, e1, ("ln", a, w, out, kw)))
+    return r
+
+
+hip.gemm_f16_ln = timed_gemm_ln
 import crowdsam_amd.encoder as _enc
 NF = 5
 t_seq0 = time.perf_counter()
@@ -69,6 +91,7 @@ for _ in range(NF):
 clk_seq = clock_mhz()
 torch.cuda.synchronize()
 hip.gemm_f16 = orig
+hip.gemm_f16_ln = orig_ln
 args_by_key = {}
 for key, e0, e1, a in calls:
     records.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)
@@ -76,28 +99,34 @@ for key, e0, e1, a in calls:
 print("SAM ViT-L encoder, eager op sequence, %d forwards; shader clock during the sequence %.0f MHz" % (NF, clk_seq))
 
 
-def iso(a, n=20):
+def launch(a):
+    if a[0] == "ln":
+        _, aa, w, out, kw = a
+        return orig_ln(aa, w, out, **kw)
     aa, w, out, bias, act, residual, colscale, out_dtype, M = a
+    return orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+
+
+def iso(a, n=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+    launch(a)
     e0.record()
     for _ in range(n):
-        orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+        launch(a)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
 
 
 def load(seconds, a):
-    aa, w, out, bias, act, residual, colscale, out_dtype, M = a
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(200):
-            orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+            launch(a)
         torch.cuda.synchronize()
 
 
-print("%-28s %6s | %9s %7s | %9s %7s %5s | %9s %7s %5s" % ("M x N x K epilogue", "calls", "in-seq us", "TF/s", "cold us", "TF/s", "MHz", "hot us", "TF/s", "MHz"))
+print("%-36s %6s | %9s %7s | %9s %7s %5s | %9s %7s %5s" % ("M x N x K epilogue", "calls", "in-seq us", "TF/s", "cold us", "TF/s", "MHz", "hot us", "TF/s", "MHz"))
 tot_seq = tot_cold = tot_hot = 0.0
 for key, ts in sorted(records.items(), key=lambda kv: -sum(kv[1])):
     m, n, k, ep = key
@@ -112,13 +141,12 @@ for key, ts in sorted(records.items(), key=lambda kv: -sum(kv[1])):
     time.sleep(0.5)
     load(2.0, a)
     # clock while the hot launches are in flight
-    aa, w, out, bias, act, residual, colscale, out_dtype, M = a
     for _ in range(300):
-        orig(aa, w, out=out, bias=bias, act=act, residual=residual, colscale=colscale, out_dtype=out_dtype, M=M)
+        launch(a)
     clk_hot = clock_mhz()
     t_hot = iso(a)
     per_fwd = len(ts) / NF
     tot_seq += t_seq * per_fwd; tot_cold += t_cold * per_fwd; tot_hot += t_hot * per_fwd
-    print("%5d x %4d x %4d %-8s %6d | %9.1f %7.0f | %9.1f %7.0f %5.0f | %9.1f %7.0f %5.0f"
+    print("%5d x %4d x %4d %-16s %6d | %9.1f %7.0f | %9.1f %7.0f %5.0f | %9.1f %7.0f %5.0f"
           % (m, n, k, ep, per_fwd, t_seq, fl / t_seq / 1e6, t_cold, fl / t_cold / 1e6, clk_cold, t_hot, fl / t_hot / 1e6, clk_hot))
 print("GEMM time per forward: in-sequence %.0f us, isolated cold %.0f us, isolated hot %.0f us" % (tot_seq, tot_cold, tot_hot))
