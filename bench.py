@@ -441,7 +441,7 @@ def main():
         two = _pred._TWO_STREAMS
         _pred._TWO_STREAMS = False
         GEMM_NAMES = ["csam_gemm_f16", "csam_gemm_f16_ln", "csam_gemm_f16_resmod", "csam_gemm_f16_batched"]
-        SWEEP_NAMES = ["csam_i2t_t2i", "csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_i2t_rank_proj", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_shared",
+        SWEEP_NAMES = ["csam_i2t_t2i", "csam_i2t_t2i_fold", "csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_i2t_rank_proj", "csam_t2i_fused", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_shared",
                        "csam_upscale_fused", "csam_upscale_stream",
                        "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_post_scored", "csam_mask_write"]
         timer = hip.KernelTimer(GEMM_NAMES + SWEEP_NAMES)
@@ -497,7 +497,7 @@ def main():
             if sweep_ms > 0 and args.mode == "dense":
                 # csam_i2t_t2i folds the two token->image reads into the image->token writes: the sweep the kernels
                 # EXECUTE then has four key-state passes, and the roofline is priced on those (10.75 MB), not on six
-                fused_passes = "csam_i2t_t2i" in full and full["csam_i2t_t2i"]["calls"] > 0
+                fused_passes = any(k in full and full[k]["calls"] > 0 for k in ("csam_i2t_t2i", "csam_i2t_t2i_fold"))
                 per_prompt = 14.94e6 - (2 * 4096 * 256 * 2 if fused_passes else 0)
                 gbs = per_prompt * n_prompts * args.steps / (sweep_ms * 1e-3) / 1e9
                 res["roofline_decoder_sweep"] = {

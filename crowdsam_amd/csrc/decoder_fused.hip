@@ -728,8 +728,10 @@ struct IrArgs {
 };
 
 // M_b^T[c][slot] = sum_d Wo[c][head*16 + d] v[b][j][head*16 + d]  (j = 7: zero), slot order as in the header
+// bo_fold (csam_i2t_t2i_fold bit 0): the out-projection bias rides in M_b -- each valid slot carries bo[c] / 8, and the softmax
+// weights of a head's 7 keys sum to 1, so the 8 heads together add exactly bo[c] (up to the fp16 rounding of the M entries).
 __global__ __launch_bounds__(256) void i2t_rank_prep_kernel(const half_t* __restrict__ v, const half_t* __restrict__ Wo,
-                                                            half_t* __restrict__ M) {
+                                                            half_t* __restrict__ M, const float* __restrict__ bo_fold = nullptr) {
   __shared__ float vs[7 * 128];
   const int b = blockIdx.x, c = threadIdx.x;
   for (int i = c; i < 7 * 128; i += 256) vs[i] = (float)v[(long)b * 7 * 128 + i];
@@ -753,6 +755,7 @@ __global__ __launch_bounds__(256) void i2t_rank_prep_kernel(const half_t* __rest
       if (j < 7) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) acc = fmaf(w[head * 16 + d], vs[j * 128 + head * 16 + d], acc);
+        if (bo_fold) acc += 0.125f * bo_fold[c];
       }
       o[e] = (half_t)acc;
     }
@@ -2840,7 +2843,10 @@ struct IF {
   static constexpr int SMEM = PAR + 3 * 256 * 4;
 };
 
-template <bool PROJ>
+// FOLD (csam_i2t_t2i_fold): bit 0 = the out-projection bias is in M_b (no bias rows read from LDS: the residual's identity
+// MFMAs start from zero); bit 1 = the LayerNorm's gamma / beta are folded into the CONSUMERS of these keys (upscaler first conv,
+// final attention), the producer stores the plain normalised values (layer 1 only: its keys have no residual consumer).
+template <bool PROJ, int FOLD>
 __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, int prompts_per_wg) {
   typedef IF<PROJ> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2969,8 +2975,11 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         for (int nj = 0; nj < 8; ++nj) {
           half8_t xf;
           __builtin_memcpy(&xf, &xres[nj], 16);
-          const floatx4 b0 = *(const floatx4*)(par + nj * 32 + fg * 4);
-          const floatx4 b1 = *(const floatx4*)(par + nj * 32 + 16 + fg * 4);
+          floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+          if constexpr (!(FOLD & 1)) {
+            b0 = *(const floatx4*)(par + nj * 32 + fg * 4);
+            b1 = *(const floatx4*)(par + nj * 32 + 16 + fg * 4);
+          }
           acc[2 * nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_lo, xf, b0, 0, 0, 0);
           acc[2 * nj + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_hi, xf, b1, 0, 0, 0);
         }
@@ -3018,12 +3027,15 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
 #pragma unroll
         for (int ni = 0; ni < 16; ++ni) {
           if ((ni & 3) == 0) asm volatile("" ::: "memory");
-          const floatx4 gm = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
-          const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
-          const float2_t g0 = {gm[0], gm[1]}, g1 = {gm[2], gm[3]}, b0 = {be[0], be[1]}, b1 = {be[2], be[3]};
           const float2_t v0 = {acc[ni][0], acc[ni][1]}, v1 = {acc[ni][2], acc[ni][3]};
-          const float2_t y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(v0, rs2, nm2), g0, b0);
-          const float2_t y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(v1, rs2, nm2), g1, b1);
+          float2_t y0 = __builtin_elementwise_fma(v0, rs2, nm2), y1 = __builtin_elementwise_fma(v1, rs2, nm2);
+          if constexpr (!(FOLD & 2)) {
+            const floatx4 gm = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
+            const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
+            const float2_t g0 = {gm[0], gm[1]}, g1 = {gm[2], gm[3]}, b0 = {be[0], be[1]}, b1 = {be[2], be[3]};
+            y0 = __builtin_elementwise_fma(y0, g0, b0);
+            y1 = __builtin_elementwise_fma(y1, g1, b1);
+          }
           const int chunk = ni * 2 + (fg >> 1);
           *(half4_t*)(slice + fr * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
               half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
@@ -3218,15 +3230,17 @@ extern "C" int csam_dbg_set_fuse_ts(void* p) { return (int)hipMemcpyToSymbol(HIP
 #endif
 extern "C" long csam_i2t_t2i_workspace_bytes(int B) { return (long)B * (IR_M_BYTES + IR_KP_BYTES + 64 * 256 * 2); }
 
-extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
-                            const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
-                            const float* bo, const float* gamma, const float* beta, float eps, void* out_f16,
-                            const void* t2i_Wk_f16, const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T,
-                            void* workspace, long workspace_bytes) {
+static int i2t_t2i_launch(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                          const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
+                          const float* bo, const float* gamma, const float* beta, float eps, void* out_f16,
+                          const void* t2i_Wk_f16, const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T,
+                          void* workspace, long workspace_bytes, int fold) {
   CSAM_REQUIRE(X_f16 && Q_f16 && k_scaled_f16 && v_f16 && Wo_f16 && bo && gamma && beta && out_f16 && t2i_Wk_f16 &&
                    t2i_kpe_f16 && t2i_qs_f16 && Y_f16 && workspace,
                "csam_i2t_t2i: null pointer");
   CSAM_REQUIRE(B > 0 && T > 0 && T % 64 == 0, "csam_i2t_t2i: T must be a multiple of 64");
+  CSAM_REQUIRE(fold == 0 || fold == 1 || (fold == 3 && Wq_f16),
+               "csam_i2t_t2i_fold: fold must be 0, 1 (bias in M_b) or 3 (+ gamma / beta folded downstream; projected form only)");
   if (workspace_bytes < csam_i2t_t2i_workspace_bytes(B)) {
     csam_set_error("csam_i2t_t2i: workspace too small");
     return CSAM_ERR_WORKSPACE;
@@ -3234,15 +3248,19 @@ extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_strid
   static csam_once_t once;
   const int n_cu = csam_cu_count();
   if (csam_first_call(once)) {
-    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<false>::SMEM);
-    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<false>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<false>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
+    (void)hipFuncSetAttribute((const void*)i2t_t2i_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, IF<true>::SMEM);
   }
   hipStream_t s = (hipStream_t)stream;
   half_t* Mws = (half_t*)workspace;
   half_t* Kpws = Mws + (long)B * 256 * 64;
   half_t* Qpws = Kpws + (long)B * 64 * 256;
   const dim3 pgrid(B < 2 * n_cu ? B : 2 * n_cu);
-  hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, s, (const half_t*)v_f16, (const half_t*)Wo_f16, Mws);
+  hipLaunchKernelGGL(i2t_rank_prep_kernel, dim3(B), dim3(256), 0, s, (const half_t*)v_f16, (const half_t*)Wo_f16, Mws,
+                     (fold & 1) ? bo : (const float*)nullptr);
   if (Wq_f16)
     hipLaunchKernelGGL(i2t_rank_kp_kernel, pgrid, dim3(256), 0, s, (const half_t*)k_scaled_f16, (const half_t*)Wq_f16, Kpws, B);
   hipLaunchKernelGGL(t2i_rank_prep_kernel, pgrid, dim3(256), 0, s, (const half_t*)t2i_qs_f16, (const half_t*)t2i_Wk_f16, Qpws, B);
@@ -3254,12 +3272,39 @@ extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_strid
   t.X = nullptr; t.Qp = Qpws; t.qs = (const half_t*)t2i_qs_f16; t.kpe = (const half_t*)t2i_kpe_f16; t.Y = (half_t*)Y_f16;
   t.B = B; t.T = T;
   const int per = csam_cdiv(B, n_cu);               // whole prompts per workgroup, one 8-wave workgroup per CU
-  if (Wq_f16)
-    hipLaunchKernelGGL((i2t_t2i_kernel<true>), dim3(csam_cdiv(B, per)), dim3(512), IF<true>::SMEM, s, a, t, per);
-  else
-    hipLaunchKernelGGL((i2t_t2i_kernel<false>), dim3(csam_cdiv(B, per)), dim3(512), IF<false>::SMEM, s, a, t, per);
+  const dim3 grid(csam_cdiv(B, per));
+#define CSAM_I2T_T2I_GO(PROJ_, FOLD_) \
+  hipLaunchKernelGGL((i2t_t2i_kernel<PROJ_, FOLD_>), grid, dim3(512), IF<PROJ_>::SMEM, s, a, t, per)
+  if (Wq_f16) {
+    if (fold == 3) CSAM_I2T_T2I_GO(true, 3);
+    else if (fold == 1) CSAM_I2T_T2I_GO(true, 1);
+    else CSAM_I2T_T2I_GO(true, 0);
+  } else {
+    if (fold == 1) CSAM_I2T_T2I_GO(false, 1);
+    else CSAM_I2T_T2I_GO(false, 0);
+  }
+#undef CSAM_I2T_T2I_GO
   CSAM_LAUNCH_CHECK("csam_i2t_t2i");
   return CSAM_OK;
+}
+
+extern "C" int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                            const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
+                            const float* bo, const float* gamma, const float* beta, float eps, void* out_f16,
+                            const void* t2i_Wk_f16, const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T,
+                            void* workspace, long workspace_bytes) {
+  return i2t_t2i_launch(stream, X_f16, x_prompt_stride, Q_f16, q_prompt_stride, Wq_f16, k_scaled_f16, v_f16, Wo_f16, bo, gamma,
+                        beta, eps, out_f16, t2i_Wk_f16, t2i_kpe_f16, t2i_qs_f16, Y_f16, B, T, workspace, workspace_bytes, 0);
+}
+
+// csam_i2t_t2i with constants folded out of the producer's tile loop (include/csam.h).
+extern "C" int csam_i2t_t2i_fold(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                                 const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16,
+                                 const float* bo, const float* gamma, const float* beta, float eps, void* out_f16,
+                                 const void* t2i_Wk_f16, const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B,
+                                 int T, void* workspace, long workspace_bytes, int fold) {
+  return i2t_t2i_launch(stream, X_f16, x_prompt_stride, Q_f16, q_prompt_stride, Wq_f16, k_scaled_f16, v_f16, Wo_f16, bo, gamma,
+                        beta, eps, out_f16, t2i_Wk_f16, t2i_kpe_f16, t2i_qs_f16, Y_f16, B, T, workspace, workspace_bytes, fold);
 }
 
 extern "C" int csam_t2i_merge_launch(void* stream, const float* part, void* out_f16, int B, int nparts);

@@ -118,6 +118,10 @@ class DecoderPlan:
         self.t2i_rank = os.environ.get("CSAM_T2I_RANK", "1") != "0"       # rank-56 token->image, layers 1 / final (B >= 256)
         # image->token of layer L + token->image of the next block in one pass over the key state (csam_i2t_t2i, B >= 256)
         self.i2t_t2i = os.environ.get("CSAM_I2T_T2I", "1") != "0"
+        # round 4: constants folded out of csam_i2t_t2i's producer loop (csam_i2t_t2i_fold): the out-projection bias into M_b
+        # (both layers), layer 1's norm4 gamma / beta into the consumers of the final key state (upscaler first conv, final
+        # attention).  Only on the csam_i2t_t2i path (B >= 256); CSAM_I2T_FOLD=0 keeps the plain kernel.
+        self.i2t_fold = os.environ.get("CSAM_I2T_FOLD", "1") != "0"
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -192,6 +196,20 @@ class DecoderPlan:
         self.up2_w = f16(w2.permute(2, 3, 1, 0).reshape(128, 64))
         self.up2_b = f32(sd[M + "output_upscaling.3.bias"].repeat(4))
         self.up2_w_perm = f16(w2.permute(2, 3, 1, 0).reshape(128, 64)[:, _kperm(64)])
+        # consumers of the final key state with layer 1's norm4 folded in (keys arrive as plain normalised values n,
+        # the true keys being gamma (.) n + beta): first conv W1 (.) gamma, b1 + W1 beta; final attention Wk (.) gamma (the
+        # beta Wk^T term is constant over the keys: softmax-invariant), Wc (.) gamma per head block, bc + Wc beta (sum p = 1)
+        g4 = sd[T + "layers.1.norm4.weight"].detach().float().cpu()
+        b4 = sd[T + "layers.1.norm4.bias"].detach().float().cpu()
+        w1m = w1.detach().float().cpu().permute(2, 3, 1, 0).reshape(256, 256)
+        self.up1_w_fold = f16(w1m * g4[None, :])
+        self.up1_b_fold = f32(sd[M + "output_upscaling.0.bias"].detach().float().cpu().repeat(4) + w1m @ b4)
+        wc32 = torch.einsum("ohd,hdk->ohk", fa["o_w"].detach().float().cpu().view(256, 8, 16),
+                            fa["v_w"].detach().float().cpu().view(8, 16, 256))                     # [256, 8, 256]
+        self.final_fold = dict(self.final)
+        self.final_fold.update(k_w=f16(fa["k_w"].detach().float().cpu() * g4[None, :]),
+                               wc=f16((wc32 * g4[None, None, :]).reshape(256, 2048)),
+                               bc=f32(self.final["bc"].detach().float().cpu() + (wc32 * b4[None, None, :]).sum((1, 2))))
 
         def mlp(prefix, n):
             return [(f32(sd[f"{prefix}.layers.{i}.weight"]), f32(sd[f"{prefix}.layers.{i}.bias"])) for i in range(n)]
@@ -412,6 +430,7 @@ class DecoderPlan:
         fuse_next = (self.fused and self.i2t_stream and self.i2t_rank and self.i2t_rank_l1 and self.t2i_rank
                      and self.t2i_stream and self.i2t_t2i and B >= 256)
         y_ready = False
+        keys_plain = False
         for li, L in enumerate(self.layers):
             if not y_ready:
                 self_attn(li, L)
@@ -445,11 +464,14 @@ class DecoderPlan:
                 if li == 0:
                     hip.i2t_t2i(st["src16"], 0, st["qi0"], 0, None, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
                                 L["norm4_g"], L["norm4_b"], 1e-5, keys_out, R["k_w"], R["kpe16"], ws["t2i_q"], ws["t2i_y"],
-                                B, T_IMG, ws["i2t_t2i_ws"])
+                                B, T_IMG, ws["i2t_t2i_ws"], fold=1 if self.i2t_fold else 0)
                 else:
+                    # (the reader of this pass is the FINAL attention: with the fold its Wk carries norm4's gamma)
                     hip.i2t_t2i(keys_in, T_IMG * 256, L["i2t_q_peb16"], 0, L["i2t_q_w"], ws["i2t_k"], ws["i2t_v"],
-                                L["i2t_o_w"], L["i2t_o_b"], L["norm4_g"], L["norm4_b"], 1e-5, keys_out, R["k_w"], R["kpe16"],
-                                ws["t2i_q"], ws["t2i_y"], B, T_IMG, ws["i2t_t2i_ws"])
+                                L["i2t_o_w"], L["i2t_o_b"], L["norm4_g"], L["norm4_b"], 1e-5, keys_out,
+                                (self.final_fold if self.i2t_fold else R)["k_w"], R["kpe16"],
+                                ws["t2i_q"], ws["t2i_y"], B, T_IMG, ws["i2t_t2i_ws"], fold=3 if self.i2t_fold else 0)
+                    keys_plain = self.i2t_fold          # the final key state holds plain normalised values
                 y_ready = True
             elif stream:
                 if li == 0 and self.i2t_rank and B >= 256:
@@ -487,7 +509,7 @@ class DecoderPlan:
                 hip.layernorm(keys_out[:BT], L["norm4_g"], L["norm4_b"], 1e-5, out=keys_out[:BT])
             keys_in, keys_out = keys_out, ws["keysB"]
         # ---- final token -> image attention (transformer.py:105-112)
-        F = self.final                                   # qpe16 still holds fp16(queries + tokens0) from the last norm3
+        F = self.final_fold if keys_plain else self.final     # qpe16 still holds fp16(queries + tokens0) from the last norm3
         hs16 = ws["hs16"][:M7]
         if self.fused:
             t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
@@ -514,8 +536,8 @@ class DecoderPlan:
         masks = ws["masks"][:B]
         if self.fused:
             up = hip.upscale_stream if (self.up_stream and B >= 256) else hip.upscale_fused
-            up(keys_in, self.up1_w, self.up1_b, self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm,
-                              self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
+            up(keys_in, self.up1_w_fold if keys_plain else self.up1_w, self.up1_b_fold if keys_plain else self.up1_b,
+               self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm, self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
         else:
             hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
         # ---- IoU head (:184) + parallel residual head (:194-198)

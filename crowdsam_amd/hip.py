@@ -74,6 +74,7 @@ SIGNATURES = {
     "csam_t2i_stream": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "csam_t2i_rank": [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I],
     "csam_i2t_t2i": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _L],
+    "csam_i2t_t2i_fold": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _L, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
     "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
@@ -856,12 +857,18 @@ def i2t_t2i_workspace_bytes(B):
 
 
 def i2t_t2i(X, x_bstride, Q, q_bstride, Wq, k_scaled, v, Wo, bo, gamma, beta, eps, out, t2i_Wk, t2i_kpe16, t2i_q_scaled, Y,
-            B, T, workspace):
+            B, T, workspace, fold=0):
     """``i2t_rank`` (Wq None: Q = hoisted image-side queries) / ``i2t_rank_proj`` (Q = qpe16) writing ``out``, with the NEXT
-    block's ``t2i_rank`` folded in: Y f16 [B*7, 8*256] comes from the new keys while they are still in LDS."""
-    call("csam_i2t_t2i", _stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq) if Wq is not None else None,
-         _ptr(k_scaled), _ptr(v), _ptr(Wo), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ptr(t2i_Wk),
-         _ptr(t2i_kpe16), _ptr(t2i_q_scaled), _ptr(Y), B, T, _ptr(workspace), workspace.numel() * workspace.element_size())
+    block's ``t2i_rank`` folded in: Y f16 [B*7, 8*256] comes from the new keys while they are still in LDS.
+    ``fold`` (csam_i2t_t2i_fold): 1 = out-projection bias in M_b; 3 = also plain normalised keys (gamma / beta folded into
+    the consumers by the caller; ``t2i_Wk`` must then be Wk (.) gamma)."""
+    args = (_stream(), _ptr(X), x_bstride, _ptr(Q), q_bstride, _ptr(Wq) if Wq is not None else None,
+            _ptr(k_scaled), _ptr(v), _ptr(Wo), _ptr(bo), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ptr(t2i_Wk),
+            _ptr(t2i_kpe16), _ptr(t2i_q_scaled), _ptr(Y), B, T, _ptr(workspace), workspace.numel() * workspace.element_size())
+    if fold:
+        call("csam_i2t_t2i_fold", *args, int(fold))
+    else:
+        call("csam_i2t_t2i", *args)
     return out, Y
 
 

@@ -243,6 +243,16 @@ int csam_i2t_t2i(void* stream, const void* X_f16, long x_prompt_stride, const vo
                  const float* gamma, const float* beta, float eps, void* out_f16, const void* t2i_Wk_f16,
                  const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T, void* workspace,
                  long workspace_bytes);
+/* csam_i2t_t2i with per-tile constants folded out of the producer's loop (transformer.py:186-190): fold bit 0 -- the
+ * out-projection bias rides in M_b (bo / 8 per valid slot; a head's 7 softmax weights sum to 1), so no bias rows are read per
+ * tile; fold = 3 (projected form only) additionally stores the PLAIN normalised keys: the caller has folded the LayerNorm's
+ * gamma / beta into the consumers of these keys -- the first conv of csam_upscale_* (W1 (.) gamma, b1 + W1 beta) and the final
+ * attention (t2i_Wk_f16 = Wk (.) gamma here; Wc (.) gamma and bc + Wc beta in the GEMM after Y).  fold = 0 is csam_i2t_t2i. */
+int csam_i2t_t2i_fold(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,
+                      const void* Wq_f16, const void* k_scaled_f16, const void* v_f16, const void* Wo_f16, const float* bo,
+                      const float* gamma, const float* beta, float eps, void* out_f16, const void* t2i_Wk_f16,
+                      const void* t2i_kpe_f16, const void* t2i_qs_f16, void* Y_f16, int B, int T, void* workspace,
+                      long workspace_bytes, int fold);
 /* mask_decoder.py:172-181: ConvT -> LayerNorm2d -> GELU -> ConvT -> GELU -> hyper-network product */
 int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
