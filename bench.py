@@ -384,7 +384,7 @@ def main():
     # third leg (rank 0): the tail alone on PERSON-SHAPED masks.  The random-weight masks of the timed
     # frames are noise-like blobs (worst case for connected components: every 64 x 64 tile is mixed); a real crowd frame keeps
     # compact person silhouettes.  The same number of kept masks as the timed frames, drawn as filled ellipses with a few
-    # small holes and islands each, go through the same three tail stages: small-region clean-up (connected components x 2 +
+    # small holes and nearby islands each, go through the same three tail stages: small-region clean-up (connected components x 2 +
     # NMS), run-length encoding, COCO string packing.  Reported next to the tail of the timed (noise) frames.
     tail_person = None
     if crowded and rank == 0:
@@ -403,19 +403,25 @@ def main():
             for _ in range(3):
                 hy, hx = int(cy + rs.uniform(-0.5, 0.5) * ay), int(cx + rs.uniform(-0.4, 0.4) * ax)
                 m[hy:hy + 3, hx:hx + 3] = False
-            for _ in range(2):
-                sy, sx = int(rs.uniform(0, Hh - 6)), int(rs.uniform(0, Ww - 6))
+            for _ in range(2):                     # specks next to the silhouette (within 1.5 x its half-axes)
+                sy = int(min(max(cy + rs.uniform(-1.5, 1.5) * ay, 0), Hh - 6))
+                sx = int(min(max(cx + rs.uniform(-1.5, 1.5) * ax, 0), Ww - 6))
                 m[sy:sy + 4, sx:sx + 4] = True
             store[i] = m
         ref_store = store.clone()
+        rows_any, cols_any = ref_store.any(2), ref_store.any(1)           # boxes as the statistics pass reports them
+        ar_h, ar_w = torch.arange(Hh, device=dev), torch.arange(Ww, device=dev)
+        big = 1 << 30
+        pboxes = torch.stack([torch.where(cols_any, ar_w, big).amin(1), torch.where(rows_any, ar_h, big).amin(1),
+                              torch.where(cols_any, ar_w, -1).amax(1), torch.where(rows_any, ar_h, -1).amax(1)], 1).long()
 
         def tail_once():
             store.copy_(ref_store)
             data = MaskData(mask_slots=torch.arange(n_m, dtype=torch.int32, device=dev),
-                            boxes=torch.zeros(n_m, 4, dtype=torch.long, device=dev),
+                            boxes=pboxes.clone(),
                             iou_preds=torch.linspace(1.0, 0.5, n_m, device=dev))
             data = _CS.postprocess_small_regions(data, model.min_mask_region_area, 1.0, mask_store=store)
-            rl = mask_to_rle_arrays(store, idx=data["mask_slots"].contiguous())
+            rl = mask_to_rle_arrays(store, idx=data["mask_slots"].contiguous(), boxes=data["boxes"])
             return len(coco_encode_rles(rl))
 
         tail_once()

@@ -41,6 +41,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
+_WINDOWED_REGIONS = os.environ.get("CSAM_CC_WINDOWED", "1") != "0"      # small-region clean-up inside the masks' boxes
 
 
 class CrowdSAM:
@@ -455,7 +456,10 @@ class CrowdSAM:
             data["scores"] = data["iou_preds"] ** 0.5 * cls ** 0.5
         else:
             data["scores"] = data["iou_preds"]
-        data["rles"] = mask_to_rle_arrays(mstore, idx=data["mask_slots"].contiguous())    # run lengths -> C string packer
+        # run lengths -> C string packer; the passes read the masks' boxes (exact for the final masks: the statistics pass's for
+        # untouched masks, the clean-up's for edited ones), not the frames
+        data["rles"] = mask_to_rle_arrays(mstore, idx=data["mask_slots"].contiguous(),
+                                          boxes=data["boxes"] if _WINDOWED_REGIONS else None)
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
         del data["mask_slots"]
@@ -557,7 +561,13 @@ class CrowdSAM:
         if mask_store is not None and "mask_slots" in mask_data:
             if len(mask_data["mask_slots"]) == 0:
                 return mask_data
-            changed, boxes = hip.small_regions_idx(mask_store, mask_data["mask_slots"].contiguous(), min_area)
+            # bounding-box-restricted form (round 4): person-sized masks are cleaned up inside their padded boxes, frame-filling
+            # ones as before; identical results (hip.small_regions_windowed)
+            if _WINDOWED_REGIONS and "boxes" in mask_data:
+                changed, boxes = hip.small_regions_windowed(mask_store, mask_data["mask_slots"].contiguous(),
+                                                            mask_data["boxes"], min_area)
+            else:
+                changed, boxes = hip.small_regions_idx(mask_store, mask_data["mask_slots"].contiguous(), min_area)
             scores = (changed == 0).float()
             keep = batched_nms(boxes, scores, None, nms_thresh)
             edited = keep[scores[keep] == 0]

@@ -229,22 +229,50 @@ __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restric
 }
 
 // Four columns per thread (W % 4 == 0): one 4-byte load per row instead of four byte loads; the same counts / positions.
+// ``boxes`` (optional, int32 [n][4] = x0, y0, x1, y1 with inclusive maxima: the masks' bounding boxes): every set pixel lies
+// inside the box, so a column changes value only in rows y0 .. y1 + 1 -- and at row 0 against the end of the column to its
+// left -- and only the columns x0 .. x1 + 1 change at all.  The scan then touches the box instead of the frame.
+__device__ __forceinline__ void rle_rows(const int* __restrict__ boxes, int n, int x, int H, bool& active, int& ya, int& yb) {
+  active = true;
+  ya = 1;
+  yb = H - 1;
+  if (boxes) {
+    const int bx0 = boxes[n * 4], by0 = boxes[n * 4 + 1], bx1 = boxes[n * 4 + 2], by1 = boxes[n * 4 + 3];
+    active = x + 3 >= bx0 && x <= bx1 + 1;
+    ya = max(by0, 1);
+    yb = min(by1 + 1, H - 1);
+  }
+}
+
 __global__ __launch_bounds__(256) void rle_count4_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
-                                                         int H, int W, int* __restrict__ col_counts) {
+                                                         int H, int W, int* __restrict__ col_counts,
+                                                         const int* __restrict__ boxes) {
   const int n = blockIdx.y;
   const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (x >= W) return;
   const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
-  const uint32_t last = *(const uint32_t*)(m + (long)(H - 1) * W + x);      // last row of the four columns
-  uint32_t prev = (last << 8) | (x > 0 ? m[(long)(H - 1) * W + x - 1] : (m[x] != 0));   // column c starts after column c-1 ends
-  // bytes are 0 / 1: compare as packed bytes
   int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  bool active;
+  int ya, yb;
+  rle_rows(boxes, n, x, H, active, ya, yb);
+  if (active) {
+    const uint32_t last = *(const uint32_t*)(m + (long)(H - 1) * W + x);      // last row of the four columns
+    uint32_t prev = (last << 8) | (x > 0 ? m[(long)(H - 1) * W + x - 1] : (m[x] != 0));   // column c starts after column c-1 ends
+    // bytes are 0 / 1: compare as packed bytes.  Row 0 against the end of the previous column, then rows ya .. yb against
+    // the row above (rows 1 .. ya - 1 and yb + 1 .. H - 1 repeat the row above them: outside the box)
+    {
+      const uint32_t v = *(const uint32_t*)(m + x);
+      const uint32_t d = v ^ prev;
+      c0 += d & 1u; c1 += (d >> 8) & 1u; c2 += (d >> 16) & 1u; c3 += (d >> 24) & 1u;
+    }
+    prev = *(const uint32_t*)(m + (long)(ya - 1) * W + x);
 #pragma unroll 8
-  for (int y = 0; y < H; ++y) {
-    const uint32_t v = *(const uint32_t*)(m + (long)y * W + x);
-    const uint32_t d = v ^ prev;
-    c0 += d & 1u; c1 += (d >> 8) & 1u; c2 += (d >> 16) & 1u; c3 += (d >> 24) & 1u;
-    prev = v;
+    for (int y = ya; y <= yb; ++y) {
+      const uint32_t v = *(const uint32_t*)(m + (long)y * W + x);
+      const uint32_t d = v ^ prev;
+      c0 += d & 1u; c1 += (d >> 8) & 1u; c2 += (d >> 16) & 1u; c3 += (d >> 24) & 1u;
+      prev = v;
+    }
   }
   int* cc = col_counts + (long)n * W + x;
   cc[0] = c0; cc[1] = c1; cc[2] = c2; cc[3] = c3;
@@ -252,18 +280,22 @@ __global__ __launch_bounds__(256) void rle_count4_kernel(const uint8_t* __restri
 
 __global__ __launch_bounds__(256) void rle_write4_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ idx,
                                                          int H, int W, const int* __restrict__ col_offsets,
-                                                         const long* __restrict__ mask_offsets, uint32_t* __restrict__ out) {
+                                                         const long* __restrict__ mask_offsets, uint32_t* __restrict__ out,
+                                                         const int* __restrict__ boxes) {
   const int n = blockIdx.y;
   const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (x >= W) return;
+  bool active;
+  int ya, yb;
+  rle_rows(boxes, n, x, H, active, ya, yb);
+  if (!active) return;
   const uint8_t* m = masks + (long)(idx ? idx[n] : n) * H * W;
   const int* co = col_offsets + (long)n * W + x;
   uint32_t* ob = out + mask_offsets[n];
   uint32_t* o0 = ob + co[0]; uint32_t* o1 = ob + co[1]; uint32_t* o2 = ob + co[2]; uint32_t* o3 = ob + co[3];
   const uint32_t last = *(const uint32_t*)(m + (long)(H - 1) * W + x);
   uint32_t prev = (last << 8) | (x > 0 ? m[(long)(H - 1) * W + x - 1] : (m[x] != 0));
-#pragma unroll 8
-  for (int y = 0; y < H; ++y) {
+  auto step = [&](int y) {
     const uint32_t v = *(const uint32_t*)(m + (long)y * W + x);
     const uint32_t d = v ^ prev;
     if (d) {
@@ -273,7 +305,11 @@ __global__ __launch_bounds__(256) void rle_write4_kernel(const uint8_t* __restri
       if (d & 0x1000000u) *o3++ = (uint32_t)((x + 3) * H + y);
     }
     prev = v;
-  }
+  };
+  step(0);                                              // against the end of the previous column
+  prev = *(const uint32_t*)(m + (long)(ya - 1) * W + x);
+#pragma unroll 8
+  for (int y = ya; y <= yb; ++y) step(y);
 }
 
 __global__ __launch_bounds__(1024) void rle_scan_kernel(int* __restrict__ col_counts, int W, int* __restrict__ totals) {
@@ -387,13 +423,13 @@ extern "C" int csam_mask_nms(void* stream, const void* masks_u8, const float* sc
 }
 
 // masks_u8[idx[i]] for i < N when idx is given (store slots of the kept masks: no gather before the encoder), else masks_u8[i]
-extern "C" int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
-                                  int* col_offsets, int* totals) {
+extern "C" int csam_rle_count_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N,
+                                  int H, int W, int* col_offsets, int* totals) {
   CSAM_REQUIRE(masks_u8 && col_offsets && totals && N > 0 && H > 0 && W > 0 && W <= 4096, "csam_rle_count: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (W % 4 == 0 && ((long)H * W) % 4 == 0 && ((uintptr_t)masks_u8 & 3) == 0)
     hipLaunchKernelGGL(rle_count4_kernel, dim3(csam_cdiv(W, 1024), N), dim3(256), 0, s, (const uint8_t*)masks_u8, idx_or_null, H,
-                       W, col_offsets);
+                       W, col_offsets, boxes_or_null);
   else
     hipLaunchKernelGGL(rle_count_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, s, (const uint8_t*)masks_u8, idx_or_null, H,
                        W, col_offsets);
@@ -402,17 +438,27 @@ extern "C" int csam_rle_count_idx(void* stream, const void* masks_u8, const int*
   return CSAM_OK;
 }
 
-extern "C" int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
-                                  const int* col_offsets, const long* mask_offsets, uint32_t* out_positions) {
+extern "C" int csam_rle_write_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N,
+                                  int H, int W, const int* col_offsets, const long* mask_offsets, uint32_t* out_positions) {
   CSAM_REQUIRE(masks_u8 && col_offsets && mask_offsets && out_positions && N > 0, "csam_rle_write: bad args");
   if (W % 4 == 0 && ((long)H * W) % 4 == 0 && ((uintptr_t)masks_u8 & 3) == 0)
     hipLaunchKernelGGL(rle_write4_kernel, dim3(csam_cdiv(W, 1024), N), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)masks_u8, idx_or_null, H, W, col_offsets, mask_offsets, out_positions);
+                       (const uint8_t*)masks_u8, idx_or_null, H, W, col_offsets, mask_offsets, out_positions, boxes_or_null);
   else
     hipLaunchKernelGGL(rle_write_kernel, dim3(csam_cdiv(W, 256), N), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)masks_u8, idx_or_null, H, W, col_offsets, mask_offsets, out_positions);
   CSAM_LAUNCH_CHECK("csam_rle_write");
   return CSAM_OK;
+}
+
+extern "C" int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
+                                  int* col_offsets, int* totals) {
+  return csam_rle_count_box(stream, masks_u8, idx_or_null, nullptr, N, H, W, col_offsets, totals);
+}
+
+extern "C" int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
+                                  const int* col_offsets, const long* mask_offsets, uint32_t* out_positions) {
+  return csam_rle_write_box(stream, masks_u8, idx_or_null, nullptr, N, H, W, col_offsets, mask_offsets, out_positions);
 }
 
 extern "C" int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals) {

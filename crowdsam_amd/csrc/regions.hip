@@ -1116,6 +1116,59 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
   return CSAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Window copies for the bounding-box-restricted clean-up (round 4).  remove_small_regions (amg.py:267-291) looks at the
+// whole frame, but a mask's components all lie inside its bounding box: with the box padded by a ring of background the
+// clean-up of the WINDOW is the clean-up of the frame (the ring is one background component, connected to everything
+// outside, and large; islands never touch it).  csam_mask_window_copy gathers the windows of n masks into a dense
+// [n, Hc, Wc] stack (zero outside the window) or scatters them back; the caller runs csam_small_regions_idx on the stack.
+// win[i] = (x0, y0, w, h) of mask i's window inside its H x W store slot; w <= Wc, h <= Hc.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TO_STORE>
+__global__ __launch_bounds__(256) void mask_window_copy_kernel(uint8_t* __restrict__ store, const int* __restrict__ slots,
+                                                               const int* __restrict__ win, const uint8_t* __restrict__ only,
+                                                               uint8_t* __restrict__ crop, int H, int W, int Hc, int Wc) {
+  const int n = blockIdx.z;
+  if (TO_STORE && only && !only[n]) return;
+  const int x0 = win[n * 4 + 0], y0 = win[n * 4 + 1], w = win[n * 4 + 2], h = win[n * 4 + 3];
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (y >= Hc) return;
+  uint8_t* srow = store + ((long)(slots ? slots[n] : n) * H + (y0 + y)) * W + x0;
+  uint8_t* crow = crop + ((long)n * Hc + y) * Wc;
+  for (int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4; x < Wc; x += gridDim.x * 256) {
+    if (TO_STORE) {
+      if (y < h) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x + e < w) srow[x + e] = crow[x + e];
+      }
+    } else {
+      uint32_t v = 0;
+      if (y < h) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x + e < w) v |= (uint32_t)(srow[x + e] != 0) << (8 * e);
+      }
+      *(uint32_t*)(crow + x) = v;                       // Wc % 4 == 0
+    }
+  }
+}
+
+extern "C" int csam_mask_window_copy(void* stream, void* store_u8, const int* slots_or_null, const int* windows, const void* only_u8_or_null,
+                                     void* crop_u8, int n, int H, int W, int Hc, int Wc, int to_store) {
+  CSAM_REQUIRE(store_u8 && windows && crop_u8 && n > 0 && H > 0 && W > 0 && Hc > 0 && Wc > 0 && Wc % 4 == 0 && n <= 65535,
+               "csam_mask_window_copy: bad args");
+  const dim3 grid(csam_cdiv(Wc, 256), csam_cdiv(Hc, 4), n);
+  if (to_store)
+    hipLaunchKernelGGL(mask_window_copy_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (uint8_t*)store_u8, slots_or_null, windows,
+                       (const uint8_t*)only_u8_or_null, (uint8_t*)crop_u8, H, W, Hc, Wc);
+  else
+    hipLaunchKernelGGL(mask_window_copy_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (uint8_t*)store_u8, slots_or_null, windows,
+                       (const uint8_t*)only_u8_or_null, (uint8_t*)crop_u8, H, W, Hc, Wc);
+  CSAM_LAUNCH_CHECK("csam_mask_window_copy");
+  return CSAM_OK;
+}
+
 extern "C" long csam_small_regions_workspace_bytes(int n, int H, int W) {
   if (n <= 0 || H <= 0 || W <= 0) return 0;
   const long px = (long)n * H * W;

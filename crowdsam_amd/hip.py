@@ -61,11 +61,14 @@ SIGNATURES = {
     "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
     "csam_rle_count_idx": [_P, _P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write_idx": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_rle_count_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "csam_rle_write_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "csam_mask_nms": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _L],
     "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
     "csam_mask_mean_bilinear": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     "csam_small_regions": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
     "csam_small_regions_idx": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L],
+    "csam_mask_window_copy": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "csam_bilinear_f32": [_P, _P, _I, _I, _I, _P, _I, _I],
     "csam_i2t_fused": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_stream": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
@@ -662,6 +665,69 @@ def small_regions_idx(mask_store, idx, min_area, out_store=None):
     return changed, boxes
 
 
+def mask_window_copy(store, slots, windows, crop, to_store, only=None):
+    """Gather (to_store False) the windows ``windows`` int32 [n,4] = (x0, y0, w, h) of the masks store[slots[i]] into the dense
+    stack ``crop`` u8 [n, Hc, Wc] (zero outside the window), or scatter them back (``only`` u8 [n]: just those masks)."""
+    cap, H, W = store.shape
+    n, Hc, Wc = crop.shape
+    s8 = store.view(torch.uint8) if store.dtype == torch.bool else store
+    assert s8.is_contiguous() and crop.is_contiguous() and crop.dtype == torch.uint8 and windows.dtype == torch.int32
+    assert slots is None or (slots.dtype == torch.int32 and slots.is_contiguous())
+    call("csam_mask_window_copy", _stream(), _ptr(s8), _ptr(slots), _ptr(windows), _ptr(only), _ptr(crop), n, H, W, Hc, Wc,
+         1 if to_store else 0)
+
+
+SMALL_REGIONS_PAD = 16       # ring of background kept around a mask's box in the windowed clean-up
+
+
+def small_regions_windowed(mask_store, idx, boxes_xyxy, min_area):
+    """small_regions_idx restricted to the masks' bounding boxes (round 4).  remove_small_regions (amg.py:267-291) labels the
+    whole frame, but every component of the mask and every hole lies inside the mask's box; with a 16-pixel ring of
+    background around the box, the clean-up of that WINDOW is the clean-up of the frame: the ring is a single background
+    component, it is connected to everything outside, its area (>= 2 * 16 * (w + h + 32) >= 1088 pixels) exceeds min_area, and
+    no island touches it.  Masks whose padded window fits inside the frame and covers at most a quarter of it are gathered
+    into one dense stack (csam_mask_window_copy), cleaned there and scattered back where they changed; the rest -- frame-
+    filling masks, masks near the border, empty masks -- take the full-frame call.  ``boxes_xyxy``: the masks' boxes in
+    store coordinates (inclusive maxima, batched_mask_to_box), the ones the statistics pass of the mask post-processing
+    produced.  Same return as small_regions_idx; bit-identical results (tests/test_regions_gpu.py)."""
+    cap, H, W = mask_store.shape
+    n = int(idx.shape[0])
+    p = SMALL_REGIONS_PAD
+    if n < 4 or min_area > 2 * p * (2 + 2 * p):
+        return small_regions_idx(mask_store, idx, min_area)
+    import numpy as np
+    b = boxes_xyxy.detach().to(torch.int64).cpu().numpy()              # one small D2H (n x 4)
+    wx0, wy0, wx1, wy1 = b[:, 0] - p, b[:, 1] - p, b[:, 2] + p, b[:, 3] + p
+    ww, wh = wx1 - wx0 + 1, wy1 - wy0 + 1
+    small = (b[:, 2] >= b[:, 0]) & (b[:, 3] >= b[:, 1]) & (b[:, 2] + b[:, 3] > 0) & (wx0 >= 0) & (wy0 >= 0) & (wx1 < W) & \
+        (wy1 < H) & (ww * wh * 4 <= H * W)
+    ns = int(small.sum())
+    if ns < 4:
+        return small_regions_idx(mask_store, idx, min_area)
+    Hc, Wc = int(-(-wh[small].max() // 64) * 64), int(-(-ww[small].max() // 64) * 64)
+    if Hc * Wc * 2 > H * W:                                            # nothing to gain
+        return small_regions_idx(mask_store, idx, min_area)
+    dev = mask_store.device
+    changed = torch.empty((n,), dtype=torch.int32, device=dev)
+    boxes = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    sel_s = torch.as_tensor(np.nonzero(small)[0], device=dev)
+    win = torch.as_tensor(np.stack([wx0[small], wy0[small], ww[small], wh[small]], 1).astype(np.int32)).to(dev)
+    slots_s = idx[sel_s].contiguous()
+    crop = torch.empty((ns, Hc, Wc), dtype=torch.uint8, device=dev)
+    mask_window_copy(mask_store, slots_s, win, crop, False)
+    ch_s, bx_s = small_regions_idx(crop, None, min_area)
+    nonempty = (bx_s != 0).any(1, keepdim=True)                        # a non-empty mask cannot have the box (0, 0, 0, 0): that
+    origin = win[:, [0, 1, 0, 1]].to(torch.float32)                    # pixel lies in the background ring of the window
+    bx_s = torch.where(nonempty, bx_s + origin, bx_s)
+    mask_window_copy(mask_store, slots_s, win, crop, True, only=(ch_s != 0).to(torch.uint8))
+    changed[sel_s], boxes[sel_s] = ch_s, bx_s
+    if ns < n:
+        sel_l = torch.as_tensor(np.nonzero(~small)[0], device=dev)
+        ch_l, bx_l = small_regions_idx(mask_store, idx[sel_l].contiguous(), min_area)
+        changed[sel_l], boxes[sel_l] = ch_l, bx_l
+    return changed, boxes
+
+
 def mask_nms(masks, scores, thr):
     """Coverage NMS over 150x150 nearest-resampled masks (crowdsam/utils.py mask_iou_nms).  masks u8/bool [N,H,W],
     scores f32 [N] -> kept indices int64 (device) in descending-score order."""
@@ -678,20 +744,22 @@ def mask_nms(masks, scores, thr):
     return keep[: int(count.item())]
 
 
-def rle_encode(masks, idx=None):
+def rle_encode(masks, idx=None, boxes=None):
     """Column-major change positions of u8 masks -> (positions uint32 (device), offsets int64 (host, N+1)).
-    ``idx`` None: masks [N,H,W]; else masks is a store [cap,H,W] and idx (int32 device [N]) names the slots to encode."""
+    ``idx`` None: masks [N,H,W]; else masks is a store [cap,H,W] and idx (int32 device [N]) names the slots to encode.
+    ``boxes`` int32 [N,4] (x0, y0, x1, y1, inclusive): the masks' bounding boxes -- the passes then read the boxes only."""
     cap, H, W = masks.shape
     N = cap if idx is None else int(idx.shape[0])
     col = torch.empty((N, W), dtype=torch.int32, device=masks.device)
     totals = torch.empty(N, dtype=torch.int32, device=masks.device)
-    call("csam_rle_count_idx", _stream(), _ptr(masks), _ptr(idx), N, H, W, _ptr(col), _ptr(totals))
+    assert boxes is None or (boxes.dtype == torch.int32 and boxes.is_contiguous() and tuple(boxes.shape) == (N, 4))
+    call("csam_rle_count_box", _stream(), _ptr(masks), _ptr(idx), _ptr(boxes), N, H, W, _ptr(col), _ptr(totals))
     tot = totals.cpu().to(torch.int64)
     offs = torch.zeros(N + 1, dtype=torch.int64)
     offs[1:] = torch.cumsum(tot, 0)
     out = torch.empty(max(int(offs[-1]), 1), dtype=torch.int32, device=masks.device)
     offs_dev = offs[:-1].to(masks.device)
-    call("csam_rle_write_idx", _stream(), _ptr(masks), _ptr(idx), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
+    call("csam_rle_write_box", _stream(), _ptr(masks), _ptr(idx), _ptr(boxes), N, H, W, _ptr(col), _ptr(offs_dev), _ptr(out))
     return out, offs
 
 

@@ -345,6 +345,13 @@ int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_nul
                        int* totals);
 int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
                        const int* col_offsets, const long* mask_offsets, uint32_t* out_positions);
+/* The same with the masks' bounding boxes (int32 [N,4] = x0, y0, x1, y1, inclusive maxima; NULL = scan everything): a column
+ * changes value only inside the box rows (and at row 0 against the column to its left), so the passes read the boxes instead
+ * of the frames -- person-sized masks of a crowd frame cover a few percent of it. */
+int csam_rle_count_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N, int H, int W,
+                       int* col_offsets, int* totals);
+int csam_rle_write_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N, int H, int W,
+                       const int* col_offsets, const long* mask_offsets, uint32_t* out_positions);
 
 /* ---- small-region clean-up (amg.py:267-291 remove_small_regions mode "holes" then "islands", 8-connected,
  * as driven by crowdsam/model.py:394-443): masks u8 [n,H,W] -> out u8 (may alias masks), changed int32 [n]
@@ -356,6 +363,13 @@ int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_nul
 long csam_small_regions_idx_workspace_bytes(int n, int H, int W);
 int csam_small_regions_idx(void* stream, const uint8_t* masks_base, const int* idx_or_null, uint8_t* out_base, int* changed,
                            float* boxes, int n, int H, int W, int min_area, void* workspace, long workspace_bytes);
+/* Windows of masks <-> a dense [n, Hc, Wc] stack, for the bounding-box-restricted form of the clean-up above (amg.py:267-291
+ * sees the whole frame, but every component of a mask lies inside its box: with a ring of background around the box the
+ * clean-up of the window IS the clean-up of the frame -- crowdsam/model.py::postprocess_small_regions).  windows int32
+ * [n,4] = (x0, y0, w, h) inside the H x W store slots, w <= Wc, h <= Hc, Wc % 4 == 0.  to_store 0: gather (stack zero outside
+ * the window, bytes normalised to 0 / 1); 1: scatter back (only_u8 [n] non-NULL: only the masks flagged there). */
+int csam_mask_window_copy(void* stream, void* store_u8, const int* slots_or_null, const int* windows, const void* only_u8_or_null,
+                          void* crop_u8, int n, int H, int W, int Hc, int Wc, int to_store);
 long csam_small_regions_workspace_bytes(int n, int H, int W);
 int csam_small_regions(void* stream, const uint8_t* masks, uint8_t* out, int* changed, float* boxes, int n, int H,
                        int W, int min_area, void* workspace, long workspace_bytes);

@@ -150,7 +150,7 @@ def _runs_from_positions(pos, first_set, hw):
     return np.concatenate([[0], runs]) if first_set else runs
 
 
-def mask_to_rle_arrays(tensor, idx=None):
+def mask_to_rle_arrays(tensor, idx=None, boxes=None):
     """mask_to_rle_pytorch with the run lengths kept as int64 ndarrays (what the driver feeds straight into
     the C string packer: a crowded frame has 1e5+ runs per mask, Python lists would dominate the tail).
     ``idx`` (device int32 [b]): ``tensor`` is a (cap, h, w) mask store and only the slots named by idx are encoded, in
@@ -169,7 +169,9 @@ def mask_to_rle_arrays(tensor, idx=None):
             m8 = tensor.contiguous()
         else:
             m8 = (tensor != 0).view(torch.uint8).contiguous()
-        pos, offs = hip.rle_encode(m8, idx)
+        # ``boxes`` (build extension): XYXY boxes of the masks (inclusive maxima, batched_mask_to_box) -- the encoder then reads the
+        # boxes instead of the frames
+        pos, offs = hip.rle_encode(m8, idx, None if boxes is None else boxes.to(torch.int32).contiguous())
         pos = pos.cpu().numpy().astype(np.int64)
         first = (m8[:, 0, 0] if idx is None else m8[idx.long(), 0, 0]).cpu().numpy().astype(bool)
         # run lengths of ALL masks in one pass (a crowded frame keeps hundreds of masks: per-mask numpy calls were the

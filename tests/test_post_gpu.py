@@ -167,6 +167,35 @@ def test_rle_matches_oracle(cuda):
         assert counts == ref[i]["counts"]
 
 
+def test_rle_with_boxes_equals_full_scan(cuda):
+    """csam_rle_count_box / csam_rle_write_box (round 4): with the masks' bounding boxes the passes read the boxes only; the
+    change positions must be those of the full scan -- boxes touching every frame edge, a one-pixel mask at the origin, an
+    empty mask (box 0,0,0,0), a full mask, blobs."""
+    from crowdsam_amd import hip
+    from oracle import pipeline_oracle as po
+    H, W = 300, 512
+    rs = np.random.RandomState(4)
+    masks = np.zeros((12, H, W), bool)
+    for i, (y0, y1, x0, x1) in enumerate([(0, 40, 0, 30), (260, 299, 480, 511), (0, 299, 200, 203), (100, 100, 0, 511),
+                                           (0, 0, 0, 0), (299, 299, 511, 511), (50, 250, 3, 8), (1, 298, 1, 510)]):
+        sub = rs.rand(y1 - y0 + 1, x1 - x0 + 1) > 0.4
+        sub[0, :] |= True; sub[-1, :] |= True; sub[:, 0] |= True; sub[:, -1] |= True      # the box is tight
+        masks[i, y0:y1 + 1, x0:x1 + 1] = sub
+    masks[9] = True                                                                     # 8: empty, 9: full
+    low = _smooth_logits(1, 21)
+    masks[10:12] = (torch.nn.functional.interpolate(low, (H, W), mode="bilinear")[0, :2] > 0.5).numpy()
+    m8 = torch.as_tensor(masks).to(torch.uint8).to(cuda).contiguous()
+    boxes = po.batched_mask_to_box(torch.as_tensor(masks)).to(torch.int32).to(cuda).contiguous()
+    pos_a, offs_a = hip.rle_encode(m8)
+    pos_b, offs_b = hip.rle_encode(m8, boxes=boxes)
+    assert torch.equal(offs_a, offs_b) and int(offs_a[-1]) > 1000
+    assert torch.equal(pos_a[: int(offs_a[-1])], pos_b[: int(offs_b[-1])])
+    idx = torch.as_tensor(np.array([11, 0, 5, 8, 2], np.int32)).to(cuda)               # through a slot list, too
+    pos_c, offs_c = hip.rle_encode(m8, idx)
+    pos_d, offs_d = hip.rle_encode(m8, idx, boxes=boxes[idx.long()].contiguous())
+    assert torch.equal(offs_c, offs_d) and torch.equal(pos_c[: int(offs_c[-1])], pos_d[: int(offs_d[-1])])
+
+
 @pytest.mark.parametrize("w", [516, 517])
 def test_rle_of_non_boolean_bytes_is_the_rle_of_their_truth_value(cuda, w):
     """the 4-column kernels (W % 4 == 0) compare bit 0 of packed bytes, the scalar ones raw bytes; both are only

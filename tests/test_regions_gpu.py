@@ -182,3 +182,61 @@ def test_trivial_tiles(cuda):
     g[1, 0:64, 320:330] = True
     for min_area in (100, 3000):
         _check(cuda, np.concatenate([f, g]), min_area)
+
+
+def _persons(n, H, W, seed):
+    """Person-like masks: filled ellipses with pinholes, bigger holes, specks of every size around min_area inside the box,
+    some touching the frame border, one empty, one frame-filling noise mask."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((n, H, W), bool)
+    for i in range(n):
+        if i == 3:
+            continue                                                       # empty mask
+        if i == 5:
+            masks[i] = _blobs(1, H, W, seed + 1, k=9)[0]                  # frame-filling noise
+            continue
+        near_edge = i % 7 == 0
+        cy = rs.uniform(0, 40) if near_edge else rs.uniform(120, H - 120)
+        cx = rs.uniform(W - 30, W) if (near_edge and i % 14 == 0) else rs.uniform(60, W - 60)
+        ay, ax = rs.uniform(25, 110), rs.uniform(10, 45)
+        m = ((yy - cy) / ay) ** 2 + ((xx - cx) / ax) ** 2 <= 1.0
+        for _ in range(6):                                                  # holes of 1 .. ~200 pixels
+            hy, hx, s = int(cy + rs.uniform(-0.6, 0.6) * ay), int(cx + rs.uniform(-0.5, 0.5) * ax), int(rs.randint(1, 15))
+            m[max(hy, 0):hy + s, max(hx, 0):hx + s] = False
+        if m.any():                                                         # specks INSIDE the box corners (islands)
+            ys, xs = np.nonzero(m)
+            y0, y1, x0, x1 = ys.min(), ys.max(), xs.min(), xs.max()
+            for _ in range(4):
+                s = int(rs.randint(1, 13))
+                sy, sx = int(rs.randint(y0, max(y0 + 1, y1 - s))), int(rs.choice([x0, max(x0, x1 - s)]))
+                m[sy:sy + s, sx:sx + s] = True
+        masks[i] = m
+    return masks
+
+
+@pytest.mark.parametrize("hw,min_area", [((768, 1024), 100), ((1024, 1024), 100), ((500, 700), 30), ((768, 1024), 1000)])
+def test_windowed_cleanup_equals_full_frame_cleanup(cuda, hw, min_area):
+    """hip.small_regions_windowed (round 4): clean-up inside the masks' padded bounding boxes must give the masks, changed
+    flags and boxes of the full-frame clean-up -- and of the oracle (amg.py:267-291 via crowdsam/model.py:394-443) -- bit
+    for bit, for person-sized masks, masks cut by the frame border, an empty mask and a frame-filling one."""
+    from crowdsam_amd import hip
+    from oracle import pipeline_oracle as po
+    H, W = hw
+    n = 24
+    masks = _persons(n, H, W, seed=H + min_area)
+    ro, rc, rb = _oracle(masks[:8], min_area)                               # the oracle is slow: 8 masks against it ...
+    slots = np.random.RandomState(1).permutation(n + 2)[:n].astype(np.int32)
+    idx = torch.as_tensor(slots).to(cuda)
+    base = torch.zeros((n + 2, H, W), dtype=torch.uint8, device=cuda)
+    base[idx.long()] = torch.as_tensor(masks).to(cuda).to(torch.uint8)
+    boxes_in = po.batched_mask_to_box(torch.as_tensor(masks)).to(cuda)
+    a = base.clone()
+    ch_a, bx_a = hip.small_regions_idx(a, idx, min_area)                    # ... all of them against the full-frame kernel
+    b = base.clone()
+    ch_b, bx_b = hip.small_regions_windowed(b, idx, boxes_in, min_area)
+    assert torch.equal(a, b)
+    assert torch.equal(ch_a, ch_b) and torch.equal(bx_a, bx_b)
+    assert int(ch_a.sum()) >= 8                                             # the edits are not vacuous
+    assert np.array_equal(b[idx.long()[:8]].cpu().numpy().astype(bool), ro)
+    assert np.array_equal(ch_b.cpu().numpy()[:8], rc) and np.array_equal(bx_b.cpu().numpy()[:8], rb)
