@@ -1122,7 +1122,9 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
 // clean-up of the WINDOW is the clean-up of the frame (the ring is one background component, connected to everything
 // outside, and large; islands never touch it).  csam_mask_window_copy gathers the windows of n masks into a dense
 // [n, Hc, Wc] stack (zero outside the window) or scatters them back; the caller runs csam_small_regions_idx on the stack.
-// win[i] = (x0, y0, w, h) of mask i's window inside its H x W store slot; w <= Wc, h <= Hc.
+// win[i] = (x0, y0, w, h, ox, oy): mask i's window inside its H x W store slot and where it sits in the stack (ox + w <= Wc,
+// oy + h <= Hc) -- a window cut by the right / bottom frame edge is placed flush with the stack's right / bottom edge, so that
+// the zero padding never extends the frame beyond its true border.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TO_STORE>
 __global__ __launch_bounds__(256) void mask_window_copy_kernel(uint8_t* __restrict__ store, const int* __restrict__ slots,
@@ -1130,26 +1132,33 @@ __global__ __launch_bounds__(256) void mask_window_copy_kernel(uint8_t* __restri
                                                                uint8_t* __restrict__ crop, int H, int W, int Hc, int Wc) {
   const int n = blockIdx.z;
   if (TO_STORE && only && !only[n]) return;
-  const int x0 = win[n * 4 + 0], y0 = win[n * 4 + 1], w = win[n * 4 + 2], h = win[n * 4 + 3];
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (y >= Hc) return;
-  uint8_t* srow = store + ((long)(slots ? slots[n] : n) * H + (y0 + y)) * W + x0;
-  uint8_t* crow = crop + ((long)n * Hc + y) * Wc;
-  for (int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4; x < Wc; x += gridDim.x * 256) {
+  const int x0 = win[n * 6 + 0], y0 = win[n * 6 + 1], w = win[n * 6 + 2], h = win[n * 6 + 3], ox = win[n * 6 + 4],
+            oy = win[n * 6 + 5];
+  const int yc = blockIdx.y * 4 + (threadIdx.x >> 6);   // row of the stack
+  if (yc >= Hc) return;
+  const int y = yc - oy;                                // row of the window
+  const bool yin = y >= 0 && y < h;
+  const uint8_t* srow = store + ((long)(slots ? slots[n] : n) * H + (y0 + (yin ? y : 0))) * W + x0;
+  uint8_t* crow = crop + ((long)n * Hc + yc) * Wc;
+  for (int xc = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4; xc < Wc; xc += gridDim.x * 256) {
     if (TO_STORE) {
-      if (y < h) {
+      if (yin) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (x + e < w) srow[x + e] = crow[x + e];
+        for (int e = 0; e < 4; ++e) {
+          const int x = xc + e - ox;
+          if (x >= 0 && x < w) const_cast<uint8_t*>(srow)[x] = crow[xc + e];
+        }
       }
     } else {
       uint32_t v = 0;
-      if (y < h) {
+      if (yin) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (x + e < w) v |= (uint32_t)(srow[x + e] != 0) << (8 * e);
+        for (int e = 0; e < 4; ++e) {
+          const int x = xc + e - ox;
+          if (x >= 0 && x < w) v |= (uint32_t)(srow[x] != 0) << (8 * e);
+        }
       }
-      *(uint32_t*)(crow + x) = v;                       // Wc % 4 == 0
+      *(uint32_t*)(crow + xc) = v;                      // Wc % 4 == 0
     }
   }
 }

@@ -666,12 +666,13 @@ def small_regions_idx(mask_store, idx, min_area, out_store=None):
 
 
 def mask_window_copy(store, slots, windows, crop, to_store, only=None):
-    """Gather (to_store False) the windows ``windows`` int32 [n,4] = (x0, y0, w, h) of the masks store[slots[i]] into the dense
-    stack ``crop`` u8 [n, Hc, Wc] (zero outside the window), or scatter them back (``only`` u8 [n]: just those masks)."""
+    """Gather (to_store False) the windows ``windows`` int32 [n,6] = (x0, y0, w, h, ox, oy) of the masks store[slots[i]] into the
+    dense stack ``crop`` u8 [n, Hc, Wc] at (ox, oy) (zero elsewhere), or scatter them back (``only`` u8 [n]: just those masks)."""
     cap, H, W = store.shape
     n, Hc, Wc = crop.shape
     s8 = store.view(torch.uint8) if store.dtype == torch.bool else store
     assert s8.is_contiguous() and crop.is_contiguous() and crop.dtype == torch.uint8 and windows.dtype == torch.int32
+    assert windows.is_contiguous() and tuple(windows.shape) == (n, 6)
     assert slots is None or (slots.dtype == torch.int32 and slots.is_contiguous())
     call("csam_mask_window_copy", _stream(), _ptr(s8), _ptr(slots), _ptr(windows), _ptr(only), _ptr(crop), n, H, W, Hc, Wc,
          1 if to_store else 0)
@@ -683,24 +684,27 @@ SMALL_REGIONS_PAD = 16       # ring of background kept around a mask's box in th
 def small_regions_windowed(mask_store, idx, boxes_xyxy, min_area):
     """small_regions_idx restricted to the masks' bounding boxes (round 4).  remove_small_regions (amg.py:267-291) labels the
     whole frame, but every component of the mask and every hole lies inside the mask's box; with a 16-pixel ring of
-    background around the box, the clean-up of that WINDOW is the clean-up of the frame: the ring is a single background
-    component, it is connected to everything outside, its area (>= 2 * 16 * (w + h + 32) >= 1088 pixels) exceeds min_area, and
-    no island touches it.  Masks whose padded window fits inside the frame and covers at most a quarter of it are gathered
-    into one dense stack (csam_mask_window_copy), cleaned there and scattered back where they changed; the rest -- frame-
-    filling masks, masks near the border, empty masks -- take the full-frame call.  ``boxes_xyxy``: the masks' boxes in
-    store coordinates (inclusive maxima, batched_mask_to_box), the ones the statistics pass of the mask post-processing
-    produced.  Same return as small_regions_idx; bit-identical results (tests/test_regions_gpu.py)."""
+    background around the box, the clean-up of that WINDOW is the clean-up of the frame: the ring is background, connected to
+    everything outside the window exactly as the outside is connected in the frame, at least 16 x 16 pixels (> min_area)
+    wherever it is not the frame's own border strip, and no island touches it.  A window cut by a frame edge keeps that edge
+    as ITS edge (it is placed flush with the stack's edge on that side: the zero padding never extends the frame).  Masks
+    whose window covers at most a quarter of the frame are gathered into one dense stack (csam_mask_window_copy), cleaned
+    there and scattered back where they changed; the rest -- frame-filling masks, masks cut by two opposite frame edges,
+    empty masks -- take the full-frame call.  ``boxes_xyxy``: the masks' boxes in store coordinates (inclusive maxima,
+    batched_mask_to_box), the ones the statistics pass of the mask post-processing produced.  Same return as
+    small_regions_idx; bit-identical results (tests/test_regions_gpu.py)."""
     cap, H, W = mask_store.shape
     n = int(idx.shape[0])
     p = SMALL_REGIONS_PAD
-    if n < 4 or min_area > 2 * p * (2 + 2 * p):
+    if n < 4 or min_area > p * p:
         return small_regions_idx(mask_store, idx, min_area)
     import numpy as np
     b = boxes_xyxy.detach().to(torch.int64).cpu().numpy()              # one small D2H (n x 4)
-    wx0, wy0, wx1, wy1 = b[:, 0] - p, b[:, 1] - p, b[:, 2] + p, b[:, 3] + p
+    wx0, wy0 = np.maximum(b[:, 0] - p, 0), np.maximum(b[:, 1] - p, 0)
+    wx1, wy1 = np.minimum(b[:, 2] + p, W - 1), np.minimum(b[:, 3] + p, H - 1)
+    cl, ct, cr, cb = b[:, 0] - p < 0, b[:, 1] - p < 0, b[:, 2] + p > W - 1, b[:, 3] + p > H - 1      # cut by a frame edge
     ww, wh = wx1 - wx0 + 1, wy1 - wy0 + 1
-    small = (b[:, 2] >= b[:, 0]) & (b[:, 3] >= b[:, 1]) & (b[:, 2] + b[:, 3] > 0) & (wx0 >= 0) & (wy0 >= 0) & (wx1 < W) & \
-        (wy1 < H) & (ww * wh * 4 <= H * W)
+    small = (b[:, 2] >= b[:, 0]) & (b[:, 3] >= b[:, 1]) & (b[:, 2] + b[:, 3] > 0) & ~(cl & cr) & ~(ct & cb) & (ww * wh * 4 <= H * W)
     ns = int(small.sum())
     if ns < 4:
         return small_regions_idx(mask_store, idx, min_area)
@@ -711,14 +715,18 @@ def small_regions_windowed(mask_store, idx, boxes_xyxy, min_area):
     changed = torch.empty((n,), dtype=torch.int32, device=dev)
     boxes = torch.empty((n, 4), dtype=torch.float32, device=dev)
     sel_s = torch.as_tensor(np.nonzero(small)[0], device=dev)
-    win = torch.as_tensor(np.stack([wx0[small], wy0[small], ww[small], wh[small]], 1).astype(np.int32)).to(dev)
+    ox = np.where(cr[small], Wc - ww[small], 0)                        # flush right / bottom when cut there (left / top cuts sit
+    oy = np.where(cb[small], Hc - wh[small], 0)                        # at the stack's origin anyway)
+    win = torch.as_tensor(np.stack([wx0[small], wy0[small], ww[small], wh[small], ox, oy], 1).astype(np.int32)).to(dev)
     slots_s = idx[sel_s].contiguous()
     crop = torch.empty((ns, Hc, Wc), dtype=torch.uint8, device=dev)
     mask_window_copy(mask_store, slots_s, win, crop, False)
     ch_s, bx_s = small_regions_idx(crop, None, min_area)
-    nonempty = (bx_s != 0).any(1, keepdim=True)                        # a non-empty mask cannot have the box (0, 0, 0, 0): that
-    origin = win[:, [0, 1, 0, 1]].to(torch.float32)                    # pixel lies in the background ring of the window
-    bx_s = torch.where(nonempty, bx_s + origin, bx_s)
+    # stack -> store coordinates.  A non-empty mask cannot have the box (0, 0, 0, 0) unless it is the single pixel at the stack's
+    # origin, which is then the frame's (window cut left and top) origin pixel as well: the shift is 0 - 0 in that case
+    nonempty = (bx_s != 0).any(1, keepdim=True)
+    shift = (win[:, [0, 1, 0, 1]] - win[:, [4, 5, 4, 5]]).to(torch.float32)
+    bx_s = torch.where(nonempty, bx_s + shift, bx_s)
     mask_window_copy(mask_store, slots_s, win, crop, True, only=(ch_s != 0).to(torch.uint8))
     changed[sel_s], boxes[sel_s] = ch_s, bx_s
     if ns < n:

@@ -366,7 +366,8 @@ int csam_small_regions_idx(void* stream, const uint8_t* masks_base, const int* i
 /* Windows of masks <-> a dense [n, Hc, Wc] stack, for the bounding-box-restricted form of the clean-up above (amg.py:267-291
  * sees the whole frame, but every component of a mask lies inside its box: with a ring of background around the box the
  * clean-up of the window IS the clean-up of the frame -- crowdsam/model.py::postprocess_small_regions).  windows int32
- * [n,4] = (x0, y0, w, h) inside the H x W store slots, w <= Wc, h <= Hc, Wc % 4 == 0.  to_store 0: gather (stack zero outside
+ * [n,6] = (x0, y0, w, h, ox, oy): the window inside the H x W store slot and its place in the stack (ox + w <= Wc,
+ * oy + h <= Hc), Wc % 4 == 0.  to_store 0: gather (stack zero outside
  * the window, bytes normalised to 0 / 1); 1: scatter back (only_u8 [n] non-NULL: only the masks flagged there). */
 int csam_mask_window_copy(void* stream, void* store_u8, const int* slots_or_null, const int* windows, const void* only_u8_or_null,
                           void* crop_u8, int n, int H, int W, int Hc, int Wc, int to_store);

@@ -215,7 +215,7 @@ def _persons(n, H, W, seed):
     return masks
 
 
-@pytest.mark.parametrize("hw,min_area", [((768, 1024), 100), ((1024, 1024), 100), ((500, 700), 30), ((768, 1024), 1000)])
+@pytest.mark.parametrize("hw,min_area", [((768, 1024), 100), ((1024, 1024), 100), ((500, 700), 30), ((768, 1024), 250)])
 def test_windowed_cleanup_equals_full_frame_cleanup(cuda, hw, min_area):
     """hip.small_regions_windowed (round 4): clean-up inside the masks' padded bounding boxes must give the masks, changed
     flags and boxes of the full-frame clean-up -- and of the oracle (amg.py:267-291 via crowdsam/model.py:394-443) -- bit
@@ -239,4 +239,62 @@ def test_windowed_cleanup_equals_full_frame_cleanup(cuda, hw, min_area):
     assert torch.equal(ch_a, ch_b) and torch.equal(bx_a, bx_b)
     assert int(ch_a.sum()) >= 8                                             # the edits are not vacuous
     assert np.array_equal(b[idx.long()[:8]].cpu().numpy().astype(bool), ro)
+    assert np.array_equal(ch_b.cpu().numpy()[:8], rc) and np.array_equal(bx_b.cpu().numpy()[:8], rb)
+
+
+def _edge_cases(n, H, W, seed):
+    """Rectangles and ellipses pushed against every frame edge and corner (0 .. 20 pixels away, so cut, partly cut and uncut
+    windows all occur), with notches open to the frame edge, holes and specks of 1 .. 200 pixels right at the edge."""
+    rs = np.random.RandomState(seed)
+    masks = np.zeros((n, H, W), bool)
+    for i in range(n):
+        h, w = int(rs.randint(20, 200)), int(rs.randint(12, 120))
+        gap_y, gap_x = int(rs.choice([0, 0, 1, 3, 15, 16, 17, 20])), int(rs.choice([0, 0, 1, 3, 15, 16, 17, 20]))
+        side = i % 8                                                      # N, S, W, E, NW, NE, SW, SE
+        y0 = gap_y if side in (0, 4, 5) else (H - h - gap_y if side in (1, 6, 7) else int(rs.randint(40, H - h - 40)))
+        x0 = gap_x if side in (2, 4, 6) else (W - w - gap_x if side in (3, 5, 7) else int(rs.randint(40, W - w - 40)))
+        m = masks[i]
+        m[y0:y0 + h, x0:x0 + w] = True
+        for _ in range(10):                                               # holes / notches hugging the rectangle's outline
+            s, t = int(rs.randint(1, min(15, h // 2))), int(rs.randint(1, min(15, w // 2)))
+            ey = int(rs.choice([y0, y0 + h - s, rs.randint(y0, y0 + h - s + 1)]))
+            ex = int(rs.choice([x0, x0 + w - t, rs.randint(x0, x0 + w - t + 1)]))
+            m[ey:ey + s, ex:ex + t] = False
+            if rs.rand() < 0.5:                                           # ... closed again by a 1-pixel wall on the outline
+                m[ey, ex:ex + t] = True
+                m[ey:ey + s, ex] = True
+        ys, xs = np.nonzero(m)
+        by0, by1, bx0, bx1 = ys.min(), ys.max(), xs.min(), xs.max()
+        for _ in range(6):                                                # specks inside the box, some on the frame border
+            s = int(rs.randint(1, 13))
+            sy = int(rs.choice([by0, max(by0, by1 - s + 1), rs.randint(by0, max(by0 + 1, by1 - s + 1))]))
+            sx = int(rs.choice([bx0, max(bx0, bx1 - s + 1)]))
+            m[sy:min(sy + s, by1 + 1), sx:min(sx + s, bx1 + 1)] = True
+    return masks
+
+
+@pytest.mark.parametrize("hw,min_area,seed", [((768, 1024), 100, 0), ((600, 800), 100, 1), ((333, 517), 256, 2),
+                                              ((1024, 1024), 30, 3)])
+def test_windowed_cleanup_at_the_frame_border(cuda, hw, min_area, seed):
+    """Windows cut by a frame edge keep that edge (they are placed flush with the stack's edge on that side): holes, notches and
+    specks that touch the frame border must be treated exactly as the full-frame labelling treats them (amg.py:267-291 counts
+    a component that touches the border like any other)."""
+    from crowdsam_amd import hip
+    from oracle import pipeline_oracle as po
+    H, W = hw
+    n = 48
+    masks = _edge_cases(n, H, W, seed)
+    ro, rc, rb = _oracle(masks[:8], min_area)
+    idx = torch.arange(n, dtype=torch.int32, device=cuda)
+    base = torch.as_tensor(masks).to(cuda).to(torch.uint8)
+    boxes_in = po.batched_mask_to_box(torch.as_tensor(masks)).to(cuda)
+    a = base.clone()
+    ch_a, bx_a = hip.small_regions_idx(a, idx, min_area)
+    b = base.clone()
+    ch_b, bx_b = hip.small_regions_windowed(b, idx, boxes_in, min_area)
+    bad = [i for i in range(n) if not torch.equal(a[i], b[i])]
+    assert not bad, bad
+    assert torch.equal(ch_a, ch_b) and torch.equal(bx_a, bx_b)
+    assert int(ch_a.sum()) >= 24
+    assert np.array_equal(b[:8].cpu().numpy().astype(bool), ro)
     assert np.array_equal(ch_b.cpu().numpy()[:8], rc) and np.array_equal(bx_b.cpu().numpy()[:8], rb)
