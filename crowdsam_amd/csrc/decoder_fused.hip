@@ -1400,7 +1400,22 @@ constexpr int US_PAR = US_HFR + 2048;              // b2 [128] | b1 [256] | ln_g
 constexpr int US_WMX = US_PAR + 2048;              // [4 waves][2]
 constexpr int US_SMEM = US_WMX + 64;
 
-__global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B, int prompts_per_wg) {
+// developer probe (CSAM_DEFS_decoder_fused=-DCSAM_UP_RANKPROBE): the instruction mix and register footprint of a first conv
+// with K = 128 (the rank-112 form of DESIGN.md §8(7): 64 registers of per-prompt operand instead of 128 of W1) plus the per-image
+// table added to the accumulators, at THREE workgroups per CU.  Numerically meaningless (it multiplies half the key channels
+// and adds the other half): it answers "does a third wave per SIMD pay" before the producer chain is rebuilt for it.
+#ifdef CSAM_UP_RANKPROBE
+#define US_WG_PER_CU CSAM_UP_RANKPROBE        /* -DCSAM_UP_RANKPROBE=3 (or 2: the mix alone, at today's occupancy) */
+#define US_KS 4
+#define US_MG 1                               /* one 16-token sub-tile through BOTH convs at a time: half the live accumulators */
+#else
+#define US_WG_PER_CU 2
+#define US_KS 8
+#endif
+#ifndef US_MG
+#define US_MG 2                               /* 16-token sub-tiles that share one pass over W2' */
+#endif
+__global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArgs p, int B, int prompts_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1416,11 +1431,11 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
   const int first = b_first * TPP, last = b_last * TPP;
 
   // ---- launch-resident: W1 slice in registers, W2' and the small parameter vectors in LDS
-  half8_t w1[4][8];
+  half8_t w1[4][US_KS];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int ks = 0; ks < US_KS; ++ks)
       w1[ni][ks] = *(const half8_t*)(p.W1 + (long)(pos * 64 + ni * 16 + fr) * 256 + ks * 32 + fg * 8);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {                   // W2': 128 rows x 8 slots, 128-B rows, slot ^= row & 7
@@ -1475,19 +1490,24 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
     // (a) tile t landed (retired at barrier (b) of the previous tile, before its stores); outs free again
     I2S_BARRIER();
     if (t + 1 < last) issue_x(t + 1, cur ^ 1);
+#ifndef CSAM_UP_RANKPROBE
     if (tp == 0) {
       hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
       hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
     }
+#endif
 
     // ---- GEMM1 + LayerNorm2d + GELU per 16-token sub-tile: [64 co of this position] x [16 tokens], K = 256.
     // The ablation (r02) showed the GEMM1 phase at twice its MFMA time: with one fragment set in flight the
     // ~250-cycle LDS latency of a loaded CU is exposed on each of the 8 k-steps (4 MFMAs = 64 cycles of cover).  One
     // sub-tile at a time halves the live accumulators (16 instead of 32 registers) and pays for a 4-deep fragment
     // ring; sub-tile 1's MFMAs are independent of sub-tile 0's LayerNorm / GELU and may issue beneath them.
-    half8_t xf2[2][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int g = 0; g < 2 / US_MG; ++g) {
+    half8_t xf2[US_MG][2];
+#pragma unroll
+    for (int m = 0; m < US_MG; ++m) {
+      const int mi = g * US_MG + m;
       floatx4 a1[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
@@ -1499,14 +1519,26 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
 #pragma unroll
         for (int ks = 0; ks < XD - 1; ++ks) xf[ks] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          if (ks + XD - 1 < 8)
+        for (int ks = 0; ks < US_KS; ++ks) {
+          if (ks + XD - 1 < US_KS)
             xf[(ks + XD - 1) % XD] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + XD - 1) * 4 + fg) ^ fr) << 4));
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
           asm volatile("" ::: "memory");
         }
+#ifdef CSAM_UP_RANKPROBE
+        {
+          const half8_t tf0 = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((16 + fg * 2) ^ fr) << 4));
+          const half8_t tf1 = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((17 + fg * 2) ^ fr) << 4));
+          const float r0 = 1.0f + 1e-3f * (float)tf0[0];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              a1[ni][e] = __builtin_fmaf((float)(ni < 2 ? tf0 : tf1)[(ni & 1) * 4 + e], r0, a1[ni][e]);
+        }
+#endif
       }
 #else
 #ifdef CSAM_UP_NOG1_PIN      /* ablation: no GEMM1, but the 128 registers of the W1 slice stay live */
@@ -1555,8 +1587,8 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         CSAM_UP_GELU4(z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
-          xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
-          xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
+          xf2[m][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
+          xf2[m][nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
         }
       }
     }
@@ -1564,12 +1596,12 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
     // only 32 accumulator registers are live beside the 128 of the resident W1 slice
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-      floatx4 a2[2][4];                                 // seeded with the second conv's bias
+      floatx4 a2[US_MG][4];                             // seeded with the second conv's bias
 #pragma unroll
       for (int n2 = 0; n2 < 4; ++n2) {
         const floatx4 b2v = *(const floatx4*)(par + (ph * 4 + n2) * 16 + fg * 4);
-        a2[0][n2] = b2v;
-        a2[1][n2] = b2v;
+#pragma unroll
+        for (int m = 0; m < US_MG; ++m) a2[m][n2] = b2v;
       }
       UP_PRIO_M();
 #pragma unroll
@@ -1578,21 +1610,26 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         for (int n2 = 0; n2 < 4; ++n2) {
           const int row = (ph * 4 + n2) * 16 + fr;
           const half8_t wf = *(const half8_t*)(smem + US_W2S + row * 128 + (((s2 * 4 + fg) ^ (row & 7)) << 4));
-          a2[0][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[0][s2], a2[0][n2], 0, 0, 0);
-          a2[1][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[1][s2], a2[1][n2], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < US_MG; ++m) a2[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[m][s2], a2[m][n2], 0, 0, 0);
         }
       }
       UP_PRIO_V();
+#ifdef CSAM_UP_RANKPROBE
+      hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
+      hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
+#endif
 #pragma unroll
       for (int p2 = 0; p2 < 2; ++p2) {
         const int pos2 = ph * 2 + p2;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int m = 0; m < US_MG; ++m) {
+          const int mi = g * US_MG + m;
           float2_t z[4];
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[mi][p2 * 2 + h2][e], a2[mi][p2 * 2 + h2][e + 1]};
+            for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[m][p2 * 2 + h2][e], a2[m][p2 * 2 + h2][e + 1]};
           CSAM_UP_GELU4(z);
           half8_t ub;
 #pragma unroll
@@ -1615,6 +1652,7 @@ __global__ __launch_bounds__(256, 2) void upscale_stream_kernel(UpArgs p, int B,
         }
       }
     }
+    }   // g
     // (b) output half-rows complete; also retires the next tile's LDS-DMA (a whole tile old) BEFORE this tile's stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
@@ -1739,11 +1777,11 @@ __global__ __launch_bounds__(512, 1) void upscale_ws_kernel(UpArgs p, int B, int
   const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
   constexpr int PIECE = 256 * 16;
   const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
-  half8_t w1[4][8];
+  half8_t w1[4][US_KS];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int ks = 0; ks < US_KS; ++ks)
       w1[ni][ks] = *(const half8_t*)(p.W1 + (long)(pos * 64 + ni * 16 + fr) * 256 + ks * 32 + fg * 8);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {                   // W2': 128 rows x 8 slots, 128-B rows, slot ^= row & 7
@@ -2024,7 +2062,7 @@ extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const voi
     const int per = csam_cdiv(B, n_cu);               // ONE 8-wave workgroup per CU (4 matrix + 4 VALU waves)
     hipLaunchKernelGGL(upscale_ws_kernel, dim3(csam_cdiv(B, per)), dim3(512), UW_SMEM, (hipStream_t)stream, a, B, per);
   } else {
-    const int per = csam_cdiv(B, 2 * n_cu);
+    const int per = csam_cdiv(B, US_WG_PER_CU * n_cu);
     hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
   }
   CSAM_LAUNCH_CHECK("csam_upscale_stream");

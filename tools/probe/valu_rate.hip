@@ -1,0 +1,136 @@
+// What does the VALU pipe of a gfx950 SIMD charge per instruction class?  (round 4)
+// Every wave runs ITER x 16 INDEPENDENT instructions of one class (inline asm, 16 separate destination registers, so neither a
+// dependency nor the compiler is in the way) at 1 / 2 / 3 / 4 waves per SIMD; wave 0 of every workgroup brackets the loop
+// with s_memtime.  Printed: shader cycles per instruction as ONE wave sees it, and per SIMD (= that / waves per SIMD) -- the
+// second column is the pipe's price once it no longer falls with more waves.  The last rows time the upscaler's actual
+// GELU (csam_gelu_poly2_n<4>, the source the kernel compiles) per PAIR of evaluations.
+//   hipcc --offload-arch=gfx950 -O3 -I crowdsam_amd/csrc -o valu_rate tools/probe/valu_rate.hip && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include "csam_common.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int ITER = 512;
+
+#define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+template <int OP>
+__global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, float seed) {
+  float a[16];
+  f2 p[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    a[i] = seed + i + threadIdx.x;
+    p[i] = f2{seed + i, seed - i};
+  }
+  float k1 = 1.0001f + seed, k2 = 0.25f + seed;
+  f2 q1 = {k1, k1}, q2 = {k2, k2};
+  __syncthreads();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER; ++it) {
+    if (OP == 0) {
+#define M(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 1) {
+#define M(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(q1), "v"(q2));
+      REP16(M)
+#undef M
+    } else if (OP == 2) {
+#define M(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 3) {
+#define M(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(q1));
+      REP16(M)
+#undef M
+    } else if (OP == 4) {
+#define M(i) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a[i]));
+      REP16(M)
+#undef M
+    } else if (OP == 5) {
+#define M(i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+      REP16(M)
+#undef M
+    } else if (OP == 6) {
+#define M(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 7) {   // v_fma_f32 with the constants in SGPRs / literals as the compiler emits Horner steps
+#define M(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 15]), "s"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 8) {   // the upscaler's GELU, 4 pairs per call (13 instructions per pair), 4 calls per iteration
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f2 z[4] = {p[g * 4], p[g * 4 + 1], p[g * 4 + 2], p[g * 4 + 3]};
+        csam_gelu_poly2_n<4>(z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[g * 4 + q] = z[q] + q1;
+      }
+    } else if (OP == 9) {   // the same polynomial on scalars (csam_gelu_poly1_n<8>), 2 calls per iteration
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float z[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = a[g * 8 + q];
+        csam_gelu_poly1_n<8>(z);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[g * 8 + q] = z[q] + k1;
+      }
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += a[i] + p[i][0] + p[i][1];
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;
+  if (s == -1.2345f) out[0] = 0;
+}
+
+template <int OP>
+static void run(const char* name, double per_iter, const char* unit) {
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, 0);
+  const int n_cu = prop.multiProcessorCount;
+  unsigned long long* d;
+  (void)hipMalloc(&d, sizeof(unsigned long long) * n_cu * 4 * 4 * 4);
+  printf("%-44s", name);
+  for (int w = 1; w <= 4; ++w) {
+    const int blocks = n_cu * w;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d, 0.f);   // warm
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d, 0.f);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * 4);
+    (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double cyc = (double)h[h.size() / 2] / (ITER * per_iter);      // median wave
+    printf("  w=%d: %6.2f /wave %6.2f /SIMD", w, cyc, cyc / w);
+  }
+  printf("   [cycles per %s]\n", unit);
+  (void)hipFree(d);
+}
+
+int main() {
+  printf("shader cycles (s_memtime) per instruction, 16 independent instructions per loop body, %d iterations; w = waves per SIMD\n", ITER);
+  run<0>("v_fma_f32 (VGPR operands)", 16, "instruction");
+  run<7>("v_fma_f32 (VGPR x VGPR + SGPR)", 16, "instruction");
+  run<1>("v_pk_fma_f32", 16, "instruction");
+  run<3>("v_pk_mul_f32", 16, "instruction");
+  run<2>("v_med3_f32", 16, "instruction");
+  run<4>("v_cvt_f16_f32", 16, "instruction");
+  run<6>("v_pk_fma_f16", 16, "instruction");
+  run<5>("v_exp_f32", 16, "instruction");
+  run<8>("csam_gelu_poly2_n<4> (packed; + 1 pk_add)", 16, "PAIR of evaluations");
+  run<9>("csam_gelu_poly1_n<8> (scalar; + 1 add each)", 8, "PAIR of evaluations");
+  return 0;
+}
