@@ -243,6 +243,9 @@ constexpr int SMEM2_BYTES = KE_BYTES + VT_BYTES + T_BYTES;
 // the MFMA builtins hipcc selects the VGPR form here (launch bounds <= 256 registers) and recycled SrcC quads as
 // ds_read destinations two instructions behind the MFMA that reads them -- the hazard analysed in attn_flash.hip
 // (tools/lint_mfma_srcc.py flagged six such loads in this kernel).
+#ifndef CSAM_WA_ABL
+#define CSAM_WA_ABL 0      /* developer ablations: 1 = staging only, 2 = no staging */
+#endif
 #include "attn_window_asm.inc"
 
 __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restrict__ qkv,
@@ -259,31 +262,53 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
   const long ld = 3L * D;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero
-  for (int it = tid; it < (NPAD / 2) * 2 * 8; it += 256) {
-    const int ip = it >> 4, r = it & 15, which = 1 + (r >> 3), ch = r & 7;     // token pair, k|v, 8-channel chunk
-    half8_t v[2];
+  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero.
+  // A thread keeps ONE (k | v, 8-channel chunk) for all its token pairs (256 % 16 == 0), so the pad value is a per-thread
+  // constant and the 14 loads of a thread are branch-free (clamped addresses, selected afterwards) and ALL IN FLIGHT AT ONCE:
+  // round 4 found the compiler's branchy loop waiting for every load before issuing the next -- 13 serial round trips,
+  // 9.5 us of the kernel's 29 with qkv in L2 and most of its 49 us behind the qkv GEMM, where the operands come from HBM
+  const bool edge = (wy == 4) | (wx == 4);            // uniform: only these windows have pad tokens
+#if CSAM_WA_ABL == 2
+  if (qkv == nullptr)
+#endif
+  {
+    const int r = tid & 15, which = 1 + (r >> 3), ch = r & 7;
+    const int col = which * D + head * 64 + ch * 8;
+    half8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (edge) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int i = 2 * ip + t;
-      v[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      if (i < NTOK) {
-        const int y = wy * WS + i / WS, x = wx * WS + i % WS;
-        const int col = which * D + head * 64 + ch * 8;
-        if (y < 64 && x < 64) {
-          v[t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
-        } else {
+      for (int e = 0; e < 8; ++e) bv[e] = (half_t)qkv_bias[col + e];
+    }
+    half8_t v[7][2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[t][e] = (half_t)qkv_bias[col + e];
-        }
+    for (int i = 0; i < 7; ++i) {
+      const int ip = (tid >> 4) + 16 * i;             // token pair (104 of them: the last round is half empty)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tok = min(2 * ip + t, NTOK - 1);
+        const int y = min(wy * WS + tok / WS, 63), x = min(wx * WS + tok % WS, 63);
+        v[i][t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
       }
     }
-    if (which == 1) {
-      *(half8_t*)(Ke + (2 * ip) * KE_LD + ch * 8) = v[0];
-      *(half8_t*)(Ke + (2 * ip + 1) * KE_LD + ch * 8) = v[1];
-    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[0][e], v[1][e]};
+    for (int i = 0; i < 7; ++i) {
+      const int ip = (tid >> 4) + 16 * i;
+      if (ip < NPAD / 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int tok = 2 * ip + t;
+          const bool pad = (wy * WS + tok / WS >= 64) | (wx * WS + tok % WS >= 64);
+          if (tok >= NTOK) v[i][t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+          else if (pad) v[i][t] = bv;
+        }
+        if (which == 1) {
+          *(half8_t*)(Ke + (2 * ip) * KE_LD + ch * 8) = v[i][0];
+          *(half8_t*)(Ke + (2 * ip + 1) * KE_LD + ch * 8) = v[i][1];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[i][0][e], v[i][1][e]};
+        }
+      }
     }
   }
   for (int it = tid; it < 64 * 12; it += 256)       // keys 208..231 of V^T (read by the last, half-empty k-step)
@@ -308,10 +333,29 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
   unsigned vaddr[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) vaddr[dt] = lds0 + KE_BYTES + (dt * 16 + fr) * (VT_LD * 2) + fg * 8;
-  __syncthreads();
 
   const float sl2 = scale * 1.4426950408889634f;     // scores in base-2 units
   const float l2e = 1.4426950408889634f;
+#if CSAM_WA_ABL == 1
+  if (scale != 123.f) { if (tid == 0) out[blockIdx.x] = Ke[win] + Vt[head]; return; }
+#endif
+  // q fragments: fetched a tile ahead, branch-free (clamped address, pad / out-of-range selected afterwards)
+  half8_t qb[2] = {half8_t{0, 0, 0, 0, 0, 0, 0, 0}, half8_t{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (edge) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qb[ks][e] = (half_t)qkv_bias[head * 64 + (ks * 4 + fg) * 8 + e];
+  }
+  auto load_q = [&](int rt, half8_t (&q)[2]) {
+    const int qi = min(rt * 16 + fr, NTOK - 1);
+    const int y = min(wy * WS + qi / WS, 63), x = min(wx * WS + qi % WS, 63);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) q[ks] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + head * 64 + (ks * 4 + fg) * 8);
+  };
+  half8_t qn[2];
+  load_q(wave, qn);
+  __syncthreads();                                    // K / V^T staged (the first q fragments are already on their way)
   for (int rt = wave; rt < 13; rt += 4) {
     const int qi = rt * 16 + fr;
     const int qh = qi / WS, qw = qi % WS;
@@ -319,16 +363,9 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
     const bool inside = qi < NTOK && y < 64 && x < 64;
     half8_t qf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int col = head * 64 + (ks * 4 + fg) * 8;
-      qf[ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      if (inside) {
-        qf[ks] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
-      } else if (qi < NTOK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)qkv_bias[col + e];
-      }
-    }
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = inside ? qn[ks] : (qi < NTOK ? qb[ks] : half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+    load_q(min(rt + 4, 12), qn);                      // next tile (the last round re-reads tile 12: harmless)
     // bias table of this query tile: T[j][q] = relcat[j] . q, scattered to Th[kh = qh + 13 - j], Tw[kw = qw + 13 - (j - 27)]
     floatx4 t4[4];
     win_bias_mfma(t4, rf, qf);
@@ -451,31 +488,48 @@ __global__ __launch_bounds__(64 * NW80, 1) void win_attn2_hd80_kernel(const half
   const long ld = 3L * D;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero
-  for (int it = tid; it < (NPAD / 2) * 20; it += 64 * NW80) {
-    const int ip = it / 20, r = it % 20, which = 1 + r / 10, ch = r % 10;       // token pair, k|v, 8-channel chunk
-    half8_t v[2];
+  // ---- stage K (row-major, 16-B writes) and V^T (two keys per 4-B write); pad tokens take the qkv bias, keys >= 196 zero.
+  // As in win_attn2_kernel: a thread keeps one (k | v, 8-channel chunk) -- 500 of the 512 threads, 25 token pairs per round,
+  // five rounds -- so its ten loads are branch-free and in flight together
+  const bool edge = (wy == 4) | (wx == 4);
+  if (tid < 500) {
+    const int r = tid % 20, which = 1 + r / 10, ch = r % 10;
+    const int col = which * D + head * HD80 + ch * 8;
+    half8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (edge) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int i = 2 * ip + t;
-      v[t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      if (i < NTOK) {
-        const int y = wy * WS + i / WS, x = wx * WS + i % WS;
-        const int col = which * D + head * HD80 + ch * 8;
-        if (y < 64 && x < 64) {
-          v[t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
-        } else {
+      for (int e = 0; e < 8; ++e) bv[e] = (half_t)qkv_bias[col + e];
+    }
+    half8_t v[5][2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[t][e] = (half_t)qkv_bias[col + e];
-        }
+    for (int i = 0; i < 5; ++i) {
+      const int ip = tid / 20 + 25 * i;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tok = min(2 * ip + t, NTOK - 1);
+        const int y = min(wy * WS + tok / WS, 63), x = min(wx * WS + tok % WS, 63);
+        v[i][t] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
       }
     }
-    if (which == 1) {
-      *(half8_t*)(Ke + (2 * ip) * KE80_LD + ch * 8) = v[0];
-      *(half8_t*)(Ke + (2 * ip + 1) * KE80_LD + ch * 8) = v[1];
-    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[0][e], v[1][e]};
+    for (int i = 0; i < 5; ++i) {
+      const int ip = tid / 20 + 25 * i;
+      if (ip < NPAD / 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int tok = 2 * ip + t;
+          const bool pad = (wy * WS + tok / WS >= 64) | (wx * WS + tok % WS >= 64);
+          if (tok >= NTOK) v[i][t] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+          else if (pad) v[i][t] = bv;
+        }
+        if (which == 1) {
+          *(half8_t*)(Ke + (2 * ip) * KE80_LD + ch * 8) = v[i][0];
+          *(half8_t*)(Ke + (2 * ip + 1) * KE80_LD + ch * 8) = v[i][1];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) *(half2_t*)(Vt + (ch * 8 + e) * VT_LD + 2 * ip) = half2_t{v[i][0][e], v[i][1][e]};
+        }
+      }
     }
   }
   for (int it = tid; it < HD80 * 12; it += 64 * NW80)   // keys 208..231 of V^T (read by the last, half-empty k-step)
@@ -501,37 +555,43 @@ __global__ __launch_bounds__(64 * NW80, 1) void win_attn2_hd80_kernel(const half
   unsigned vaddr[5];
 #pragma unroll
   for (int dt = 0; dt < 5; ++dt) vaddr[dt] = lds0 + KE80_BYTES + (dt * 16 + fr) * (VT_LD * 2) + fg * 8;
-  __syncthreads();
 
   const float sl2 = scale * 1.4426950408889634f;
   const float l2e = 1.4426950408889634f;
+  // q fragments a tile ahead, branch-free (see win_attn2_kernel)
+  half8_t qb[2] = {half8_t{0, 0, 0, 0, 0, 0, 0, 0}, half8_t{0, 0, 0, 0, 0, 0, 0, 0}};
+  half4_t qbg = {0, 0, 0, 0};
+  if (edge) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qb[ks][e] = (half_t)qkv_bias[head * HD80 + (ks * 4 + fg) * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qbg[e] = (half_t)qkv_bias[head * HD80 + 64 + fg * 4 + e];
+  }
+  auto load_q = [&](int rt, half8_t (&q)[2], half4_t& g) {
+    const int qi = min(rt * 16 + fr, NTOK - 1);
+    const int y = min(wy * WS + qi / WS, 63), x = min(wx * WS + qi % WS, 63);
+    const half_t* src = qkv + (long)(y * 64 + x) * ld + head * HD80;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) q[ks] = *(const half8_t*)(src + (ks * 4 + fg) * 8);
+    g = *(const half4_t*)(src + 64 + fg * 4);
+  };
+  half8_t qn[2];
+  half4_t qng;
+  load_q(min(wave, 12), qn, qng);
+  __syncthreads();
   for (int rt = wave; rt < 13; rt += NW80) {
     const int qi = rt * 16 + fr;
     const int qh = qi / WS, qw = qi % WS;
     const int y = wy * WS + qh, x = wx * WS + qw;
     const bool inside = qi < NTOK && y < 64 && x < 64;
     half8_t qf[2];
-    half4_t qg = {0, 0, 0, 0};
+    half4_t qg = inside ? qng : (qi < NTOK ? qbg : half4_t{0, 0, 0, 0});
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int col = head * HD80 + (ks * 4 + fg) * 8;
-      qf[ks] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      if (inside) {
-        qf[ks] = *(const half8_t*)(qkv + (long)(y * 64 + x) * ld + col);
-      } else if (qi < NTOK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)qkv_bias[col + e];
-      }
-    }
-    {
-      const int col = head * HD80 + 64 + fg * 4;
-      if (inside) {
-        qg = *(const half4_t*)(qkv + (long)(y * 64 + x) * ld + col);
-      } else if (qi < NTOK) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) qg[e] = (half_t)qkv_bias[col + e];
-      }
-    }
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = inside ? qn[ks] : (qi < NTOK ? qb[ks] : half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+    load_q(min(rt + NW80, 12), qn, qng);
     floatx4 t4[4];
     win_bias_mfma80(t4, rf, rg, qf, qg);
 #pragma unroll
