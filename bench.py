@@ -310,6 +310,7 @@ def main():
             crowd_how = "calibrated on rank 0's warm-up frame, broadcast to all ranks"
 
     def timed_leg(collect_rows):
+        step_trace = [] if os.environ.get("CSAM_BENCH_TRACE") else None
         kept = pre = 0
         rws = [np.zeros((0, 6), np.float32)]
         if not args.serial:
@@ -327,6 +328,12 @@ def main():
             # frame i's tail; the first timed frame starts cold and the last one has no successor, so the region holds
             # exactly K whole images
             out = model.generate(frames[i], next_image=frames[i + 1] if (i < last and not args.serial) else None)
+            if step_trace is not None:
+                step_trace.append(time.perf_counter() - t0)
+                if getattr(model, "timings", None):    # CSAM_TIMING=1: device-synchronised stage times of this step
+                    print("step %d stages: " % (i - args.warmup) + " ".join("%s %.1f" % kv for kv in model.timings.items())
+                          + " | kept %d" % len(out["boxes"]), file=sys.stderr, flush=True)
+                    model.timings = {}
             kept += len(out["boxes"])
             pre += model.last_candidates
             if collect_rows:
@@ -334,6 +341,9 @@ def main():
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         barrier()
+        if step_trace:                                 # developer: CSAM_BENCH_TRACE=1 -> when each generate() returned (ms)
+            print("step returns (ms): " + " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip([0.0] + step_trace, step_trace)),
+                  file=sys.stderr, flush=True)
         return time.perf_counter() - t0, mine, kept, pre, rws
 
     elapsed, my_elapsed, n_kept, n_pre_nms, rows = timed_leg(True)

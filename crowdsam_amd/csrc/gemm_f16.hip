@@ -23,6 +23,12 @@
 
 namespace {
 
+// developer A/B (CSAM_DEFS_gemm_f16=-DCSAM_GEMM_NT): output stores with the non-temporal hint
+#ifdef CSAM_GEMM_NT
+#define GEMM_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define GEMM_ST(ptr, val) (*(ptr) = (val))
+#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
@@ -273,12 +279,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
           const int mr = p.res_mod > 0 ? m % p.res_mod : m;
           v += *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + n);
         }
-        *(floatx4*)((float*)p.C + (long)m * p.ldc + n) = v;
+        GEMM_ST((floatx4*)((float*)p.C + (long)m * p.ldc + n), v);
         if (p.C16) {                                   // the next projection's fp16 operand (the LayerNorm is folded into it)
           half4_t h;
 #pragma unroll
           for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
-          *(half4_t*)(p.C16 + (long)m * p.ldc16 + n) = h;
+          GEMM_ST((half4_t*)(p.C16 + (long)m * p.ldc16 + n), h);
         }
       }
       if (p.st_out) {                                  // 32 consecutive lanes hold one row's 128 columns
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       const int m = bm0 + row;
       if (m < p.M) {
         const int n = bn0 + ((sl ^ (row & 15)) << 3);
-        *(half8_t*)((half_t*)p.C + (long)m * p.ldc + n) = *(const half8_t*)(smem + c * 16);
+        GEMM_ST((half8_t*)((half_t*)p.C + (long)m * p.ldc + n), *(const half8_t*)(smem + c * 16));
       }
     }
   }
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int m = bm0 + row;
     if (m < p.M) {
       const int n = bn0 + ((sl ^ (row & 31)) << 3);
-      *(half8_t*)((half_t*)p.C + (long)m * p.ldc + n) = *(const half8_t*)(smem + c * 16);
+      GEMM_ST((half8_t*)((half_t*)p.C + (long)m * p.ldc + n), *(const half8_t*)(smem + c * 16));
     }
   }
 }

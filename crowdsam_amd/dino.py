@@ -67,7 +67,8 @@ class DinoPlan:
         # round 4: LayerNorm folded into the qkv / fc1 projections (csam_gemm_f16_ln); block 0's first LayerNorm stays a
         # kernel (its input's cls row comes from a copy, not from a projection)
         self.ln_fold = os.environ.get("CSAM_LN_FOLD", "1") != "0"
-        self.fc1_split = 4096 if os.environ.get("CSAM_DINO_FC1_SPLIT", "0") == "1" else 1 << 30      # A/B: no end-to-end gain measured
+        # fc1 in two launches (4096 + 1234 rows), both on the ping-pong kernel; CSAM_DINO_FC1_SPLIT=0: one 336-tile launch
+        self.fc1_split = 4096 if os.environ.get("CSAM_DINO_FC1_SPLIT", "1") != "0" else 1 << 30
         if self.ln_fold:
             for i, bl in enumerate(self.blocks):
                 B = f"blocks.{i}."
@@ -113,7 +114,9 @@ class DinoPlan:
                                 stats_out=st)
                 # fc1 in two row ranges: 4096 rows are exactly ONE round of the 256 x 256 ping-pong kernel (16 x 16 tiles on
                 # 256 CUs, as in the SAM encoder); all 5330 rows would be 336 tiles = 1.3 rounds and fall back to the
-                # 128 x 128 kernel (77 us at 580 TFLOP/s).  The remaining 1234 rows take that kernel alone.
+                # 128 x 128 kernel (77 us at 580 TFLOP/s alone, 127 us beside the SAM encoder's stream).  The remaining 1234
+                # rows are 80 more tiles of the same kernel.  Serial trace: -1.4 ms of GEMM time per frame
+                # (profiles/r04_dino_fc1_split.txt).
                 S = min(self.fc1_split, T)
                 hip.gemm_f16_ln(x16[:S], b["fc1_wf"], ws["mlp"][:S], bias=b["fc1_bf"], act=hip.ACT_GELU, M=S, stats_in=st[:S],
                                 colsum=b["fc1_cs"], eps=1e-6)

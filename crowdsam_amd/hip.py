@@ -752,6 +752,26 @@ def mask_nms(masks, scores, thr):
     return keep[: int(count.item())]
 
 
+_D2H = {"buf": None}
+
+
+def to_host_numpy(t):
+    """Device tensor -> numpy array through a reusable PINNED staging buffer (grown geometrically).  A pageable ``.cpu()`` of
+    the change positions of a frame with noise-like masks (100+ MB) runs at a few GB/s and was a 30-70 ms stall of single
+    frames (bench.py CSAM_BENCH_TRACE=1); pinned, the same copy runs at PCIe speed.  The returned array is a VIEW of the
+    staging buffer: consume (or copy) it before the next call."""
+    import numpy as np
+    n = t.numel() * t.element_size()
+    if n == 0:
+        return np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+    if _D2H["buf"] is None or _D2H["buf"].numel() < n:
+        _D2H["buf"] = torch.empty(max(2 * n, 1 << 24), dtype=torch.uint8).pin_memory()
+    host = _D2H["buf"][:n].view(t.dtype).view(t.shape)
+    host.copy_(t.contiguous(), non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
+
+
 def rle_encode(masks, idx=None, boxes=None):
     """Column-major change positions of u8 masks -> (positions uint32 (device), offsets int64 (host, N+1)).
     ``idx`` None: masks [N,H,W]; else masks is a store [cap,H,W] and idx (int32 device [N]) names the slots to encode.

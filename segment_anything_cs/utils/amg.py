@@ -172,7 +172,7 @@ def mask_to_rle_arrays(tensor, idx=None, boxes=None):
         # ``boxes`` (build extension): XYXY boxes of the masks (inclusive maxima, batched_mask_to_box) -- the encoder then reads the
         # boxes instead of the frames
         pos, offs = hip.rle_encode(m8, idx, None if boxes is None else boxes.to(torch.int32).contiguous())
-        pos = pos.cpu().numpy().astype(np.int64)
+        pos = hip.to_host_numpy(pos).astype(np.int64)              # pinned staging buffer; astype copies out of it
         first = (m8[:, 0, 0] if idx is None else m8[idx.long(), 0, 0]).cpu().numpy().astype(bool)
         # run lengths of ALL masks in one pass (a crowded frame keeps hundreds of masks: per-mask numpy calls were the
         # tail's largest host cost): per mask the sequence [0 if the first pixel is set] 0 pos... hw, differenced
