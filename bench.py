@@ -549,12 +549,13 @@ def main():
                     "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_note": tr_note,
                     "launches": up["calls"], "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch,
                     "note": ("dominant kernel of the timed region.  HBM is the roof SURVEY.md 8d assigns to the decoder sweep; PMC "
-                             "traffic equals the algorithmic bytes (no wasted re-reads), and what bounds the kernel is the VALU "
-                             "pipe: 12.9 G erf-GELU evaluations per launch as packed-fp32 polynomials (~1.5 ms of pure VALU-pipe "
-                             "time per 2048 prompts at any occupancy).  The matrix and vector pipes are SEPARATE and overlap across "
-                             "waves of a SIMD, but not inside one wave (profiles/r03_valu_mfma_overlap_probe.txt, DESIGN.md "
-                             "section 4.2a); ablations: no GELU -40 %, no first-conv MFMAs -18 %, no hyper MFMAs -7 %, no stores "
-                             "-3 % (profiles/r03_upscale_ablation.txt)")}
+                             "traffic equals the algorithmic bytes (no wasted re-reads).  What bounds the kernel is per-SIMD pipe time: "
+                             "12.9 G erf-GELU evaluations per launch as packed-fp32 polynomials (870 VALU + 112 MFMA instructions per "
+                             "32-token tile and wave).  Round 4 measured the same throughput at 1, 2 and 3 resident waves per SIMD "
+                             "(wave-specialised kernel, third-wave probe: profiles/r04_upscale_wave_specialised.txt, "
+                             "r04_upscale_rank_probe.txt, r04_valu_rate.txt; DESIGN.md section 4.2e): occupancy and scheduling are not "
+                             "levers, only less work per pixel is.  Ablations: no GELU -40 %, no first-conv MFMAs -18 %, no hyper MFMAs "
+                             "-7 %, no stores -3 % (profiles/r03_upscale_ablation.txt)")}
             else:
                 res["roofline"] = res["roofline_gemm"]
         if not args.no_cpu_baseline and world == 1:
