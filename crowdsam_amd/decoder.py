@@ -122,6 +122,15 @@ class DecoderPlan:
         # (both layers), layer 1's norm4 gamma / beta into the consumers of the final key state (upscaler first conv, final
         # attention).  Only on the csam_i2t_t2i path (B >= 256); CSAM_I2T_FOLD=0 keeps the plain kernel.
         self.i2t_fold = os.environ.get("CSAM_I2T_FOLD", "1") != "0"
+        # small batches (the shipped EPS configuration: 32 prompts) are a chain of ~65 launches that each fill a few CUs: the
+        # independent branches of the chain -- image->token pass of layer l beside the token-side prologue of layer l + 1, the
+        # IoU heads beside the hyper-network / upscaler / classifier branch -- are captured on a second stream (fork / join
+        # inside the hipGraph).  Same kernels on the same operands: bit-identical -- and SLOWER: the shipped EPS frame takes
+        # 38.0 ms with the forked graphs against 28.1 ms with one stream (profiles/r04_eps_fork_join.txt): a hipGraph with
+        # parallel branches is replayed through cross-stream events that cost more than the ~100 us per batch the branches
+        # overlap.  Kept as a measured experiment (CSAM_DEC_FORK=1), off by default
+        self.fork = os.environ.get("CSAM_DEC_FORK", "0") == "1"
+        self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -278,7 +287,7 @@ class DecoderPlan:
             kv=u(BT, 256), qi=u(BT, 128), att=u(BT, 128), up2=u(BT * 4, 128),
             hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
             iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512), cls=e(B * 4, self.n_class, dt=f),
-            hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f),
+            hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f), g1b=e(B * 4, 256), g2b=e(B * 4, 256, dt=f),
             pooled16=e(B * 4, 256),
             stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
@@ -431,9 +440,21 @@ class DecoderPlan:
                      and self.t2i_stream and self.i2t_t2i and B >= 256)
         y_ready = False
         keys_plain = False
+        forked = self.fork and B < 256 and self.fused and self.i2t_stream and not fuse_next
+        main_s = side_s = None
+        if forked:
+            main_s = torch.cuda.current_stream()
+            if self._fork_stream is None:
+                self._fork_stream = torch.cuda.Stream(device=coords_f32.device)
+            side_s = self._fork_stream
+        sa_done, joined = False, True               # next layer's self-attention already issued / side stream joined
         for li, L in enumerate(self.layers):
-            if not y_ready:
+            if not y_ready and not sa_done:
                 self_attn(li, L)
+            sa_done = False
+            if not joined:                          # the keys of the previous layer's image->token pass (side stream)
+                main_s.wait_stream(side_s)
+                joined = True
             # ---- token -> image cross attention (:173-177)
             if li == 0:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
@@ -473,6 +494,19 @@ class DecoderPlan:
                                 ws["t2i_q"], ws["t2i_y"], B, T_IMG, ws["i2t_t2i_ws"], fold=3 if self.i2t_fold else 0)
                     keys_plain = self.i2t_fold          # the final key state holds plain normalised values
                 y_ready = True
+            elif stream and forked and li + 1 < len(self.layers):
+                # fork: this layer's image->token pass on the side stream, the next layer's token self-attention + norm1 here
+                side_s.wait_stream(main_s)
+                with torch.cuda.stream(side_s):
+                    if li == 0:
+                        hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                       L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
+                    else:
+                        hip.i2t_stream(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                       L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],
+                                       qpe=L["i2t_q_peb"])
+                self_attn(li + 1, self.layers[li + 1])
+                sa_done, joined = True, False
             elif stream:
                 if li == 0 and self.i2t_rank and B >= 256:
                     # hoisted-Q layer in its rank-56 form (whole prompts per workgroup: needs >= 256 prompts)
@@ -525,6 +559,25 @@ class DecoderPlan:
             hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
             hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
         tok16 = hs16.view(B, 7, 256)
+        # ---- IoU head (:184) + parallel residual head (:194-198)
+        def iou_heads(g1, g2):
+            hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)
+            hip.gemm_f16(g1[:B], self.iou_w16[1], out=g2[:B], bias=self.iou_head[1][1], act=hip.ACT_RELU)
+            iou0 = hip.linear_f32(g2[:B], self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
+            fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
+            fused[:, :, :256] = tok16[:, 0].unsqueeze(1)     # plumbing: concat [iou_tok | mask_tok_l]
+            fused[:, :, 256:] = tok16[:, 1:5]
+            ft = ws["fused_tok"][:B * 4]
+            hip.gemm_f16(ft, self.par_w16[0], out=g1[:B * 4], bias=self.par_iou_head[0][1], act=hip.ACT_RELU)
+            hip.gemm_f16(g1[:B * 4], self.par_w16[1], out=g2[:B * 4], bias=self.par_iou_head[1][1], act=hip.ACT_RELU)
+            return hip.linear_f32(g2[:B * 4], self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
+                                  residual=iou0.view(B * 4, 1))
+
+        iou = None
+        if forked:                                   # fork: the heads need the tokens only; their own scratch (g1b / g2b)
+            side_s.wait_stream(main_s)
+            with torch.cuda.stream(side_s):
+                iou = iou_heads(ws["g1b"], ws["g2b"])
         # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
         hh1, hh2 = ws["hh1"], ws["hh2"]
         hip.gemm_f16_batched(tok16[:, 1], 7 * 256, 256, self.hyper_w0, 256, 256 * 256, hh1, 256, hh1.stride(0),
@@ -540,19 +593,9 @@ class DecoderPlan:
                self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm, self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
         else:
             hip.hyper_masks(ws["up2"], ws["hyper"], masks, B)
-        # ---- IoU head (:184) + parallel residual head (:194-198)
         g1, g2 = ws["g1"], ws["g2"]
-        hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)
-        hip.gemm_f16(g1[:B], self.iou_w16[1], out=g2[:B], bias=self.iou_head[1][1], act=hip.ACT_RELU)
-        iou0 = hip.linear_f32(g2[:B], self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
-        fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
-        fused[:, :, :256] = tok16[:, 0].unsqueeze(1)     # plumbing: concat [iou_tok | mask_tok_l]
-        fused[:, :, 256:] = tok16[:, 1:5]
-        ft = ws["fused_tok"][:B * 4]
-        hip.gemm_f16(ft, self.par_w16[0], out=g1[:B * 4], bias=self.par_iou_head[0][1], act=hip.ACT_RELU)
-        hip.gemm_f16(g1[:B * 4], self.par_w16[1], out=g2[:B * 4], bias=self.par_iou_head[1][1], act=hip.ACT_RELU)
-        iou = hip.linear_f32(g2[:B * 4], self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
-                             residual=iou0.view(B * 4, 1))
+        if iou is None:
+            iou = iou_heads(g1, g2)
         # ---- PWD-Net pooling + classifier (:186-192)
         R = B * 4
         if self.fused:      # plane max already in stats[:,0] (upscale kernel atomics); one pass over the logits
@@ -566,4 +609,6 @@ class DecoderPlan:
         hip.add_cast(ws["pooled"][:R], out16=ws["pooled16"][:R])
         hip.gemm_f16(ws["pooled16"][:R], self.cls_w16, out=g2[:R], bias=b1, act=hip.ACT_RELU)
         cls = hip.linear_f32(g2[:R], w2, b2, out=ws["cls"][:R])
+        if forked:
+            main_s.wait_stream(side_s)              # join: the heads
         return masks, iou.view(B, 4), cls.view(B, 4, self.n_class)
