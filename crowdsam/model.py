@@ -41,6 +41,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
+_WORK_STREAM = os.environ.get("CSAM_WORK_STREAM", "1") != "0"
 _WINDOWED_REGIONS = os.environ.get("CSAM_CC_WINDOWED", "1") != "0"      # small-region clean-up inside the masks' boxes
 
 
@@ -120,6 +121,7 @@ class CrowdSAM:
         self._prefetched = None
         self._pf_stream = None
         self._hi_stream = None
+        self._work_stream = None
 
     def load_sam_model(self, sam_model, sam_arch, sam_checkpoint, sam_adapter_checkpoint, dino_model, n_class,
                        sam_state_dict=None):
@@ -168,7 +170,21 @@ class CrowdSAM:
         (tests/test_pipelined_gpu.py).  Ignored with crop_n_layers > 0 (the crops of one frame share the buffers)."""
         self._next_image = next_image if self.crop_n_layers == 0 else None
         try:
-            return self._generate_masks(image)
+            if not _WORK_STREAM or self.device.type != "cuda":
+                return self._generate_masks(image)
+            # the whole frame on a non-default stream of its own: torch's default stream is HIP's legacy NULL stream, whose
+            # implicit synchronisation with every blocking stream costs the pipelined modes 1.3 ms per frame
+            # (profiles/r04_eps_pipeline_overlap.txt).  Callers on other streams are ordered before / after it.
+            if self._work_stream is None:
+                self._work_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            cur = torch.cuda.current_stream(self.device)
+            if cur == self._work_stream:
+                return self._generate_masks(image)
+            self._work_stream.wait_stream(cur)
+            with torch.cuda.stream(self._work_stream):
+                out = self._generate_masks(image)
+            cur.wait_stream(self._work_stream)
+            return out
         finally:
             self._next_image = None
 
@@ -346,7 +362,11 @@ class CrowdSAM:
         # batch, each waiting for the one before -- goes onto a HIGH-priority stream: its workgroups are dispatched ahead of the
         # encoder GEMMs' whenever a CU frees up, so the chain's latency stays close to what it is on an idle GPU
         sweep_ctx = contextlib.ExitStack()
-        if early:
+        if early and self._work_stream is not None and torch.cuda.current_stream() == self._work_stream:
+            early_hi = False                        # the frame's own stream already has the high priority
+        else:
+            early_hi = early
+        if early_hi:
             if self._hi_stream is None:
                 self._hi_stream = torch.cuda.Stream(device=dev, priority=-1)
             self._hi_stream.wait_stream(torch.cuda.current_stream())
@@ -413,7 +433,7 @@ class CrowdSAM:
                 count += batch_size
                 n_batches += 1
         sweep_ctx.close()
-        if early:
+        if early_hi:
             main_stream.wait_stream(self._hi_stream)
         self.predictor.reset_image()
         if self._next_image is not None:

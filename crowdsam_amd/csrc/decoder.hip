@@ -613,6 +613,28 @@ __global__ __launch_bounds__(256) void rowscale_bias_kernel(const float* __restr
   for (int c = threadIdx.x; c < N; c += 256) out[(long)r * N + c] = P[(long)r * N + c] * inv + bias[c];
 }
 
+// split-K epilogue: out[r,c] = (sum_s P[s][r][c]) * (stats ? 1 / stats[r][1] : 1) + bias[c] + residual[r,c], the partial
+// products summed in the order s = 0 .. S-1 (bit-repeatable).  4 columns per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, int S, long slab,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, long ldr,
+                                                            float* __restrict__ out, long ldo, int rows, int N) {
+  const int n4 = N >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * n4) return;
+  const int r = (int)(i / n4), c = (int)(i % n4) * 4;
+  floatx4 acc = *(const floatx4*)(P + (long)r * N + c);
+  for (int s = 1; s < S; ++s) acc += *(const floatx4*)(P + s * slab + (long)r * N + c);
+  if (stats) {
+    const float inv = 1.f / stats[r * 2 + 1];
+    acc *= inv;
+  }
+  if (bias) acc += *(const floatx4*)(bias + c);
+  if (residual) acc += *(const floatx4*)(residual + (long)r * ldr + c);
+  *(floatx4*)(out + (long)r * ldo + c) = acc;
+}
+
 }  // namespace
 
 extern "C" int csam_point_tokens(void* stream, const float* coords, const float* gauss, const float* out_tokens5,
@@ -743,6 +765,19 @@ extern "C" int csam_pool_adjoint_mfma(void* stream, const float* masks, float* s
   hipLaunchKernelGGL(pool_adjoint_mfma_kernel, dim3(csam_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, masks, stats,
                      (const AdjMfma*)tables_dev, (half_t*)w_f16, ldw, rows);
   CSAM_LAUNCH_CHECK("csam_pool_adjoint_mfma");
+  return CSAM_OK;
+}
+
+extern "C" int csam_splitk_reduce(void* stream, const float* partials, int splits, long slab_stride,
+                                  const float* stats_or_null, const float* bias_or_null, const float* residual_or_null,
+                                  long ldr, float* out, long ldo, int rows, int N) {
+  CSAM_REQUIRE(partials && out && splits > 0 && rows > 0 && N > 0 && N % 4 == 0 && ldo % 4 == 0 && slab_stride % 4 == 0 &&
+                   (!residual_or_null || ldr % 4 == 0),
+               "csam_splitk_reduce: bad args");
+  const long n = (long)rows * (N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)csam_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                     splits, slab_stride, stats_or_null, bias_or_null, residual_or_null, ldr, out, ldo, rows, N);
+  CSAM_LAUNCH_CHECK("csam_splitk_reduce");
   return CSAM_OK;
 }
 

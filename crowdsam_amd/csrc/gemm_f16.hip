@@ -561,7 +561,17 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     const char* e = getenv("CSAM_GEMM_96");
     use96 = e ? atoi(e) : 1;
   }
-  const bool mid = use96 && !small && t128 < 512 && t96 <= 512;
+  bool mid = use96 && !small && t128 < 512 && t96 <= 512;
+  // developer A/B (tools/debug/gemm_switch_ab.sh): CSAM_GEMM_ROWS=64|96|128 forces the tile height of the 128-column kernel
+  static int force_rows = -1;
+  if (force_rows < 0) {
+    const char* e = getenv("CSAM_GEMM_ROWS");
+    force_rows = e ? atoi(e) : 0;
+  }
+  bool small_f = small;
+  if (force_rows == 64) { small_f = true; mid = false; }
+  else if (force_rows == 96) { small_f = false; mid = true; }
+  else if (force_rows == 128) { small_f = false; mid = false; }
   static int variant = -1, xcd = 1;
   if (variant < 0) {
     const char* e = getenv("CSAM_GEMM_VARIANT");
@@ -586,7 +596,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }
-  dim3 grid((N / BN) * csam_cdiv(M, small ? 64 : mid ? 96 : BM), 1, batch);
+  dim3 grid((N / BN) * csam_cdiv(M, mid ? 96 : small_f ? 64 : BM), 1, batch);
 #define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
@@ -600,7 +610,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   }
   if (mid) {
     CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
-  } else if (small) {
+  } else if (small_f) {
     if (variant == 0) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
     else if (variant == 1) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 4, 32)
     else CSAM_GEMM_LAUNCH(2, 4, 2, 2, 6, 32)

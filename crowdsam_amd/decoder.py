@@ -130,6 +130,9 @@ class DecoderPlan:
         # parallel branches is replayed through cross-stream events that cost more than the ~100 us per batch the branches
         # overlap.  Kept as a measured experiment (CSAM_DEC_FORK=1), off by default
         self.fork = os.environ.get("CSAM_DEC_FORK", "0") == "1"
+        # small batches: the two skinny GEMMs with a long K (MLP second layer K = 2048: 26 us on 4 workgroups; PWD-Net pooling
+        # product K = 5376: 54 us) as split-K launches summed in slice order (hip.gemm_f16_splitk).  CSAM_DEC_SPLITK=0: single pass
+        self.splitk = os.environ.get("CSAM_DEC_SPLITK", "1") != "0"
         self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -288,6 +291,7 @@ class DecoderPlan:
             hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
             iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512), cls=e(B * 4, self.n_class, dt=f),
             hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f), g1b=e(B * 4, 256), g2b=e(B * 4, 256, dt=f),
+            splitk=e(12 * min(B, 256) * 7 * 256, dt=f),
             pooled16=e(B * 4, 256),
             stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
             pooled_raw=e(B * 4, 256, dt=f), pooled=e(B * 4, 256, dt=f),
@@ -469,7 +473,11 @@ class DecoderPlan:
                     cast16=q16)
             # ---- MLP (:180-183)
             hip.gemm_f16(q16, L["mlp1_w"], out=ws["mlp_h"][:M7], bias=L["mlp1_b"], act=hip.ACT_RELU)
-            hip.gemm_f16(ws["mlp_h"][:M7], L["mlp2_w"], out=ws["tmp32"][:M7], bias=L["mlp2_b"], residual=queries)
+            if self.splitk and B < 256:
+                hip.gemm_f16_splitk(ws["mlp_h"][:M7], L["mlp2_w"], ws["tmp32"][:M7], 8, ws["splitk"], bias=L["mlp2_b"],
+                                    residual=queries)
+            else:
+                hip.gemm_f16(ws["mlp_h"][:M7], L["mlp2_w"], out=ws["tmp32"][:M7], bias=L["mlp2_b"], residual=queries)
             ln_queries(L["norm3_g"], L["norm3_b"])
             # ---- image -> token cross attention (:186-190): keys = LN4(keys + out_proj(attn))
             stream = self.fused and self.i2t_stream
@@ -603,8 +611,12 @@ class DecoderPlan:
         else:
             hip.softmax_stats(masks, ws["stats"], R)
             hip.pool_adjoint(masks, ws["stats"], self.taps, ws["wadj"], R)
-        hip.gemm_f16(ws["wadj"][:R], st["GT"], out=ws["pooled_raw"][:R])
-        hip.rowscale_bias(ws["pooled_raw"], ws["stats"], self.dino_proj_b, ws["pooled"], R, 256)
+        if self.splitk and B < 256:                 # pooled = (wadj . GT^T) / sum + bias: the row scale rides in the reduction
+            hip.gemm_f16_splitk(ws["wadj"][:R], st["GT"], ws["pooled"][:R], 12, ws["splitk"], bias=self.dino_proj_b,
+                                rowstats=ws["stats"])
+        else:
+            hip.gemm_f16(ws["wadj"][:R], st["GT"], out=ws["pooled_raw"][:R])
+            hip.rowscale_bias(ws["pooled_raw"], ws["stats"], self.dino_proj_b, ws["pooled"], R, 256)
         (w1, b1), (w2, b2) = self.classifier
         hip.add_cast(ws["pooled"][:R], out16=ws["pooled16"][:R])
         hip.gemm_f16(ws["pooled16"][:R], self.cls_w16, out=g2[:R], bias=b1, act=hip.ACT_RELU)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "csam_softmax_stats": [_P, _P, _P, _I],
     "csam_pool_adjoint": [_P, _P, _P, _P, _P, _L, _I],
     "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
+    "csam_splitk_reduce": [_P, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I],
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "csam_mask_post_scored": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
@@ -459,6 +460,25 @@ def gemm_f16_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=
     """batch independent GEMMs (grid.z): element strides sa/sw/sc/sbias between problems."""
     call("csam_gemm_f16_batched", _stream(), _ptr(a), lda, sa, _ptr(w), ldw, sw, _ptr(out), ldc, sc, _dt(out.dtype),
          _ptr(bias), sbias, act, M, N, K, batch)
+    return out
+
+
+def gemm_f16_splitk(a, w, out, splits, scratch, bias=None, residual=None, rowstats=None, M=None):
+    """fp32 out[M,N] = (a[M,K] @ w[N,K]^T) * (1 / rowstats[:,1]) + bias + residual with K cut into ``splits`` slices that run as
+    one batched launch (csam_gemm_f16_batched) into ``scratch`` (fp32, >= splits * M * N) and are summed in slice order
+    (csam_splitk_reduce).  For skinny products (M of a few hundred rows, K in the thousands) whose single-pass form is a serial
+    chain of K / 64 steps on a handful of workgroups."""
+    if M is None:
+        M = a.shape[0]
+    K = a.shape[1]
+    N = w.shape[0]
+    assert a.dtype == torch.float16 and w.dtype == torch.float16 and out.dtype == torch.float32 and scratch.dtype == torch.float32
+    assert K % (64 * splits) == 0 and scratch.numel() >= splits * M * N and a.stride(-1) == 1 and w.stride(-1) == 1
+    ks = K // splits
+    call("csam_gemm_f16_batched", _stream(), _ptr(a), a.stride(0), ks, _ptr(w), w.stride(0), ks, _ptr(scratch), N, M * N,
+         _dt(torch.float32), None, 0, ACT_NONE, M, N, ks, splits)
+    call("csam_splitk_reduce", _stream(), _ptr(scratch), splits, M * N, _ptr(rowstats), _ptr(bias), _ptr(residual),
+         0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, N)
     return out
 
 

@@ -187,6 +187,14 @@ int csam_pool_adjoint_mfma(void* stream, const float* masks, float* stats, const
                            long ldw, int rows);
 int csam_rowscale_bias(void* stream, const float* P, const float* stats, const float* bias, float* out, int rows,
                        int N);
+/* Epilogue of a split-K GEMM (round 4; the small-batch decoder's skinny GEMMs -- mask_decoder.py's MLP second layer
+ * transformer.py:215-216 at K = 2048 and the PWD-Net pooling product at K = 5376 -- run as `splits` K-slices through
+ * csam_gemm_f16_batched and are summed here in slice order, bit-repeatably):
+ * out[r,c] = (sum_s partials[s * slab_stride + r * N + c]) * (stats ? 1 / stats[2 r + 1] : 1) + bias[c] + residual[r * ldr + c];
+ * stats / bias / residual may be NULL.  N % 4 == 0. */
+int csam_splitk_reduce(void* stream, const float* partials, int splits, long slab_stride, const float* stats_or_null,
+                       const float* bias_or_null, const float* residual_or_null, long ldr, float* out, long ldo, int rows,
+                       int N);
 
 /* ---- fused decoder kernels: one pass over the per-prompt key state each (SURVEY.md 8d's R1..R4) */
 /* whole image->token half-block (transformer.py:186-190): [Q-proj] -> 7-key attention -> out-proj ->
