@@ -133,6 +133,10 @@ class DecoderPlan:
         # small batches: the two skinny GEMMs with a long K (MLP second layer K = 2048: 26 us on 4 workgroups; PWD-Net pooling
         # product K = 5376: 54 us) as split-K launches summed in slice order (hip.gemm_f16_splitk).  CSAM_DEC_SPLITK=0: single pass
         self.splitk = os.environ.get("CSAM_DEC_SPLITK", "1") != "0"
+        # small batches: the token side of a block in two launches instead of fourteen (csam_token_block_a / _b: self-attention
+        # block + norm1 + q projection; out projection + norm2 + MLP + norm3 + k / v projections).  CSAM_TOKEN_BLOCK=0: the
+        # separate GEMM / LayerNorm / attention launches
+        self.token_block = os.environ.get("CSAM_TOKEN_BLOCK", "1") != "0"
         self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -395,8 +399,10 @@ class DecoderPlan:
             qpe16 = fp16(queries + tokens0) (csam_layernorm_cast: LayerNorm + two add_cast in one launch)"""
             hip.layernorm_cast(ws["tmp32"][:M7], g, b, 1e-5, queries, out16=q16, pe=tokens0, outpe16=qpe16)
 
-        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None, cast16=None):
-            """queries <- LN(queries + out_proj(attention)); cast16 receives fp16(queries) for the next consumer"""
+        def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None, cast16=None, q_ready=False,
+                epilogue=True):
+            """queries <- LN(queries + out_proj(attention)); cast16 receives fp16(queries) for the next consumer.
+            q_ready: ws["t2i_q"] already holds the q projection; epilogue False: stop after the attention (ws["t2i_o"])"""
             if fused_args is not None and "rank" in fused_args and self.t2i_rank and self.t2i_stream and B >= 256:
                 # rank-56 form (csam_t2i_rank): no per-key K / V projections; Wv and the out-projection in one GEMM
                 R = fused_args["rank"]
@@ -406,7 +412,8 @@ class DecoderPlan:
                 hip.gemm_f16(ws["t2i_y"][:M7], R["wc"], out=ws["tmp32"][:M7], bias=R["bc"], residual=queries)
                 hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
                 return
-            hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
+            if not q_ready:
+                hip.gemm_f16(qpe16, q_w, out=ws["t2i_q"][:M7], bias=q_b)
             if fused_args is not None and "K0" in fused_args:
                 hip.t2i_shared(ws["t2i_q"], st["k0h"], st["v0h"], ws["t2i_o"], B)
             elif fused_args is not None and self.t2i_stream and B >= 256:
@@ -417,6 +424,8 @@ class DecoderPlan:
                 hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **{k: v for k, v in fused_args.items() if k not in ("rank", "y_ready")})
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
+            if not epilogue:
+                return
             hip.gemm_f16(ws["t2i_o"][:M7], o_w, out=ws["tmp32"][:M7], bias=o_b, residual=queries)
             hip.layernorm_cast(ws["tmp32"][:M7], norm_g, norm_b, 1e-5, queries, out16=cast16)
 
@@ -452,7 +461,36 @@ class DecoderPlan:
                 self._fork_stream = torch.cuda.Stream(device=coords_f32.device)
             side_s = self._fork_stream
         sa_done, joined = False, True               # next layer's self-attention already issued / side stream joined
+        tok = self.token_block and B < 256 and self.fused and self.i2t_stream and not fuse_next and not forked
+        final_q_ready = False
         for li, L in enumerate(self.layers):
+            if tok:
+                # ---- token side in two launches around the token->image attention (csrc/token_block.hip)
+                hip.token_block_a(None if li == 0 else qpe16, q16, tokens0, None if li == 0 else queries, L["sa_qk_w"],
+                                  L["sa_qk_b"], L["sa_v_w"], L["sa_v_b"], L["sa_o_w"], L["sa_o_b"], L["norm1_g"], L["norm1_b"],
+                                  1e-5, L["t2i_q_w"], L["t2i_q_b"], queries, q16, qpe16, ws["t2i_q"], B)
+                if li == 0:
+                    t2i(None, None, st["kv0"], 256, 0, None, None, None, None, dict(K0=st["k0"], V0T=st["v0t"]),
+                        q_ready=True, epilogue=False)
+                else:
+                    t2i(None, None, None, 0, 0, None, None, None, None,
+                        dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]), q_ready=True, epilogue=False)
+                last = li + 1 == len(self.layers)
+                hip.token_block_b(ws["t2i_o"], queries, tokens0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                                  L["mlp1_w"], L["mlp1_b"], L["mlp2_w"], L["mlp2_b"], L["norm3_g"], L["norm3_b"],
+                                  L["i2t_k_w_s"], L["i2t_k_b_s"], L["i2t_v_w"], L["i2t_v_b"], 1e-5, q16, qpe16, ws["i2t_k"],
+                                  ws["i2t_v"], B, next_q_w=self.final["q_w"] if last else None,
+                                  next_q_b=self.final["q_b"] if last else None, t2i_q=ws["t2i_q"] if last else None)
+                final_q_ready = last
+                if li == 0:
+                    hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                   L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
+                else:
+                    hip.i2t_stream(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
+                                   L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],
+                                   qpe=L["i2t_q_peb"])
+                keys_in, keys_out = keys_out, ws["keysB"]
+                continue
             if not y_ready and not sa_done:
                 self_attn(li, L)
             sa_done = False
@@ -556,7 +594,7 @@ class DecoderPlan:
         if self.fused:
             t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
                 dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"], rank=rank_consts(F, ""), y_ready=y_ready),
-                cast16=hs16)
+                cast16=hs16, q_ready=final_q_ready)
         else:
             hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
             t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], cast16=hs16)

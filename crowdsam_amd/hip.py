@@ -48,6 +48,9 @@ SIGNATURES = {
     "csam_pool_adjoint": [_P, _P, _P, _P, _P, _L, _I],
     "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
     "csam_splitk_reduce": [_P, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I],
+    "csam_token_block_a": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I],
+    "csam_token_block_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+                           _P, _I],
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "csam_mask_post_scored": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
@@ -480,6 +483,24 @@ def gemm_f16_splitk(a, w, out, splits, scratch, bias=None, residual=None, rowsta
     call("csam_splitk_reduce", _stream(), _ptr(scratch), splits, M * N, _ptr(rowstats), _ptr(bias), _ptr(residual),
          0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, N)
     return out
+
+
+def token_block_a(src_qk, src_v, tokens0, residual, qk_w, qk_b, v_w, v_b, o_w, o_b, norm_g, norm_b, eps, q_w, q_b,
+                  queries, q16, qpe16, t2i_q, B):
+    """Token self-attention block + norm1 + the q projection of the token->image attention in one launch (small batches;
+    csrc/token_block.hip).  ``src_qk`` None: layer 0, both operands are fp16(tokens0)."""
+    call("csam_token_block_a", _stream(), _ptr(src_qk), _ptr(src_v), _ptr(tokens0), 1 if src_qk is None else 0, _ptr(residual),
+         _ptr(qk_w), _ptr(qk_b), _ptr(v_w), _ptr(v_b), _ptr(o_w), _ptr(o_b), _ptr(norm_g), _ptr(norm_b), eps, _ptr(q_w),
+         _ptr(q_b), _ptr(queries), _ptr(q16), _ptr(qpe16), _ptr(t2i_q), B)
+
+
+def token_block_b(attn_o, queries, tokens0, o_w, o_b, n2_g, n2_b, m1_w, m1_b, m2_w, m2_b, n3_g, n3_b, k_w, k_b, v_w, v_b,
+                  eps, q16, qpe16, i2t_k, i2t_v, B, next_q_w=None, next_q_b=None, t2i_q=None):
+    """Out projection of the token->image attention + norm2 + MLP + norm3 + the k / v projections of the image->token
+    attention (+ the next token->image attention's q projection) in one launch (small batches; csrc/token_block.hip)."""
+    call("csam_token_block_b", _stream(), _ptr(attn_o), _ptr(queries), _ptr(tokens0), _ptr(o_w), _ptr(o_b), _ptr(n2_g), _ptr(n2_b),
+         _ptr(m1_w), _ptr(m1_b), _ptr(m2_w), _ptr(m2_b), _ptr(n3_g), _ptr(n3_b), _ptr(k_w), _ptr(k_b), _ptr(v_w), _ptr(v_b),
+         _ptr(next_q_w), _ptr(next_q_b), eps, _ptr(q16), _ptr(qpe16), _ptr(i2t_k), _ptr(i2t_v), _ptr(t2i_q), B)
 
 
 def linear_f32(a, w, bias=None, out=None, act=ACT_NONE, residual=None, M=None, lda=None):

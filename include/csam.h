@@ -192,6 +192,28 @@ int csam_rowscale_bias(void* stream, const float* P, const float* stats, const f
  * csam_gemm_f16_batched and are summed here in slice order, bit-repeatably):
  * out[r,c] = (sum_s partials[s * slab_stride + r * N + c]) * (stats ? 1 / stats[2 r + 1] : 1) + bias[c] + residual[r * ldr + c];
  * stats / bias / residual may be NULL.  N % 4 == 0. */
+/* The token side of a two-way decoder block for small prompt batches (round 4; csrc/token_block.hip): one 16-wave workgroup
+ * per two prompts walks the launch sequence it replaces with the activations in LDS.
+ * _a: transformer.py:164-170 token self-attention (q | k and v projections, 7 x 7 attention per head, out projection,
+ *     + residual unless residual_or_null is NULL = layer 0's skip_first_layer_pe form, norm1) and the q projection of the
+ *     token->image attention (:173-177).  from_tokens != 0: both operands are fp16(tokens0) and src_* are ignored.
+ *     Writes queries fp32 [B*7,256], q16 = fp16(queries), qpe16 = fp16(queries + tokens0), t2i_q fp16 [B*7,128].
+ * _b: out projection of the token->image attention + residual + norm2 (:175-177), MLP 256 -> 2048 ReLU -> 256 + residual +
+ *     norm3 (:180-183), the k / v projections of the image->token attention (:186-190) and, when next_q_w is given, the q
+ *     projection of the NEXT token->image attention.  queries is read (residual) and rewritten.
+ * Weights fp16 row-major [N][K], biases / LayerNorm parameters fp32.  Bit-identical to the launch sequence they replace
+ * (csam_gemm_f16, csam_token_self_attn, csam_layernorm_cast ... in single-pass form). */
+int csam_token_block_a(void* stream, const void* src_qk_f16, const void* src_v_f16, const float* tokens0, int from_tokens,
+                       const float* residual_or_null, const void* qk_w_f16, const float* qk_b, const void* v_w_f16,
+                       const float* v_b, const void* o_w_f16, const float* o_b, const float* norm_g, const float* norm_b,
+                       float eps, const void* q_w_f16, const float* q_b, float* queries, void* q16, void* qpe16,
+                       void* t2i_q_f16, int B);
+int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, const float* tokens0, const void* o_w_f16,
+                       const float* o_b, const float* norm2_g, const float* norm2_b, const void* mlp1_w_f16,
+                       const float* mlp1_b, const void* mlp2_w_f16, const float* mlp2_b, const float* norm3_g,
+                       const float* norm3_b, const void* k_w_f16, const float* k_b, const void* v_w_f16, const float* v_b,
+                       const void* next_q_w_f16_or_null, const float* next_q_b_or_null, float eps, void* q16, void* qpe16,
+                       void* i2t_k_f16, void* i2t_v_f16, void* t2i_q_f16_or_null, int B);
 int csam_splitk_reduce(void* stream, const float* partials, int splits, long slab_stride, const float* stats_or_null,
                        const float* bias_or_null, const float* residual_or_null, long ldr, float* out, long ldo, int rows,
                        int N);

@@ -184,6 +184,7 @@ def test_small_batch_fork_join_graph_is_bit_identical(cuda, B):
     from crowdsam_amd.decoder import DecoderPlan
     sd = synth.make_sam_state_dict("vit_test128")
     plan = DecoderPlan(sd, cuda, n_class=1, max_batch=64)
+    plan.token_block = False                        # the forked graph is a form of the separate-launch sequence
     _set_image(plan, cuda)
     outs = {}
     for rep, on in enumerate((True, False, True, True)):
@@ -204,6 +205,38 @@ def test_small_batch_fork_join_graph_is_bit_identical(cuda, B):
     ref = plan.run_batch(coords)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(outs[3], ref))
+
+
+@pytest.mark.parametrize("B", [32, 7, 1])
+def test_token_block_kernels_match_the_launch_sequence_they_replace(cuda, B):
+    """csam_token_block_a / _b (round 4): the token side of a decoder block for small batches in two launches.  Same operands,
+    same rounding points, fp32 accumulation in the same K order as the GEMM / LayerNorm / attention launches they replace (the
+    split-K form of two of those GEMMs is switched off for the comparison): masks, IoU and class scores are BIT-IDENTICAL, for
+    even, odd and single-prompt batches."""
+    from crowdsam_amd import synth
+    from crowdsam_amd.decoder import DecoderPlan
+    sd = synth.make_sam_state_dict("vit_test128")
+    plan = DecoderPlan(sd, cuda, n_class=1, max_batch=64)
+    assert plan.token_block
+    _set_image(plan, cuda)
+    plan.splitk = False
+    pts = np.random.RandomState(21).randint(0, 1024, size=(B, 2)).astype(np.float32)
+    coords = torch.from_numpy(pts).to(cuda).contiguous()
+    outs = {}
+    for on in (True, False, True):
+        plan.token_block = on
+        plan.batch_graphs.clear()
+        m, iou, cls = plan.run_batch(coords)
+        torch.cuda.synchronize()
+        cur = (m.clone(), iou.clone(), cls.clone())
+        if on in outs:
+            assert all(torch.equal(a, b) for a, b in zip(outs[on], cur))       # repeatable
+        outs[on] = cur
+    scale = outs[False][0].abs().mean().item()
+    d = [(a - b).abs().max().item() for a, b in zip(outs[True], outs[False])]
+    print("B=%d token blocks vs separate launches: max |diff| masks %.3e (mean |logit| %.3f), iou %.3e, cls %.3e"
+          % (B, d[0], scale, d[1], d[2]))
+    assert d[0] == 0.0 and d[1] == 0.0 and d[2] == 0.0
 
 
 def test_decoder_folded_constants_stay_inside_the_fp16_noise(cuda):
