@@ -317,6 +317,217 @@ __global__ __launch_bounds__(TB_THREADS) void token_block_b_kernel(TokB p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// csam_token_heads: everything between the final token->image attention and the upscaler / PWD-Net branch, for small batches:
+// out projection + residual + final LayerNorm (transformer.py:105-112), the four hyper-network MLPs (mask_decoder.py:175-179),
+// the IoU head (:184) and Crowd-SAM's parallel residual IoU head (:194-198).  13 launches in one.  Per pair of prompts the first
+// and second layers of the six MLPs are six 256-wide products each: every wave owns one 16-feature tile of each, and walks its
+// 7 / 6 fragment sets back to back (two in flight).  The third layers stay fp32 on the VALU in the summation order of
+// csam_linear_f32[_batched] (they feed discrete decisions): IoU outputs bit-identical to the launch sequence, hyper-network
+// outputs to the last bit (that kernel's rows 6, 7 of 8 are scheduled without fma contraction).
+// ---------------------------------------------------------------------------------------------------------------
+struct TokH {
+  const half_t* attn_o; const float* queries; const half_t* o_w; const float* o_b; const float* n_g; const float* n_b; float eps;
+  const half_t* hw0; const float* hb0; const half_t* hw1; const float* hb1; const float* hw2; const float* hb2;
+  const half_t* iw0; const float* ib0; const half_t* iw1; const float* ib1; const float* iw2; const float* ib2;
+  const half_t* pw0; const float* pb0; const half_t* pw1; const float* pb1; const float* pw2; const float* pb2;
+  float* hyper; float* iou0; float* res_iou; int M7; int B;
+};
+
+constexpr int H_XO = 0;                                  // [16][LD128] fp16
+constexpr int H_Y = H_XO + 16 * LD128 * 2;               // [16][LDY] fp32
+constexpr int H_HS = H_Y + 16 * LDY * 4;                 // [16][LD256] fp16: the final token state (rows 14, 15 zero)
+constexpr int H_XF = H_HS + 16 * LD256 * 2;              // [8][LD512] fp16: [iou token | mask token l] of (prompt, l)
+constexpr int H_ZERO = H_XF + 8 * LD512 * 2;             // [LD512] fp16 zeros: the operand row of unused tile rows
+constexpr int H_L1 = H_ZERO + LD512 * 2;                 // first-layer outputs fp16: hyper [4][2] | iou [2] | par [8] rows of LD256
+constexpr int H_L2 = H_L1 + 18 * LD256 * 2;              // second-layer outputs fp32: the same 18 rows of LDY
+constexpr int H_I0 = H_L2 + 18 * LDY * 4;                // iou0 [2][4] fp32
+constexpr int H_SMEM = H_I0 + 64;
+
+struct HItem { const half_t* w; const half_t* x; int g; bool first, last; };
+
+template <class Get, class Epi>
+__device__ __forceinline__ void chunk_pass(int total, Get get, Epi epi) {
+  half8_t wa[8], wb[8];
+  floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](half8_t (&w)[8], int it) {
+    const HItem t = get(it);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w[ks] = *(const half8_t*)(t.w + ks * 32);
+  };
+  auto consume = [&](half8_t (&w)[8], int it) {
+    const HItem t = get(it);
+    if (t.first) acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const half8_t xf = *(const half8_t*)(t.x + ks * 32);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks], xf, acc, 0, 0, 0);
+    }
+    if (t.last) epi(t.g, acc);
+  };
+  issue(wa, 0);
+  for (int it = 0; it < total; it += 2) {
+    if (it + 1 < total) issue(wb, it + 1);
+    consume(wa, it);
+    if (it + 2 < total) issue(wa, it + 2);
+    if (it + 1 < total) consume(wb, it + 1);
+  }
+}
+
+__global__ __launch_bounds__(TB_THREADS) void token_heads_kernel(TokH p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* xo = (half_t*)(smem + H_XO);
+  float* y = (float*)(smem + H_Y);
+  half_t* hs = (half_t*)(smem + H_HS);
+  half_t* xf = (half_t*)(smem + H_XF);
+  half_t* zero = (half_t*)(smem + H_ZERO);
+  half_t* l1 = (half_t*)(smem + H_L1);
+  float* l2 = (float*)(smem + H_L2);
+  float* i0 = (float*)(smem + H_I0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int row0 = blockIdx.x * TB_ROWS;
+  const int nrow = min(TB_ROWS, p.M7 - row0);
+  const int npr = nrow / 7;                                // prompts of this workgroup: 2, or 1
+  if (tid < 16 * 16) {
+    const int r = tid >> 4, c = (tid & 15) * 8;
+    half8_t a = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < nrow) a = *(const half8_t*)(p.attn_o + (long)(row0 + r) * 128 + c);
+    *(half8_t*)(xo + r * LD128 + c) = a;
+  }
+  if (tid >= 256 && tid < 256 + LD512 / 8) *(half8_t*)(zero + (tid - 256) * 8) = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();
+  // ---- out projection of the final attention + residual -> final LayerNorm
+  linear16<128, LD128>(p.o_w, 256, xo, wave, lane, [&](int nt, floatx4 acc) {
+    floatx4 v = acc + *(const floatx4*)(p.o_b + nt * 16 + fg * 4);
+    if (fr < nrow) v += *(const floatx4*)(p.queries + (long)(row0 + fr) * 256 + nt * 16 + fg * 4);
+    *(floatx4*)(y + fr * LDY + nt * 16 + fg * 4) = v;
+  });
+  __syncthreads();
+  {
+    const int r = wave;
+    const floatx4 o = ln_row(y + r * LDY, p.n_g, p.n_b, p.eps, lane);
+    *(half4_t*)(hs + r * LD256 + lane * 4) = r < nrow ? to_half4(o) : half4_t{0, 0, 0, 0};
+  }
+  __syncthreads();
+  // operand of the parallel head: row (prompt pr, mask l) = [token 0 | token 1 + l] of the prompt
+  for (int i = tid; i < 8 * 64; i += TB_THREADS) {
+    const int r = i >> 6, c = (i & 63) * 8, pr = r >> 2, l = r & 3;
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pr < npr) v = *(const half8_t*)(hs + (pr * 7 + (c < 256 ? 0 : 1 + l)) * LD256 + (c & 255));
+    *(half8_t*)(xf + r * LD512 + c) = v;
+  }
+  __syncthreads();
+  // ---- first layers (fp16 out, ReLU): g = 0..3 hyper MLP l = g on token 1 + l, g = 4 IoU head on token 0, g = 5 parallel head
+  // (K = 512: two fragment sets).  Tile row fr of product g is prompt fr (g < 5) / (prompt, mask) fr (g = 5); the rest reads zeros.
+  {
+    const int n0 = wave * 16 + fr;                         // this lane's weight row inside a 256-row matrix
+    auto get = [&](int it) {
+      HItem t;
+      const int g = it < 6 ? it : 5, c = it == 6 ? 1 : 0;
+      t.g = g; t.first = c == 0; t.last = g < 5 || c == 1;
+      if (g < 4) {
+        t.w = p.hw0 + ((long)g * 256 + n0) * 256 + fg * 8;
+        t.x = (fr < npr ? hs + (fr * 7 + 1 + g) * LD256 : zero) + fg * 8;
+      } else if (g == 4) {
+        t.w = p.iw0 + (long)n0 * 256 + fg * 8;
+        t.x = (fr < npr ? hs + (fr * 7) * LD256 : zero) + fg * 8;
+      } else {
+        t.w = p.pw0 + (long)n0 * 512 + c * 256 + fg * 8;
+        t.x = (fr < 8 ? xf + fr * LD512 + c * 256 : zero) + fg * 8;
+      }
+      return t;
+    };
+    chunk_pass(7, get, [&](int g, floatx4 acc) {
+      const float* b = g < 4 ? p.hb0 + g * 256 : g == 4 ? p.ib0 : p.pb0;
+      floatx4 v = acc + *(const floatx4*)(b + wave * 16 + fg * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      const int rows = g < 5 ? 2 : 8, base = g < 4 ? g * 2 : g == 4 ? 8 : 10;
+      if (fr < rows) *(half4_t*)(l1 + (base + fr) * LD256 + wave * 16 + fg * 4) = to_half4(v);
+    });
+  }
+  __syncthreads();
+  // ---- second layers (fp32 out, ReLU)
+  {
+    const int n0 = wave * 16 + fr;
+    auto get = [&](int it) {
+      HItem t;
+      t.g = it; t.first = t.last = true;
+      const half_t* w = it < 4 ? p.hw1 + (long)it * 256 * 256 : it == 4 ? p.iw1 : p.pw1;
+      t.w = w + (long)n0 * 256 + fg * 8;
+      const int rows = it < 5 ? 2 : 8, base = it < 4 ? it * 2 : it == 4 ? 8 : 10;
+      t.x = (fr < rows ? l1 + (base + fr) * LD256 : zero) + fg * 8;
+      return t;
+    };
+    chunk_pass(6, get, [&](int g, floatx4 acc) {
+      const float* b = g < 4 ? p.hb1 + g * 256 : g == 4 ? p.ib1 : p.pb1;
+      floatx4 v = acc + *(const floatx4*)(b + wave * 16 + fg * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      const int rows = g < 5 ? 2 : 8, base = g < 4 ? g * 2 : g == 4 ? 8 : 10;
+      if (fr < rows) *(floatx4*)(l2 + (base + fr) * LDY + wave * 16 + fg * 4) = v;
+    });
+  }
+  __syncthreads();
+  // ---- third layers in fp32.  Hyper-network outputs: thread = (prompt, l, j), one accumulator, k ascending (csam_linear_f32_batched)
+  if (tid < 256) {
+    const int pr = tid >> 7, l = (tid >> 5) & 3, j = tid & 31;
+    if (pr < npr) {
+      const float* a = l2 + (l * 2 + pr) * LDY;
+      const float* w = p.hw2 + ((long)l * 32 + j) * 256;
+      float acc = 0.f;
+      for (int k = 0; k < 256; k += 4) {
+        const floatx4 wv = *(const floatx4*)(w + k);
+        const floatx4 av = *(const floatx4*)(a + k);
+        acc = __builtin_fmaf(av[0], wv[0], acc);
+        acc = __builtin_fmaf(av[1], wv[1], acc);
+        acc = __builtin_fmaf(av[2], wv[2], acc);
+        acc = __builtin_fmaf(av[3], wv[3], acc);
+      }
+      p.hyper[((long)(blockIdx.x * 2 + pr)) * 128 + l * 32 + j] = acc + p.hb2[l * 32 + j];
+    }
+  } else if (wave >= 4 && wave < 6) {
+    // IoU head output (4 per prompt): one wave per row, 4 consecutive k per lane, wave reduction (linear_f32_rowdot_kernel)
+    const int pr = wave - 4;
+    if (pr < npr) {
+      const floatx4 av = *(const floatx4*)(l2 + (8 + pr) * LDY + lane * 4);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const floatx4 wv = *(const floatx4*)(p.iw2 + n * 256 + lane * 4);
+        float acc = 0.f;
+        acc = fmaf(av[0], wv[0], acc);
+        acc = fmaf(av[1], wv[1], acc);
+        acc = fmaf(av[2], wv[2], acc);
+        acc = fmaf(av[3], wv[3], acc);
+        const float sum = csam_wave_sum(acc);
+        if (lane == 0) {
+          const float v = sum + p.ib2[n];
+          i0[pr * 4 + n] = v;
+          p.iou0[(long)(blockIdx.x * 2 + pr) * 4 + n] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 8) {                                          // parallel head: row (prompt, l), one output + the IoU head's as residual
+    const int pr = wave >> 2, l = wave & 3;
+    if (pr < npr) {
+      const floatx4 av = *(const floatx4*)(l2 + (10 + wave) * LDY + lane * 4);
+      const floatx4 wv = *(const floatx4*)(p.pw2 + lane * 4);
+      float acc = 0.f;
+      acc = fmaf(av[0], wv[0], acc);
+      acc = fmaf(av[1], wv[1], acc);
+      acc = fmaf(av[2], wv[2], acc);
+      acc = fmaf(av[3], wv[3], acc);
+      const float sum = csam_wave_sum(acc);
+      if (lane == 0) p.res_iou[(long)(blockIdx.x * 2 + pr) * 4 + l] = (sum + p.pb2[0]) + i0[pr * 4 + l];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int csam_token_block_a(void* stream, const void* src_qk_f16, const void* src_v_f16, const float* tokens0,
@@ -364,5 +575,32 @@ extern "C" int csam_token_block_b(void* stream, const void* attn_o_f16, float* q
     (void)hipFuncSetAttribute((const void*)token_block_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_SMEM);
   hipLaunchKernelGGL(token_block_b_kernel, dim3(csam_cdiv(B, 2)), dim3(TB_THREADS), B_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_token_block_b");
+  return CSAM_OK;
+}
+
+extern "C" int csam_token_heads(void* stream, const void* attn_o_f16, const float* queries, const void* o_w_f16, const float* o_b,
+                                const float* norm_g, const float* norm_b, float eps, const void* hyper_w0_f16,
+                                const float* hyper_b0, const void* hyper_w1_f16, const float* hyper_b1, const float* hyper_w2,
+                                const float* hyper_b2, const void* iou_w0_f16, const float* iou_b0, const void* iou_w1_f16,
+                                const float* iou_b1, const float* iou_w2, const float* iou_b2, const void* par_w0_f16,
+                                const float* par_b0, const void* par_w1_f16, const float* par_b1, const float* par_w2,
+                                const float* par_b2, float* hyper_out, float* iou0_out, float* res_iou_out, int B) {
+  CSAM_REQUIRE(attn_o_f16 && queries && o_w_f16 && o_b && norm_g && norm_b && hyper_w0_f16 && hyper_b0 && hyper_w1_f16 &&
+                   hyper_b1 && hyper_w2 && hyper_b2 && iou_w0_f16 && iou_b0 && iou_w1_f16 && iou_b1 && iou_w2 && iou_b2 &&
+                   par_w0_f16 && par_b0 && par_w1_f16 && par_b1 && par_w2 && par_b2 && hyper_out && iou0_out && res_iou_out &&
+                   B > 0,
+               "csam_token_heads: bad args");
+  TokH a;
+  a.attn_o = (const half_t*)attn_o_f16; a.queries = queries; a.o_w = (const half_t*)o_w_f16; a.o_b = o_b; a.n_g = norm_g;
+  a.n_b = norm_b; a.eps = eps; a.hw0 = (const half_t*)hyper_w0_f16; a.hb0 = hyper_b0; a.hw1 = (const half_t*)hyper_w1_f16;
+  a.hb1 = hyper_b1; a.hw2 = hyper_w2; a.hb2 = hyper_b2; a.iw0 = (const half_t*)iou_w0_f16; a.ib0 = iou_b0;
+  a.iw1 = (const half_t*)iou_w1_f16; a.ib1 = iou_b1; a.iw2 = iou_w2; a.ib2 = iou_b2; a.pw0 = (const half_t*)par_w0_f16;
+  a.pb0 = par_b0; a.pw1 = (const half_t*)par_w1_f16; a.pb1 = par_b1; a.pw2 = par_w2; a.pb2 = par_b2; a.hyper = hyper_out;
+  a.iou0 = iou0_out; a.res_iou = res_iou_out; a.M7 = B * 7; a.B = B;
+  static csam_once_t once;
+  if (csam_first_call(once))
+    (void)hipFuncSetAttribute((const void*)token_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM);
+  hipLaunchKernelGGL(token_heads_kernel, dim3(csam_cdiv(B, 2)), dim3(TB_THREADS), H_SMEM, (hipStream_t)stream, a);
+  CSAM_LAUNCH_CHECK("csam_token_heads");
   return CSAM_OK;
 }

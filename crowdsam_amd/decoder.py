@@ -591,47 +591,60 @@ class DecoderPlan:
         # ---- final token -> image attention (transformer.py:105-112)
         F = self.final_fold if keys_plain else self.final     # qpe16 still holds fp16(queries + tokens0) from the last norm3
         hs16 = ws["hs16"][:M7]
-        if self.fused:
-            t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
-                dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"], rank=rank_consts(F, ""), y_ready=y_ready),
-                cast16=hs16, q_ready=final_q_ready)
-        else:
-            hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
-            t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], cast16=hs16)
-        # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
-        if not self.fused:
-            up1 = ws["kv"]                                   # reuse [BT,256] f16
-            hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
-            hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
-            hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
-        tok16 = hs16.view(B, 7, 256)
-        # ---- IoU head (:184) + parallel residual head (:194-198)
-        def iou_heads(g1, g2):
-            hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)
-            hip.gemm_f16(g1[:B], self.iou_w16[1], out=g2[:B], bias=self.iou_head[1][1], act=hip.ACT_RELU)
-            iou0 = hip.linear_f32(g2[:B], self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
-            fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
-            fused[:, :, :256] = tok16[:, 0].unsqueeze(1)     # plumbing: concat [iou_tok | mask_tok_l]
-            fused[:, :, 256:] = tok16[:, 1:5]
-            ft = ws["fused_tok"][:B * 4]
-            hip.gemm_f16(ft, self.par_w16[0], out=g1[:B * 4], bias=self.par_iou_head[0][1], act=hip.ACT_RELU)
-            hip.gemm_f16(g1[:B * 4], self.par_w16[1], out=g2[:B * 4], bias=self.par_iou_head[1][1], act=hip.ACT_RELU)
-            return hip.linear_f32(g2[:B * 4], self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
-                                  residual=iou0.view(B * 4, 1))
-
         iou = None
-        if forked:                                   # fork: the heads need the tokens only; their own scratch (g1b / g2b)
-            side_s.wait_stream(main_s)
-            with torch.cuda.stream(side_s):
-                iou = iou_heads(ws["g1b"], ws["g2b"])
-        # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
-        hh1, hh2 = ws["hh1"], ws["hh2"]
-        hip.gemm_f16_batched(tok16[:, 1], 7 * 256, 256, self.hyper_w0, 256, 256 * 256, hh1, 256, hh1.stride(0),
-                             B, 256, 256, 4, bias=self.hyper_b0, sbias=256, act=hip.ACT_RELU)
-        hip.gemm_f16_batched(hh1, 256, hh1.stride(0), self.hyper_w1, 256, 256 * 256, hh2, 256, hh2.stride(0),
-                             B, 256, 256, 4, bias=self.hyper_b1, sbias=256, act=hip.ACT_RELU)
-        hip.linear_f32_batched(hh2, 256, hh2.stride(0), self.hyper_w2, 256, 32 * 256, self.hyper_b2, 32, ws["hyper"],
-                               128, 32, B, 32, 256, 4)
+        if tok:
+            # small batches: attention, then ONE launch for its out projection + final LayerNorm, the four hyper-network MLPs,
+            # the IoU head and the parallel residual head (csam_token_heads; the 13 launches below, equal to the last fp32 bit)
+            t2i(None, None, None, 0, 0, None, None, None, None, dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"]),
+                q_ready=final_q_ready, epilogue=False)
+            hip.token_heads(ws["t2i_o"], queries, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], 1e-5, self.hyper_w0,
+                            self.hyper_b0, self.hyper_w1, self.hyper_b1, self.hyper_w2, self.hyper_b2, self.iou_w16[0],
+                            self.iou_head[0][1], self.iou_w16[1], self.iou_head[1][1], self.iou_head[2][0], self.iou_head[2][1],
+                            self.par_w16[0], self.par_iou_head[0][1], self.par_w16[1], self.par_iou_head[1][1],
+                            self.par_iou_head[2][0], self.par_iou_head[2][1], ws["hyper"], ws["iou"], ws["res_iou"], B)
+            iou = ws["res_iou"][:B * 4]
+        if not tok:
+            if self.fused:
+                t2i(F["q_w"], F["q_b"], None, 0, 0, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"],
+                    dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"], rank=rank_consts(F, ""), y_ready=y_ready),
+                    cast16=hs16, q_ready=final_q_ready)
+            else:
+                hip.gemm_f16_resmod(keys_in, F["kv_w"], ws["kv"][:BT], F["kv_b"], F["kv_pe"], T_IMG, M=BT)
+                t2i(F["q_w"], F["q_b"], ws["kv"], 256, T_IMG * 256, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], cast16=hs16)
+            # ---- upscaling (mask_decoder.py:172-173) + hyper-network product (:175-181)
+            if not self.fused:
+                up1 = ws["kv"]                                   # reuse [BT,256] f16
+                hip.gemm_f16(keys_in[:BT], self.up1_w, out=up1[:BT], bias=self.up1_b)
+                hip.ln64_gelu(up1, self.up_ln_g, self.up_ln_b, BT * 4)
+                hip.gemm_f16(up1[:BT].view(BT * 4, 64), self.up2_w, out=ws["up2"][:BT * 4], bias=self.up2_b, act=hip.ACT_GELU)
+            tok16 = hs16.view(B, 7, 256)
+            # ---- IoU head (:184) + parallel residual head (:194-198)
+            def iou_heads(g1, g2):
+                hip.gemm_f16(tok16[:, 0], self.iou_w16[0], out=g1[:B], bias=self.iou_head[0][1], act=hip.ACT_RELU, M=B)
+                hip.gemm_f16(g1[:B], self.iou_w16[1], out=g2[:B], bias=self.iou_head[1][1], act=hip.ACT_RELU)
+                iou0 = hip.linear_f32(g2[:B], self.iou_head[2][0], self.iou_head[2][1], out=ws["iou"][:B])
+                fused = ws["fused_tok"][:B * 4].view(B, 4, 512)
+                fused[:, :, :256] = tok16[:, 0].unsqueeze(1)     # plumbing: concat [iou_tok | mask_tok_l]
+                fused[:, :, 256:] = tok16[:, 1:5]
+                ft = ws["fused_tok"][:B * 4]
+                hip.gemm_f16(ft, self.par_w16[0], out=g1[:B * 4], bias=self.par_iou_head[0][1], act=hip.ACT_RELU)
+                hip.gemm_f16(g1[:B * 4], self.par_w16[1], out=g2[:B * 4], bias=self.par_iou_head[1][1], act=hip.ACT_RELU)
+                return hip.linear_f32(g2[:B * 4], self.par_iou_head[2][0], self.par_iou_head[2][1], out=ws["res_iou"][:B * 4],
+                                      residual=iou0.view(B * 4, 1))
+
+            iou = None
+            if forked:                                   # fork: the heads need the tokens only; their own scratch (g1b / g2b)
+                side_s.wait_stream(main_s)
+                with torch.cuda.stream(side_s):
+                    iou = iou_heads(ws["g1b"], ws["g2b"])
+            # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
+            hh1, hh2 = ws["hh1"], ws["hh2"]
+            hip.gemm_f16_batched(tok16[:, 1], 7 * 256, 256, self.hyper_w0, 256, 256 * 256, hh1, 256, hh1.stride(0),
+                                 B, 256, 256, 4, bias=self.hyper_b0, sbias=256, act=hip.ACT_RELU)
+            hip.gemm_f16_batched(hh1, 256, hh1.stride(0), self.hyper_w1, 256, 256 * 256, hh2, 256, hh2.stride(0),
+                                 B, 256, 256, 4, bias=self.hyper_b1, sbias=256, act=hip.ACT_RELU)
+            hip.linear_f32_batched(hh2, 256, hh2.stride(0), self.hyper_w2, 256, 32 * 256, self.hyper_b2, 32, ws["hyper"],
+                                   128, 32, B, 32, 256, 4)
         masks = ws["masks"][:B]
         if self.fused:
             up = hip.upscale_stream if (self.up_stream and B >= 256) else hip.upscale_fused

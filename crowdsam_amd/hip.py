@@ -49,6 +49,7 @@ SIGNATURES = {
     "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
     "csam_splitk_reduce": [_P, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I],
     "csam_token_block_a": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I],
+    "csam_token_heads": [_P, _P, _P, _P, _P, _P, _P, _F] + [_P] * 21 + [_I],
     "csam_token_block_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                            _P, _I],
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
@@ -501,6 +502,15 @@ def token_block_b(attn_o, queries, tokens0, o_w, o_b, n2_g, n2_b, m1_w, m1_b, m2
     call("csam_token_block_b", _stream(), _ptr(attn_o), _ptr(queries), _ptr(tokens0), _ptr(o_w), _ptr(o_b), _ptr(n2_g), _ptr(n2_b),
          _ptr(m1_w), _ptr(m1_b), _ptr(m2_w), _ptr(m2_b), _ptr(n3_g), _ptr(n3_b), _ptr(k_w), _ptr(k_b), _ptr(v_w), _ptr(v_b),
          _ptr(next_q_w), _ptr(next_q_b), eps, _ptr(q16), _ptr(qpe16), _ptr(i2t_k), _ptr(i2t_v), _ptr(t2i_q), B)
+
+
+def token_heads(attn_o, queries, o_w, o_b, norm_g, norm_b, eps, hw0, hb0, hw1, hb1, hw2, hb2, iw0, ib0, iw1, ib1, iw2, ib2,
+                pw0, pb0, pw1, pb1, pw2, pb2, hyper, iou0, res_iou, B):
+    """Out projection + LayerNorm of the final token->image attention, the four hyper-network MLPs, the IoU head and the
+    parallel residual IoU head in one launch (small batches; csrc/token_block.hip)."""
+    call("csam_token_heads", _stream(), _ptr(attn_o), _ptr(queries), _ptr(o_w), _ptr(o_b), _ptr(norm_g), _ptr(norm_b), eps,
+         _ptr(hw0), _ptr(hb0), _ptr(hw1), _ptr(hb1), _ptr(hw2), _ptr(hb2), _ptr(iw0), _ptr(ib0), _ptr(iw1), _ptr(ib1), _ptr(iw2),
+         _ptr(ib2), _ptr(pw0), _ptr(pb0), _ptr(pw1), _ptr(pb1), _ptr(pw2), _ptr(pb2), _ptr(hyper), _ptr(iou0), _ptr(res_iou), B)
 
 
 def linear_f32(a, w, bias=None, out=None, act=ACT_NONE, residual=None, M=None, lda=None):

@@ -214,6 +214,21 @@ int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, con
                        const float* norm3_b, const void* k_w_f16, const float* k_b, const void* v_w_f16, const float* v_b,
                        const void* next_q_w_f16_or_null, const float* next_q_b_or_null, float eps, void* q16, void* qpe16,
                        void* i2t_k_f16, void* i2t_v_f16, void* t2i_q_f16_or_null, int B);
+/* Small batches: everything between the final token->image attention and the upscaler in one launch -- out projection +
+ * residual + final LayerNorm (transformer.py:105-112), the four hyper-network MLPs (mask_decoder.py:175-179: 256 -> 256 -> 256 -> 32
+ * on mask tokens 1..4; third layer fp32), the IoU head (:184, on token 0; third layer fp32, 4 outputs) and the parallel residual
+ * IoU head (:194-198: [token 0 | mask token l] 512 -> 256 -> 256 -> 1, + the IoU head's output l).  hyper_w0 / w1 fp16 [4][256][256],
+ * hyper_w2 fp32 [4][32][256]; iou_w0 / w1 fp16 [256][256], iou_w2 fp32 [4][256]; par_w0 fp16 [256][512], par_w1 fp16 [256][256],
+ * par_w2 fp32 [1][256].  Writes hyper fp32 [B][4][32], iou0 fp32 [B][4], res_iou fp32 [B][4].  IoU outputs bit-identical to the
+ * launch sequence csam_gemm_f16 / _batched + csam_layernorm_cast + csam_linear_f32 / _batched it replaces, hyper outputs to
+ * the last fp32 bit. */
+int csam_token_heads(void* stream, const void* attn_o_f16, const float* queries, const void* o_w_f16, const float* o_b,
+                     const float* norm_g, const float* norm_b, float eps, const void* hyper_w0_f16, const float* hyper_b0,
+                     const void* hyper_w1_f16, const float* hyper_b1, const float* hyper_w2, const float* hyper_b2,
+                     const void* iou_w0_f16, const float* iou_b0, const void* iou_w1_f16, const float* iou_b1,
+                     const float* iou_w2, const float* iou_b2, const void* par_w0_f16, const float* par_b0,
+                     const void* par_w1_f16, const float* par_b1, const float* par_w2, const float* par_b2, float* hyper_out,
+                     float* iou0_out, float* res_iou_out, int B);
 int csam_splitk_reduce(void* stream, const float* partials, int splits, long slab_stride, const float* stats_or_null,
                        const float* bias_or_null, const float* residual_or_null, long ldr, float* out, long ldo, int rows,
                        int N);
