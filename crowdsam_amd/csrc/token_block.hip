@@ -13,8 +13,10 @@
 //      of the token->image attention;
 //   B: out projection of the token->image attention + residual -> norm2 -> MLP (256 -> 2048 ReLU -> 256) + residual -> norm3
 //      -> k / v projections of the image->token attention [-> q projection of the NEXT token->image attention].
-// Weights stream from L2 as MFMA A-fragments (16 output features x 32 inputs per instruction, 16-byte loads straight from the
-// row-major [N][K] matrices, two fragment sets in flight per wave); the token rows are the B operand, read from LDS.
+// Weights stream from L2 as MFMA A-fragments (16 output features x 32 inputs per instruction).  They are stored in FRAGMENT
+// ORDER -- [N / 16][K / 32][lane = 16 (k % 32 / 8) + n % 16][8] instead of row-major [N][K], a plan-time permutation
+// (hip.frag_order) -- so that a wave's load is one contiguous KB; two fragment sets are in flight per wave.  The token rows
+// are the B operand, read from LDS.
 // Rounding points are those of the launch sequence it replaces: fp16 operands, fp32 accumulation in ascending K order, fp16
 // outputs where the separate kernels wrote fp16, the LayerNorm expression of csam_layernorm_cast.
 #include "csam_common.h"
@@ -41,9 +43,10 @@ __device__ __forceinline__ void linear16(const half_t* __restrict__ W, int N, co
   floatx4 acc = {0.f, 0.f, 0.f, 0.f};
   auto issue = [&](half8_t (&w)[KS], int it) {
     const int nt = wave + (it / NCH) * TB_WAVES, c = it % NCH;
-    const half_t* src = W + (long)(nt * 16 + fr) * LDW + c * (KS * 32) + fg * 8;
+    // fragment order: [n-tile][k-step][lane][8] -- a wave's load is 1 KB contiguous
+    const half_t* src = W + (((long)nt * (LDW / 32) + c * KS) * 64 + lane) * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) w[ks] = *(const half8_t*)(src + ks * 32);
+    for (int ks = 0; ks < KS; ++ks) w[ks] = *(const half8_t*)(src + ks * 512);
   };
   auto consume = [&](half8_t (&w)[KS], int it) {
     const int nt = wave + (it / NCH) * TB_WAVES, c = it % NCH;
@@ -354,7 +357,7 @@ __device__ __forceinline__ void chunk_pass(int total, Get get, Epi epi) {
   auto issue = [&](half8_t (&w)[8], int it) {
     const HItem t = get(it);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w[ks] = *(const half8_t*)(t.w + ks * 32);
+    for (int ks = 0; ks < 8; ++ks) w[ks] = *(const half8_t*)(t.w + ks * 512);
   };
   auto consume = [&](half8_t (&w)[8], int it) {
     const HItem t = get(it);
@@ -423,19 +426,19 @@ __global__ __launch_bounds__(TB_THREADS) void token_heads_kernel(TokH p) {
   // ---- first layers (fp16 out, ReLU): g = 0..3 hyper MLP l = g on token 1 + l, g = 4 IoU head on token 0, g = 5 parallel head
   // (K = 512: two fragment sets).  Tile row fr of product g is prompt fr (g < 5) / (prompt, mask) fr (g = 5); the rest reads zeros.
   {
-    const int n0 = wave * 16 + fr;                         // this lane's weight row inside a 256-row matrix
+    // weights in fragment order: tile `wave` of a [256][K] matrix starts at wave * (K / 32) * 512 halfs
     auto get = [&](int it) {
       HItem t;
       const int g = it < 6 ? it : 5, c = it == 6 ? 1 : 0;
       t.g = g; t.first = c == 0; t.last = g < 5 || c == 1;
       if (g < 4) {
-        t.w = p.hw0 + ((long)g * 256 + n0) * 256 + fg * 8;
+        t.w = p.hw0 + (long)g * 256 * 256 + ((long)wave * 8 * 64 + lane) * 8;
         t.x = (fr < npr ? hs + (fr * 7 + 1 + g) * LD256 : zero) + fg * 8;
       } else if (g == 4) {
-        t.w = p.iw0 + (long)n0 * 256 + fg * 8;
+        t.w = p.iw0 + ((long)wave * 8 * 64 + lane) * 8;
         t.x = (fr < npr ? hs + (fr * 7) * LD256 : zero) + fg * 8;
       } else {
-        t.w = p.pw0 + (long)n0 * 512 + c * 256 + fg * 8;
+        t.w = p.pw0 + (((long)wave * 16 + c * 8) * 64 + lane) * 8;
         t.x = (fr < 8 ? xf + fr * LD512 + c * 256 : zero) + fg * 8;
       }
       return t;
@@ -452,12 +455,11 @@ __global__ __launch_bounds__(TB_THREADS) void token_heads_kernel(TokH p) {
   __syncthreads();
   // ---- second layers (fp32 out, ReLU)
   {
-    const int n0 = wave * 16 + fr;
     auto get = [&](int it) {
       HItem t;
       t.g = it; t.first = t.last = true;
       const half_t* w = it < 4 ? p.hw1 + (long)it * 256 * 256 : it == 4 ? p.iw1 : p.pw1;
-      t.w = w + (long)n0 * 256 + fg * 8;
+      t.w = w + ((long)wave * 8 * 64 + lane) * 8;
       const int rows = it < 5 ? 2 : 8, base = it < 4 ? it * 2 : it == 4 ? 8 : 10;
       t.x = (fr < rows ? l1 + (base + fr) * LD256 : zero) + fg * 8;
       return t;

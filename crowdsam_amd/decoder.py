@@ -137,6 +137,7 @@ class DecoderPlan:
         # block + norm1 + q projection; out projection + norm2 + MLP + norm3 + k / v projections).  CSAM_TOKEN_BLOCK=0: the
         # separate GEMM / LayerNorm / attention launches
         self.token_block = os.environ.get("CSAM_TOKEN_BLOCK", "1") != "0"
+        self._tb = None                              # fragment-ordered copies of the token-side weights (built on first use)
         self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -372,6 +373,17 @@ class DecoderPlan:
         return self.state["fg"]
 
     # ------------------------------------------------------------------------------------------
+    def _token_weights(self):
+        """Fragment-ordered copies (hip.frag_order) of the weights csam_token_block_a / _b / csam_token_heads stream."""
+        fo = hip.frag_order
+        layers = [{k: fo(L[k]) for k in ("sa_qk_w", "sa_v_w", "sa_o_w", "t2i_q_w", "t2i_o_w", "mlp1_w", "mlp2_w", "i2t_k_w_s",
+                                         "i2t_v_w")} for L in self.layers]
+        final = {k: fo(self.final[k]) for k in ("q_w", "o_w")}
+        heads = dict(hw0=fo(self.hyper_w0), hw1=fo(self.hyper_w1), iw0=fo(self.iou_w16[0]), iw1=fo(self.iou_w16[1]),
+                     pw0=fo(self.par_w16[0]), pw1=fo(self.par_w16[1]))
+        self._tb = dict(layers=layers, final=final, heads=heads)
+        return self._tb
+
     def run_batch(self, coords_f32):
         """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C]).
         The ~100 launches of a batch are captured once per batch size into a hipGraph and replayed."""
@@ -466,9 +478,11 @@ class DecoderPlan:
         for li, L in enumerate(self.layers):
             if tok:
                 # ---- token side in two launches around the token->image attention (csrc/token_block.hip)
-                hip.token_block_a(None if li == 0 else qpe16, q16, tokens0, None if li == 0 else queries, L["sa_qk_w"],
-                                  L["sa_qk_b"], L["sa_v_w"], L["sa_v_b"], L["sa_o_w"], L["sa_o_b"], L["norm1_g"], L["norm1_b"],
-                                  1e-5, L["t2i_q_w"], L["t2i_q_b"], queries, q16, qpe16, ws["t2i_q"], B)
+                TB = self._tb or self._token_weights()
+                W = TB["layers"][li]
+                hip.token_block_a(None if li == 0 else qpe16, q16, tokens0, None if li == 0 else queries, W["sa_qk_w"],
+                                  L["sa_qk_b"], W["sa_v_w"], L["sa_v_b"], W["sa_o_w"], L["sa_o_b"], L["norm1_g"], L["norm1_b"],
+                                  1e-5, W["t2i_q_w"], L["t2i_q_b"], queries, q16, qpe16, ws["t2i_q"], B)
                 if li == 0:
                     t2i(None, None, st["kv0"], 256, 0, None, None, None, None, dict(K0=st["k0"], V0T=st["v0t"]),
                         q_ready=True, epilogue=False)
@@ -476,10 +490,10 @@ class DecoderPlan:
                     t2i(None, None, None, 0, 0, None, None, None, None,
                         dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]), q_ready=True, epilogue=False)
                 last = li + 1 == len(self.layers)
-                hip.token_block_b(ws["t2i_o"], queries, tokens0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
-                                  L["mlp1_w"], L["mlp1_b"], L["mlp2_w"], L["mlp2_b"], L["norm3_g"], L["norm3_b"],
-                                  L["i2t_k_w_s"], L["i2t_k_b_s"], L["i2t_v_w"], L["i2t_v_b"], 1e-5, q16, qpe16, ws["i2t_k"],
-                                  ws["i2t_v"], B, next_q_w=self.final["q_w"] if last else None,
+                hip.token_block_b(ws["t2i_o"], queries, tokens0, W["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                                  W["mlp1_w"], L["mlp1_b"], W["mlp2_w"], L["mlp2_b"], L["norm3_g"], L["norm3_b"],
+                                  W["i2t_k_w_s"], L["i2t_k_b_s"], W["i2t_v_w"], L["i2t_v_b"], 1e-5, q16, qpe16, ws["i2t_k"],
+                                  ws["i2t_v"], B, next_q_w=TB["final"]["q_w"] if last else None,
                                   next_q_b=self.final["q_b"] if last else None, t2i_q=ws["t2i_q"] if last else None)
                 final_q_ready = last
                 if li == 0:
@@ -597,10 +611,12 @@ class DecoderPlan:
             # the IoU head and the parallel residual head (csam_token_heads; the 13 launches below, equal to the last fp32 bit)
             t2i(None, None, None, 0, 0, None, None, None, None, dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"]),
                 q_ready=final_q_ready, epilogue=False)
-            hip.token_heads(ws["t2i_o"], queries, F["o_w"], F["o_b"], F["norm_g"], F["norm_b"], 1e-5, self.hyper_w0,
-                            self.hyper_b0, self.hyper_w1, self.hyper_b1, self.hyper_w2, self.hyper_b2, self.iou_w16[0],
-                            self.iou_head[0][1], self.iou_w16[1], self.iou_head[1][1], self.iou_head[2][0], self.iou_head[2][1],
-                            self.par_w16[0], self.par_iou_head[0][1], self.par_w16[1], self.par_iou_head[1][1],
+            TB = self._tb or self._token_weights()
+            H = TB["heads"]
+            hip.token_heads(ws["t2i_o"], queries, TB["final"]["o_w"], F["o_b"], F["norm_g"], F["norm_b"], 1e-5, H["hw0"],
+                            self.hyper_b0, H["hw1"], self.hyper_b1, self.hyper_w2, self.hyper_b2, H["iw0"],
+                            self.iou_head[0][1], H["iw1"], self.iou_head[1][1], self.iou_head[2][0], self.iou_head[2][1],
+                            H["pw0"], self.par_iou_head[0][1], H["pw1"], self.par_iou_head[1][1],
                             self.par_iou_head[2][0], self.par_iou_head[2][1], ws["hyper"], ws["iou"], ws["res_iou"], B)
             iou = ws["res_iou"][:B * 4]
         if not tok:

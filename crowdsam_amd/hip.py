@@ -486,6 +486,14 @@ def gemm_f16_splitk(a, w, out, splits, scratch, bias=None, residual=None, rowsta
     return out
 
 
+def frag_order(w):
+    """fp16 [.., N, K] row-major -> the fragment order csam_token_block_* / csam_token_heads read (include/csam.h)."""
+    *lead, N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0 and w.dtype == torch.float16
+    return w.reshape(*lead, N // 16, 16, K // 32, 4, 8).permute(*range(len(lead)), len(lead), len(lead) + 2, len(lead) + 3,
+                                                                len(lead) + 1, len(lead) + 4).contiguous()
+
+
 def token_block_a(src_qk, src_v, tokens0, residual, qk_w, qk_b, v_w, v_b, o_w, o_b, norm_g, norm_b, eps, q_w, q_b,
                   queries, q16, qpe16, t2i_q, B):
     """Token self-attention block + norm1 + the q projection of the token->image attention in one launch (small batches;

@@ -201,8 +201,10 @@ int csam_rowscale_bias(void* stream, const float* P, const float* stats, const f
  * _b: out projection of the token->image attention + residual + norm2 (:175-177), MLP 256 -> 2048 ReLU -> 256 + residual +
  *     norm3 (:180-183), the k / v projections of the image->token attention (:186-190) and, when next_q_w is given, the q
  *     projection of the NEXT token->image attention.  queries is read (residual) and rewritten.
- * Weights fp16 row-major [N][K], biases / LayerNorm parameters fp32.  Bit-identical to the launch sequence they replace
- * (csam_gemm_f16, csam_token_self_attn, csam_layernorm_cast ... in single-pass form). */
+ * fp16 weights in FRAGMENT ORDER: element (n, k) of a row-major [N][K] matrix at
+ *   ((n / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + n % 16) * 8 + k % 8
+ * (one 1 KB wave load per MFMA A-fragment); biases / LayerNorm parameters fp32.  Bit-identical to the launch sequence they
+ * replace (csam_gemm_f16, csam_token_self_attn, csam_layernorm_cast ... in single-pass form). */
 int csam_token_block_a(void* stream, const void* src_qk_f16, const void* src_v_f16, const float* tokens0, int from_tokens,
                        const float* residual_or_null, const void* qk_w_f16, const float* qk_b, const void* v_w_f16,
                        const float* v_b, const void* o_w_f16, const float* o_b, const float* norm_g, const float* norm_b,
@@ -216,7 +218,7 @@ int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, con
                        void* i2t_k_f16, void* i2t_v_f16, void* t2i_q_f16_or_null, int B);
 /* Small batches: everything between the final token->image attention and the upscaler in one launch -- out projection +
  * residual + final LayerNorm (transformer.py:105-112), the four hyper-network MLPs (mask_decoder.py:175-179: 256 -> 256 -> 256 -> 32
- * on mask tokens 1..4; third layer fp32), the IoU head (:184, on token 0; third layer fp32, 4 outputs) and the parallel residual
+ * on mask tokens 1..4; third layer fp32; fp16 weights in the fragment order of csam_token_block_a, per matrix), the IoU head (:184, on token 0; third layer fp32, 4 outputs) and the parallel residual
  * IoU head (:194-198: [token 0 | mask token l] 512 -> 256 -> 256 -> 1, + the IoU head's output l).  hyper_w0 / w1 fp16 [4][256][256],
  * hyper_w2 fp32 [4][32][256]; iou_w0 / w1 fp16 [256][256], iou_w2 fp32 [4][256]; par_w0 fp16 [256][512], par_w1 fp16 [256][256],
  * par_w2 fp32 [1][256].  Writes hyper fp32 [B][4][32], iou0 fp32 [B][4], res_iou fp32 [B][4].  IoU outputs bit-identical to the
