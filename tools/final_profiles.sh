@@ -20,10 +20,11 @@ for i in 1 2 3; do python bench.py --no-cpu-baseline --no-kernel-timer 2>/dev/nu
 python tools/dev_bench_gemm.py > gpurun_out/${TAG}_gemm_shapes.txt 2>&1
 python tools/dev_gemm_ingraph.py > gpurun_out/${TAG}_gemm_ingraph.txt 2>&1
 python tools/dev_gemm_breakdown.py > gpurun_out/${TAG}_gemm_breakdown.txt 2>&1
-bash tools/prof_bench.sh ${TAG}_bench --steps 10 --warmup 3 --no-cpu-e2e
+bash tools/prof_bench.sh ${TAG}_bench --steps 10 --warmup 3 --no-cpu-e2e --serial     # per-kernel averages: the serial trace
+bash tools/prof_bench.sh ${TAG}_bench_pipelined --steps 10 --warmup 3 --no-cpu-e2e
 bash tools/prof_bench.sh ${TAG}_encoder_only --encoder-only --steps 20 --warmup 3
 bash tools/prof_bench.sh ${TAG}_eps_mode --mode eps --grid 192 --points-per-batch 32 --stability-thresh 0.25 --steps 6 --warmup 3 --crowd-keep 0
-bash tools/collect_pmc.sh --serial
+bash tools/collect_pmc.sh --crowd-keep 0 --serial     # one leg only: the collapsed leg would double the image count
 cp gpurun_out/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 bash tools/pmc_mfma_calib.sh > /dev/null 2>&1
 bash tools/pmc_mfma_util.sh encoder > /dev/null 2>&1
