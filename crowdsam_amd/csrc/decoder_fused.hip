@@ -3352,7 +3352,7 @@ extern "C" long csam_t2i_fused_workspace_bytes(int B) { return (long)B * T2I_PAR
 extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
                               const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
                               void* workspace, long workspace_bytes) {
-  CSAM_REQUIRE(q_f16 && out_f16 && workspace && B > 0, "csam_t2i_fused: bad args");
+  CSAM_REQUIRE(q_f16 && workspace && B > 0, "csam_t2i_fused: bad args");
   CSAM_REQUIRE((X_f16 != nullptr) != (K0_f16 != nullptr), "csam_t2i_fused: give either keys+weights or hoisted K0/V0T");
   CSAM_REQUIRE(!X_f16 || (Wkv_f16 && kpe && bv), "csam_t2i_fused: Wkv/kpe/bv required with keys");
   CSAM_REQUIRE(!K0_f16 || V0T_f16, "csam_t2i_fused: V0T required with K0");
@@ -3375,5 +3375,8 @@ extern "C" int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f
   else
     hipLaunchKernelGGL(t2i_fused_kernel<0>, grid, dim3(T2I_NW * 64), T2I_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_t2i_fused");
+  if (!out_f16) return CSAM_OK;       // the caller merges the csam_t2i_fused_parts() partial records itself (csam_token_block_b)
   return csam_t2i_merge_launch(stream, (const float*)workspace, out_f16, B, T2I_PARTS);
 }
+
+extern "C" int csam_t2i_fused_parts(void) { return T2I_PARTS; }

@@ -92,6 +92,43 @@ __device__ __forceinline__ half4_t to_half4(floatx4 v) {
   return half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
 }
 
+// the attention output of rows 0 .. nrow-1 into xo [16][LD128]: either the merged fp16 rows, or merged here from
+// csam_t2i_fused's partial records (t2i_merge_kernel's arithmetic: thread = (prompt, head, query))
+__device__ __forceinline__ void load_attn(half_t* xo, const half_t* attn_o, const float* part, int nparts, int row0, int nrow,
+                                          int tid) {
+  if (part) {
+    if (tid < 112) {
+      const int pr = tid / 56, t = tid % 56, h = t / 7, qi = t % 7, r = pr * 7 + qi;
+      if (r < nrow) {
+        const int b = row0 / 7 + pr;
+        float m = -INFINITY, l = 0.f, acc[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+        for (int q = 0; q < nparts; ++q) {
+          const float* src = part + ((((long)b * nparts + q) * 8 + h) * 7 + qi) * 18;
+          const float mo = src[0], lo = src[1];
+          const float mn = fmaxf(m, mo);
+          const float a = csam_exp2(m - mn), bb = csam_exp2(mo - mn);
+          l = l * a + lo * bb;
+#pragma unroll
+          for (int d = 0; d < 16; ++d) acc[d] = acc[d] * a + src[2 + d] * bb;
+          m = mn;
+        }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) xo[r * LD128 + h * 16 + d] = (half_t)(acc[d] * inv);
+      }
+    } else if (tid >= 128 && tid < 128 + 16) {          // rows nrow .. 15: zero
+      for (int r = nrow; r < 16; ++r) *(half8_t*)(xo + r * LD128 + (tid - 128) * 8) = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  } else if (tid < 16 * 16) {                            // 16 rows x 16 chunks of 8 channels
+    const int r = tid >> 4, c = (tid & 15) * 8;
+    half8_t a = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < nrow) a = *(const half8_t*)(attn_o + (long)(row0 + r) * 128 + c);
+    *(half8_t*)(xo + r * LD128 + c) = a;
+  }
+}
+
 struct TokA {
   const half_t* src_qk; const half_t* src_v; const float* tokens0; int from_tokens; const float* residual;
   const half_t* qk_w; const float* qk_b; const half_t* v_w; const float* v_b; const half_t* o_w; const float* o_b;
@@ -224,7 +261,7 @@ __global__ __launch_bounds__(TB_THREADS) void token_block_a_kernel(TokA p) {
 }
 
 struct TokB {
-  const half_t* attn_o; float* queries; const float* tokens0;
+  const half_t* attn_o; const float* part; int nparts; float* queries; const float* tokens0;
   const half_t* o_w; const float* o_b; const float* n2_g; const float* n2_b;
   const half_t* m1_w; const float* m1_b; const half_t* m2_w; const float* m2_b; const float* n3_g; const float* n3_b;
   const half_t* k_w; const float* k_b; const half_t* v_w; const float* v_b; const half_t* q_w; const float* q_b; float eps;
@@ -250,12 +287,7 @@ __global__ __launch_bounds__(TB_THREADS) void token_block_b_kernel(TokB p) {
   const int fr = lane & 15, fg = lane >> 4;
   const int row0 = blockIdx.x * TB_ROWS;
   const int nrow = min(TB_ROWS, p.M7 - row0);
-  if (tid < 16 * 16) {                                     // 16 rows x 16 chunks of 8 channels
-    const int r = tid >> 4, c = (tid & 15) * 8;
-    half8_t a = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < nrow) a = *(const half8_t*)(p.attn_o + (long)(row0 + r) * 128 + c);
-    *(half8_t*)(xo + r * LD128 + c) = a;
-  }
+  load_attn(xo, p.attn_o, p.part, p.nparts, row0, nrow, tid);
   __syncthreads();
   // ---- out projection of the token->image attention + residual -> norm2
   linear16<128, LD128>(p.o_w, 256, xo, wave, lane, [&](int nt, floatx4 acc) {
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(TB_THREADS) void token_block_b_kernel(TokB p) {
 // outputs to the last bit (that kernel's rows 6, 7 of 8 are scheduled without fma contraction).
 // ---------------------------------------------------------------------------------------------------------------
 struct TokH {
-  const half_t* attn_o; const float* queries; const half_t* o_w; const float* o_b; const float* n_g; const float* n_b; float eps;
+  const half_t* attn_o; const float* part; int nparts; const float* queries; const half_t* o_w; const float* o_b; const float* n_g; const float* n_b; float eps;
   const half_t* hw0; const float* hb0; const half_t* hw1; const float* hb1; const float* hw2; const float* hb2;
   const half_t* iw0; const float* ib0; const half_t* iw1; const float* ib1; const float* iw2; const float* ib2;
   const half_t* pw0; const float* pb0; const half_t* pw1; const float* pb1; const float* pw2; const float* pb2;
@@ -394,12 +426,7 @@ __global__ __launch_bounds__(TB_THREADS) void token_heads_kernel(TokH p) {
   const int row0 = blockIdx.x * TB_ROWS;
   const int nrow = min(TB_ROWS, p.M7 - row0);
   const int npr = nrow / 7;                                // prompts of this workgroup: 2, or 1
-  if (tid < 16 * 16) {
-    const int r = tid >> 4, c = (tid & 15) * 8;
-    half8_t a = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < nrow) a = *(const half8_t*)(p.attn_o + (long)(row0 + r) * 128 + c);
-    *(half8_t*)(xo + r * LD128 + c) = a;
-  }
+  load_attn(xo, p.attn_o, p.part, p.nparts, row0, nrow, tid);
   if (tid >= 256 && tid < 256 + LD512 / 8) *(half8_t*)(zero + (tid - 256) * 8) = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
   // ---- out projection of the final attention + residual -> final LayerNorm
@@ -554,19 +581,20 @@ extern "C" int csam_token_block_a(void* stream, const void* src_qk_f16, const vo
   return CSAM_OK;
 }
 
-extern "C" int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, const float* tokens0,
+extern "C" int csam_token_block_b(void* stream, const void* attn_o_f16, const float* t2i_partials_or_null, int nparts,
+                                  float* queries, const float* tokens0,
                                   const void* o_w_f16, const float* o_b, const float* norm2_g, const float* norm2_b,
                                   const void* mlp1_w_f16, const float* mlp1_b, const void* mlp2_w_f16, const float* mlp2_b,
                                   const float* norm3_g, const float* norm3_b, const void* k_w_f16, const float* k_b,
                                   const void* v_w_f16, const float* v_b, const void* next_q_w_f16_or_null,
                                   const float* next_q_b_or_null, float eps, void* q16, void* qpe16, void* i2t_k_f16,
                                   void* i2t_v_f16, void* t2i_q_f16_or_null, int B) {
-  CSAM_REQUIRE(attn_o_f16 && queries && tokens0 && o_w_f16 && o_b && norm2_g && norm2_b && mlp1_w_f16 && mlp1_b && mlp2_w_f16 &&
+  CSAM_REQUIRE((attn_o_f16 || (t2i_partials_or_null && nparts > 0)) && queries && tokens0 && o_w_f16 && o_b && norm2_g && norm2_b && mlp1_w_f16 && mlp1_b && mlp2_w_f16 &&
                    mlp2_b && norm3_g && norm3_b && k_w_f16 && k_b && v_w_f16 && v_b && q16 && qpe16 && i2t_k_f16 && i2t_v_f16 &&
                    B > 0 && (!next_q_w_f16_or_null || (next_q_b_or_null && t2i_q_f16_or_null)),
                "csam_token_block_b: bad args");
   TokB a;
-  a.attn_o = (const half_t*)attn_o_f16; a.queries = queries; a.tokens0 = tokens0; a.o_w = (const half_t*)o_w_f16; a.o_b = o_b;
+  a.attn_o = (const half_t*)attn_o_f16; a.part = t2i_partials_or_null; a.nparts = nparts; a.queries = queries; a.tokens0 = tokens0; a.o_w = (const half_t*)o_w_f16; a.o_b = o_b;
   a.n2_g = norm2_g; a.n2_b = norm2_b; a.m1_w = (const half_t*)mlp1_w_f16; a.m1_b = mlp1_b; a.m2_w = (const half_t*)mlp2_w_f16;
   a.m2_b = mlp2_b; a.n3_g = norm3_g; a.n3_b = norm3_b; a.k_w = (const half_t*)k_w_f16; a.k_b = k_b;
   a.v_w = (const half_t*)v_w_f16; a.v_b = v_b; a.q_w = (const half_t*)next_q_w_f16_or_null; a.q_b = next_q_b_or_null;
@@ -580,20 +608,22 @@ extern "C" int csam_token_block_b(void* stream, const void* attn_o_f16, float* q
   return CSAM_OK;
 }
 
-extern "C" int csam_token_heads(void* stream, const void* attn_o_f16, const float* queries, const void* o_w_f16, const float* o_b,
+extern "C" int csam_token_heads(void* stream, const void* attn_o_f16, const float* t2i_partials_or_null, int nparts,
+                                const float* queries, const void* o_w_f16, const float* o_b,
                                 const float* norm_g, const float* norm_b, float eps, const void* hyper_w0_f16,
                                 const float* hyper_b0, const void* hyper_w1_f16, const float* hyper_b1, const float* hyper_w2,
                                 const float* hyper_b2, const void* iou_w0_f16, const float* iou_b0, const void* iou_w1_f16,
                                 const float* iou_b1, const float* iou_w2, const float* iou_b2, const void* par_w0_f16,
                                 const float* par_b0, const void* par_w1_f16, const float* par_b1, const float* par_w2,
                                 const float* par_b2, float* hyper_out, float* iou0_out, float* res_iou_out, int B) {
-  CSAM_REQUIRE(attn_o_f16 && queries && o_w_f16 && o_b && norm_g && norm_b && hyper_w0_f16 && hyper_b0 && hyper_w1_f16 &&
+  CSAM_REQUIRE((attn_o_f16 || (t2i_partials_or_null && nparts > 0)) && queries && o_w_f16 && o_b && norm_g && norm_b && hyper_w0_f16 && hyper_b0 && hyper_w1_f16 &&
                    hyper_b1 && hyper_w2 && hyper_b2 && iou_w0_f16 && iou_b0 && iou_w1_f16 && iou_b1 && iou_w2 && iou_b2 &&
                    par_w0_f16 && par_b0 && par_w1_f16 && par_b1 && par_w2 && par_b2 && hyper_out && iou0_out && res_iou_out &&
                    B > 0,
                "csam_token_heads: bad args");
   TokH a;
-  a.attn_o = (const half_t*)attn_o_f16; a.queries = queries; a.o_w = (const half_t*)o_w_f16; a.o_b = o_b; a.n_g = norm_g;
+  a.attn_o = (const half_t*)attn_o_f16; a.part = t2i_partials_or_null; a.nparts = nparts; a.queries = queries;
+  a.o_w = (const half_t*)o_w_f16; a.o_b = o_b; a.n_g = norm_g;
   a.n_b = norm_b; a.eps = eps; a.hw0 = (const half_t*)hyper_w0_f16; a.hb0 = hyper_b0; a.hw1 = (const half_t*)hyper_w1_f16;
   a.hb1 = hyper_b1; a.hw2 = hyper_w2; a.hb2 = hyper_b2; a.iw0 = (const half_t*)iou_w0_f16; a.ib0 = iou_b0;
   a.iw1 = (const half_t*)iou_w1_f16; a.ib1 = iou_b1; a.iw2 = iou_w2; a.ib2 = iou_b2; a.pw0 = (const half_t*)par_w0_f16;

@@ -412,9 +412,10 @@ class DecoderPlan:
             hip.layernorm_cast(ws["tmp32"][:M7], g, b, 1e-5, queries, out16=q16, pe=tokens0, outpe16=qpe16)
 
         def t2i(q_w, q_b, kv, ldkv, bstride, o_w, o_b, norm_g, norm_b, fused_args=None, cast16=None, q_ready=False,
-                epilogue=True):
+                epilogue=True, merge=True):
             """queries <- LN(queries + out_proj(attention)); cast16 receives fp16(queries) for the next consumer.
-            q_ready: ws["t2i_q"] already holds the q projection; epilogue False: stop after the attention (ws["t2i_o"])"""
+            q_ready: ws["t2i_q"] already holds the q projection; epilogue False: stop after the attention (ws["t2i_o"]);
+            merge False (csam_t2i_fused only): leave the partial records in ws["t2i_ws"] for the consumer to merge"""
             if fused_args is not None and "rank" in fused_args and self.t2i_rank and self.t2i_stream and B >= 256:
                 # rank-56 form (csam_t2i_rank): no per-key K / V projections; Wv and the out-projection in one GEMM
                 R = fused_args["rank"]
@@ -433,7 +434,8 @@ class DecoderPlan:
                 hip.t2i_stream(ws["t2i_q"], ws["t2i_o"], B, fused_args["X"], fused_args["Wkv"], fused_args["kpe"],
                                fused_args["bv"], T_IMG)
             elif fused_args is not None:
-                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"], B, ws["t2i_ws"], **{k: v for k, v in fused_args.items() if k not in ("rank", "y_ready")})
+                hip.t2i_fused(ws["t2i_q"], ws["t2i_o"] if merge else None, B, ws["t2i_ws"],
+                              **{k: v for k, v in fused_args.items() if k not in ("rank", "y_ready")})
             else:
                 hip.attn_t2i(ws["t2i_q"], kv, kv[:, 128:], ldkv, bstride, ws["t2i_o"], B, T_IMG, nsplit_t2i, ws["t2i_ws"])
             if not epilogue:
@@ -488,9 +490,10 @@ class DecoderPlan:
                         q_ready=True, epilogue=False)
                 else:
                     t2i(None, None, None, 0, 0, None, None, None, None,
-                        dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]), q_ready=True, epilogue=False)
+                        dict(X=keys_in, Wkv=L["t2i_kv_w"], kpe=L["t2i_kpe"], bv=L["t2i_bv"]), q_ready=True, epilogue=False,
+                        merge=False)
                 last = li + 1 == len(self.layers)
-                hip.token_block_b(ws["t2i_o"], queries, tokens0, W["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
+                hip.token_block_b(ws["t2i_o"], None if li == 0 else ws["t2i_ws"], queries, tokens0, W["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
                                   W["mlp1_w"], L["mlp1_b"], W["mlp2_w"], L["mlp2_b"], L["norm3_g"], L["norm3_b"],
                                   W["i2t_k_w_s"], L["i2t_k_b_s"], W["i2t_v_w"], L["i2t_v_b"], 1e-5, q16, qpe16, ws["i2t_k"],
                                   ws["i2t_v"], B, next_q_w=TB["final"]["q_w"] if last else None,
@@ -610,10 +613,10 @@ class DecoderPlan:
             # small batches: attention, then ONE launch for its out projection + final LayerNorm, the four hyper-network MLPs,
             # the IoU head and the parallel residual head (csam_token_heads; the 13 launches below, equal to the last fp32 bit)
             t2i(None, None, None, 0, 0, None, None, None, None, dict(X=keys_in, Wkv=F["kv_w"], kpe=F["kpe"], bv=F["bv"]),
-                q_ready=final_q_ready, epilogue=False)
+                q_ready=final_q_ready, epilogue=False, merge=False)
             TB = self._tb or self._token_weights()
             H = TB["heads"]
-            hip.token_heads(ws["t2i_o"], queries, TB["final"]["o_w"], F["o_b"], F["norm_g"], F["norm_b"], 1e-5, H["hw0"],
+            hip.token_heads(ws["t2i_o"], ws["t2i_ws"], queries, TB["final"]["o_w"], F["o_b"], F["norm_g"], F["norm_b"], 1e-5, H["hw0"],
                             self.hyper_b0, H["hw1"], self.hyper_b1, self.hyper_w2, self.hyper_b2, H["iw0"],
                             self.iou_head[0][1], H["iw1"], self.iou_head[1][1], self.iou_head[2][0], self.iou_head[2][1],
                             H["pw0"], self.par_iou_head[0][1], H["pw1"], self.par_iou_head[1][1],

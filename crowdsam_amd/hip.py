@@ -49,9 +49,10 @@ SIGNATURES = {
     "csam_rowscale_bias": [_P, _P, _P, _P, _P, _I, _I],
     "csam_splitk_reduce": [_P, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I],
     "csam_token_block_a": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I],
-    "csam_token_heads": [_P, _P, _P, _P, _P, _P, _P, _F] + [_P] * 21 + [_I],
-    "csam_token_block_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+    "csam_token_heads": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F] + [_P] * 21 + [_I],
+    "csam_token_block_b": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                            _P, _I],
+    "csam_t2i_fused_parts": [],
     "csam_select_masks": [_P, _P, _P, _I, _P, _P, _P, _P, _I],
     "csam_mask_post": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "csam_mask_post_scored": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
@@ -503,20 +504,24 @@ def token_block_a(src_qk, src_v, tokens0, residual, qk_w, qk_b, v_w, v_b, o_w, o
          _ptr(q_b), _ptr(queries), _ptr(q16), _ptr(qpe16), _ptr(t2i_q), B)
 
 
-def token_block_b(attn_o, queries, tokens0, o_w, o_b, n2_g, n2_b, m1_w, m1_b, m2_w, m2_b, n3_g, n3_b, k_w, k_b, v_w, v_b,
+def t2i_fused_parts():
+    return int(lib().csam_t2i_fused_parts())
+
+
+def token_block_b(attn_o, partials, queries, tokens0, o_w, o_b, n2_g, n2_b, m1_w, m1_b, m2_w, m2_b, n3_g, n3_b, k_w, k_b, v_w, v_b,
                   eps, q16, qpe16, i2t_k, i2t_v, B, next_q_w=None, next_q_b=None, t2i_q=None):
     """Out projection of the token->image attention + norm2 + MLP + norm3 + the k / v projections of the image->token
     attention (+ the next token->image attention's q projection) in one launch (small batches; csrc/token_block.hip)."""
-    call("csam_token_block_b", _stream(), _ptr(attn_o), _ptr(queries), _ptr(tokens0), _ptr(o_w), _ptr(o_b), _ptr(n2_g), _ptr(n2_b),
+    call("csam_token_block_b", _stream(), _ptr(attn_o), _ptr(partials), 0 if partials is None else t2i_fused_parts(), _ptr(queries), _ptr(tokens0), _ptr(o_w), _ptr(o_b), _ptr(n2_g), _ptr(n2_b),
          _ptr(m1_w), _ptr(m1_b), _ptr(m2_w), _ptr(m2_b), _ptr(n3_g), _ptr(n3_b), _ptr(k_w), _ptr(k_b), _ptr(v_w), _ptr(v_b),
          _ptr(next_q_w), _ptr(next_q_b), eps, _ptr(q16), _ptr(qpe16), _ptr(i2t_k), _ptr(i2t_v), _ptr(t2i_q), B)
 
 
-def token_heads(attn_o, queries, o_w, o_b, norm_g, norm_b, eps, hw0, hb0, hw1, hb1, hw2, hb2, iw0, ib0, iw1, ib1, iw2, ib2,
+def token_heads(attn_o, partials, queries, o_w, o_b, norm_g, norm_b, eps, hw0, hb0, hw1, hb1, hw2, hb2, iw0, ib0, iw1, ib1, iw2, ib2,
                 pw0, pb0, pw1, pb1, pw2, pb2, hyper, iou0, res_iou, B):
     """Out projection + LayerNorm of the final token->image attention, the four hyper-network MLPs, the IoU head and the
     parallel residual IoU head in one launch (small batches; csrc/token_block.hip)."""
-    call("csam_token_heads", _stream(), _ptr(attn_o), _ptr(queries), _ptr(o_w), _ptr(o_b), _ptr(norm_g), _ptr(norm_b), eps,
+    call("csam_token_heads", _stream(), _ptr(attn_o), _ptr(partials), 0 if partials is None else t2i_fused_parts(), _ptr(queries), _ptr(o_w), _ptr(o_b), _ptr(norm_g), _ptr(norm_b), eps,
          _ptr(hw0), _ptr(hb0), _ptr(hw1), _ptr(hb1), _ptr(hw2), _ptr(hb2), _ptr(iw0), _ptr(ib0), _ptr(iw1), _ptr(ib1), _ptr(iw2),
          _ptr(ib2), _ptr(pw0), _ptr(pb0), _ptr(pw1), _ptr(pb1), _ptr(pw2), _ptr(pb2), _ptr(hyper), _ptr(iou0), _ptr(res_iou), B)
 
@@ -956,7 +961,8 @@ def pool_adjoint_v2(masks, stats, taps, w, rows):
 
 
 def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None, V0T=None):
-    """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge."""
+    """Fused token->image attention: K/V projections of the key state + softmax + PV + partial merge (``out`` None: the
+    partial records stay in ``workspace`` for a consumer that merges them, csam_token_block_b / csam_token_heads)."""
     call("csam_t2i_fused", _stream(), _ptr(X), _ptr(Wkv), _ptr(kpe), _ptr(bv), _ptr(K0), _ptr(V0T), _ptr(q), _ptr(out),
          B, _ptr(workspace), workspace.numel() * workspace.element_size())
     return out

@@ -200,7 +200,8 @@ int csam_rowscale_bias(void* stream, const float* P, const float* stats, const f
  *     Writes queries fp32 [B*7,256], q16 = fp16(queries), qpe16 = fp16(queries + tokens0), t2i_q fp16 [B*7,128].
  * _b: out projection of the token->image attention + residual + norm2 (:175-177), MLP 256 -> 2048 ReLU -> 256 + residual +
  *     norm3 (:180-183), the k / v projections of the image->token attention (:186-190) and, when next_q_w is given, the q
- *     projection of the NEXT token->image attention.  queries is read (residual) and rewritten.
+ *     projection of the NEXT token->image attention.  queries is read (residual) and rewritten.  With t2i_partials the
+ *     attention output is merged from csam_t2i_fused's partial records here (attn_o_f16 is ignored), in csam_t2i_merge's arithmetic.
  * fp16 weights in FRAGMENT ORDER: element (n, k) of a row-major [N][K] matrix at
  *   ((n / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + n % 16) * 8 + k % 8
  * (one 1 KB wave load per MFMA A-fragment); biases / LayerNorm parameters fp32.  Bit-identical to the launch sequence they
@@ -210,7 +211,7 @@ int csam_token_block_a(void* stream, const void* src_qk_f16, const void* src_v_f
                        const float* v_b, const void* o_w_f16, const float* o_b, const float* norm_g, const float* norm_b,
                        float eps, const void* q_w_f16, const float* q_b, float* queries, void* q16, void* qpe16,
                        void* t2i_q_f16, int B);
-int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, const float* tokens0, const void* o_w_f16,
+int csam_token_block_b(void* stream, const void* attn_o_f16, const float* t2i_partials_or_null, int nparts, float* queries, const float* tokens0, const void* o_w_f16,
                        const float* o_b, const float* norm2_g, const float* norm2_b, const void* mlp1_w_f16,
                        const float* mlp1_b, const void* mlp2_w_f16, const float* mlp2_b, const float* norm3_g,
                        const float* norm3_b, const void* k_w_f16, const float* k_b, const void* v_w_f16, const float* v_b,
@@ -224,7 +225,7 @@ int csam_token_block_b(void* stream, const void* attn_o_f16, float* queries, con
  * par_w2 fp32 [1][256].  Writes hyper fp32 [B][4][32], iou0 fp32 [B][4], res_iou fp32 [B][4].  IoU outputs bit-identical to the
  * launch sequence csam_gemm_f16 / _batched + csam_layernorm_cast + csam_linear_f32 / _batched it replaces, hyper outputs to
  * the last fp32 bit. */
-int csam_token_heads(void* stream, const void* attn_o_f16, const float* queries, const void* o_w_f16, const float* o_b,
+int csam_token_heads(void* stream, const void* attn_o_f16, const float* t2i_partials_or_null, int nparts, const float* queries, const void* o_w_f16, const float* o_b,
                      const float* norm_g, const float* norm_b, float eps, const void* hyper_w0_f16, const float* hyper_b0,
                      const void* hyper_w1_f16, const float* hyper_b1, const float* hyper_w2, const float* hyper_b2,
                      const void* iou_w0_f16, const float* iou_b0, const void* iou_w1_f16, const float* iou_b1,
@@ -309,7 +310,10 @@ int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, c
 int csam_upscale_stream(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                         const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
                         const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
-/* token->image attention with the K/V projections fused in (transformer.py:173-177,105-112) */
+/* token->image attention with the K/V projections fused in (transformer.py:173-177,105-112).  out_f16 NULL: the partial
+ * records stay in the workspace -- fp32 [B][csam_t2i_fused_parts()][8 heads][7 queries][18] = (running max, sum, 16 accumulators)
+ * of an online softmax in base 2 -- for a consumer that merges them itself (csam_token_block_b, csam_token_heads) */
+int csam_t2i_fused_parts(void);
 long csam_t2i_fused_workspace_bytes(int B);
 int csam_t2i_fused(void* stream, const void* X_f16, const void* Wkv_f16, const float* kpe, const float* bv,
                    const void* K0_f16, const void* V0T_f16, const void* q_f16, void* out_f16, int B,
