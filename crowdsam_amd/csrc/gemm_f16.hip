@@ -568,6 +568,20 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     const char* e = getenv("CSAM_GEMM_ROWS");
     force_rows = e ? atoi(e) : 0;
   }
+  // bytes in flight: one workgroup per CU with a deeper ring of a TALLER tile moves fewer operand bytes with as
+  // many of them in flight.  CSAM_GEMM_DEEP: 128-row tiles with 4 stages where 128-row tiles are one round of the chip (instead
+  // of two 64-row workgroups per CU with 3 stages); CSAM_GEMM_192: 192-row tiles with 3 stages where they are one round and
+  // 128-row tiles are not (instead of two 96-row workgroups per CU with 2 stages)
+  static int deep = -1, tall = -1;
+  if (deep < 0) {
+    const char* e = getenv("CSAM_GEMM_DEEP");
+    deep = e ? atoi(e) : 0;
+    const char* f = getenv("CSAM_GEMM_192");
+    tall = f ? atoi(f) : 0;
+  }
+  const long t192 = (long)(N / BN) * csam_cdiv(M, 192) * batch;
+  const bool use_deep = deep && small && t128 > 128;
+  const bool use_tall = tall && !small && t192 <= 256;
   bool small_f = small;
   if (force_rows == 64) { small_f = true; mid = false; }
   else if (force_rows == 96) { small_f = false; mid = true; }
@@ -596,7 +610,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }
-  dim3 grid((N / BN) * csam_cdiv(M, mid ? 96 : small_f ? 64 : BM), 1, batch);
+  dim3 grid((N / BN) * csam_cdiv(M, use_tall ? 192 : use_deep ? BM : mid ? 96 : small_f ? 64 : BM), 1, batch);
 #define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
@@ -608,7 +622,11 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
     hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
   }
-  if (mid) {
+  if (use_tall) {
+    CSAM_GEMM_LAUNCH(6, 4, 2, 2, 3, 64)
+  } else if (use_deep) {
+    CSAM_GEMM_LAUNCH(4, 4, 2, 2, 4, 64)
+  } else if (mid) {
     CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
   } else if (small_f) {
     if (variant == 0) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
