@@ -178,7 +178,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
     // done reading the buffer of stage kt-1, which the next prefetch overwrites
+#ifdef CSAM_GEMM_COUNTED
+    // A/B build: NS >= 3 keeps the stage issued in the previous iteration in flight (only LDS-DMA loads are outstanding in this
+    // loop, and they retire in order) -- two iterations of latency cover instead of one
+    if (NS >= 3 && kt + 1 < nk) wait_vmcnt<(NS >= 3 ? L : 0)>();
+    else wait_vmcnt<0>();
+#else
     wait_vmcnt<0>();     // NS >= 3: this also retires the stages issued ahead, one iteration before they are read
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
