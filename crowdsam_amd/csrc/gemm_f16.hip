@@ -73,6 +73,13 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
+#ifdef CSAM_GEMM_TS   /* developer timing build: where does a k-step of gemm_f16_kernel go?  tools/debug/gemm_kstep.py */
+__device__ long long* g_gemm_ts = nullptr;
+extern "C" int csam_dbg_set_gemm_ts(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &p, sizeof(p)); }
+#define GTS(k) do { if (ts_on) { const long long t__ = __builtin_amdgcn_s_memtime(); ts_acc[k] += t__ - ts_prev; ts_prev = t__; } } while (0)
+#else
+#define GTS(k) do {} while (0)
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -174,8 +181,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) stage(s, s * KB);
 
+#ifdef CSAM_GEMM_TS
+  const bool ts_on = g_gemm_ts && blockIdx.x == 5 && lane == 0 && wave == 1;
+  long long ts_acc[5] = {0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime();
+  const long long ts_begin = ts_prev;
+#endif
   int cur = 0;                                         // kt % NS
   for (int kt = 0; kt < nk; ++kt) {
+    GTS(4);
     // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
     // done reading the buffer of stage kt-1, which the next prefetch overwrites
 #ifdef CSAM_GEMM_COUNTED
@@ -186,9 +199,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 #else
     wait_vmcnt<0>();     // NS >= 3: this also retires the stages issued ahead, one iteration before they are read
 #endif
+    GTS(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    GTS(1);
+#ifndef CSAM_GEMM_INTERLEAVE
     if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
+    GTS(2);
     const char* base = smem + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -204,8 +221,63 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
+#else
+    // round-4 EXPERIMENT (-DCSAM_GEMM_INTERLEAVE; slower, not the default).  tools/debug/gemm_kstep.py (-DCSAM_GEMM_TS): of ~1 220
+    // cycles per k-step and wave, 370 go into ISSUING the next stage's six LDS-DMA pieces back to back in front of the first
+    // MFMA and 540 into fragment reads + 16 MFMAs (256 pipe cycles).  Here the pieces are issued BETWEEN groups of MFMAs and
+    // the fragments of the second half of the step are read before the first half's MFMAs -- and the k-loop takes 102 868 instead
+    // of 79 064 cycles (fc2 shape), the encoder 5.64 instead of 5.29 ms: a piece costs more between MFMAs than in front of them
+    GTS(2);
+    {
+      const char* base = smem + cur * STAGE;
+      const bool pf = kt + NS - 1 < nk;
+      const int nbuf = cur == 0 ? NS - 1 : cur - 1, k0n = (kt + NS - 1) * KB;
+      constexpr int KK = KB / 32, NM = MI * NI * KK;
+      constexpr int STRIDE = NM / L >= 1 ? NM / L : 1;
+      half8_t af[2][MI], wf[2][NI];
+      auto frags = [&](int kk, half8_t (&a)[MI], half8_t (&w)[NI]) {
+        const int coff = ((kk * 4 + fg) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w[i] = *(const half8_t*)(base + w_off[i] + coff);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *(const half8_t*)(base + a_off[i] + coff);
+      };
+      auto piece = [&](int i) {
+        char* abase = smem + nbuf * STAGE;
+        if (i < LW) glds16(w_src[i] + k0n, abase + A_BYTES + (wave * LW + i) * 1024);
+        else glds16(a_src[i - LW] + k0n, abase + (wave * LA + (i - LW)) * 1024);
+      };
+      frags(0, af[0], wf[0]);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        if (kk + 1 < KK) frags(kk + 1, af[(kk + 1) & 1], wf[(kk + 1) & 1]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni], 0, 0, 0);
+            const int g = (kk * MI + mi) * NI + ni + 1;             // MFMAs issued so far (compile-time after unrolling)
+            if (g % STRIDE == 0 && g / STRIDE <= L) {
+              if (pf) piece(g / STRIDE - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+    }
+#endif
+#ifdef CSAM_GEMM_TS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    GTS(3);
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
+#ifdef CSAM_GEMM_TS
+  if (ts_on) {
+    for (int i = 0; i < 5; ++i) g_gemm_ts[i] = ts_acc[i];
+    g_gemm_ts[5] = nk;
+    g_gemm_ts[6] = __builtin_amdgcn_s_memtime() - ts_begin;
+  }
+#endif
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
   float* stab = (float*)(smem + TBM * 512);            // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
   if (p.st_in) {
