@@ -93,9 +93,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   <4,4,2,2,2>  128-row tile, 4 waves, 2 x 32 KB: two workgroups per CU
 //   <2,4,2,2,3>   64-row tile, 4 waves, 3 x 24 KB: two workgroups per CU; for grids that would leave CUs idle
 //   <4,2,2,4,4>  128-row tile, 8 waves, 4 x 32 KB: one workgroup per CU, two waves per SIMD, 3 stages in flight
-template <int MI, int NI, int WM, int WN, int NS, int KB>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
+// NP > 0 (round 4): NP extra PRODUCER waves do nothing but issue the LDS-DMA pieces (tools/debug/gemm_kstep.py: 370 of a k-step's
+// 1 220 cycles per wave went into issuing them in front of the MFMAs); the NW = WM x WN consumer waves only read fragments and
+// multiply.  Same ring, same barriers, same arithmetic: bit-identical results.
+template <int MI, int NI, int WM, int WN, int NS, int KB, int NP = 0>
+__global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int NL = NP ? NP : NW;               // waves that load
   constexpr int TBM = WM * MI * 16;              // rows of the workgroup tile
   static_assert(WN * NI * 16 == BN, "tile is 128 columns wide");
   static_assert(KB == 64 || KB == 32, "K step");
@@ -104,8 +108,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   constexpr int SPR = PITCH / 16;                // 16-B slots per row (8 / 4)
   constexpr int A_BYTES = TBM * PITCH;
   constexpr int STAGE = A_BYTES + BN * PITCH;    // [A: TBM rows][W: 128 rows]
-  constexpr int LA = TBM / RPI / NW, LW = BN / RPI / NW;   // global_load_lds per lane per stage
-  static_assert(LA >= 1 && LW >= 1 && LA * NW * RPI == TBM && LW * NW * RPI == BN, "staging split");
+  constexpr int LA = TBM / RPI / NL, LW = BN / RPI / NL;   // global_load_lds per lane per stage
+  static_assert(LA >= 1 && LW >= 1 && LA * NL * RPI == TBM && LW * NL * RPI == BN, "staging split");
   constexpr int L = LA + LW;
   // bank-conflict swizzle of the 16-B slot index, applied to the global SOURCE chunk and to the fragment reads:
   // 128-B rows: slot ^= row & 7;  64-B rows: slot ^= 3 * ((row >> 2) & 1)  (both conflict-free for the 16-lane
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
                                 : (void*)((half_t*)p.C + (long)blockIdx.z * p.sC);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool is_prod = NP > 0 && wave >= NW;       // wave-uniform
+  const bool loader = NP == 0 || is_prod;
+  const int lw = NP ? wave - NW : wave;          // index among the loading waves
+  const int wm = (wave % NW) / WN, wn = wave % WN;
   // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of row-major
   // tiles (N fastest): an XCD's L2 then sees few A row-tiles and A crosses the fabric about once instead of
   // 8 times.  Bijective for any tile count.
@@ -140,13 +147,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   const half_t* w_src[LW];
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
-    const int row = (wave * LW + i) * RPI + srow;
+    const int row = ((loader ? lw : 0) * LW + i) * RPI + srow;
     const int chunk = sslot ^ swz(row);
     w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    const int row = (wave * LA + i) * RPI + srow;
+    const int row = ((loader ? lw : 0) * LA + i) * RPI + srow;
     const int chunk = sslot ^ swz(row);
     int gm = bm0 + row;
     gm = gm < p.M ? gm : p.M - 1;        // clamp: rows past M are loaded but never stored
@@ -156,9 +163,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     char* abase = smem + buf * STAGE;
     char* wbase = abase + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < LW; ++i) glds16(w_src[i] + k0, wbase + (wave * LW + i) * 1024);
+    for (int i = 0; i < LW; ++i) glds16(w_src[i] + k0, wbase + (lw * LW + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < LA; ++i) glds16(a_src[i] + k0, abase + (wave * LA + i) * 1024);
+    for (int i = 0; i < LA; ++i) glds16(a_src[i] + k0, abase + (lw * LA + i) * 1024);
   };
 
   floatx4 acc[MI][NI];
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   const int nk = p.K / KB;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) stage(s, s * KB);
+    if (s < nk && loader) stage(s, s * KB);
 
 #ifdef CSAM_GEMM_TS
   const bool ts_on = g_gemm_ts && blockIdx.x == 5 && lane == 0 && wave == 1;
@@ -204,9 +211,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
     GTS(1);
 #ifndef CSAM_GEMM_INTERLEAVE
-    if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
+    if (kt + NS - 1 < nk && loader) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
     GTS(2);
     const char* base = smem + cur * STAGE;
+    if (!is_prod)
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       const int coff = ((kk * 4 + fg) ^ sw) << 4;
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
   float* stab = (float*)(smem + TBM * 512);            // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
   if (p.st_in) {
+    if (!is_prod)
     for (int r = tid; r < TBM; r += NT) {
       const int m = min(bm0 + r, p.M - 1);
       const float2_t ms = ln_row_stats(p.st_in + (long)m * p.st_np * 2, p.st_np, p.eps);
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   // tile is staged in the (now free) operand LDS with an XOR-swizzled slot index and written / residual-added
   // as whole coalesced rows, 16 B per lane.
   const bool res_late = p.R && p.c_dt == CSAM_DT_F32 && p.r_dt == CSAM_DT_F32;   // residual added at copy-out
+  if (!is_prod)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * MI * 16 + mi * 16 + fr;     // row inside the workgroup tile
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     }
   }
   __syncthreads();
+  if (is_prod) return;
   if (p.c_dt == CSAM_DT_F32) {
 #pragma unroll
     for (int it = 0; it < TBM * 32 / NT; ++it) {
@@ -690,18 +701,28 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     return CSAM_OK;
   }
   dim3 grid((N / BN) * csam_cdiv(M, use_tall ? 192 : use_deep ? BM : mid ? 96 : small_f ? 64 : BM), 1, batch);
-#define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
+#define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_) CSAM_GEMM_LAUNCH_P(MI_, NI_, WM_, WN_, NS_, KB_, 0)
+#define CSAM_GEMM_LAUNCH_P(MI_, NI_, WM_, WN_, NS_, KB_, NP_)                                                  \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
     constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
     constexpr int SM = (SM_RING > SM_OUT + 2048 ? SM_RING : SM_OUT + 2048);  /* + [TBM][2] LayerNorm table */  \
     static csam_once_t set;                                                                                    \
-    auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
+    auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_, NP_>;                                            \
     if (csam_first_call(set))                                                                                  \
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
-    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
+    hipLaunchKernelGGL(kern, grid, dim3((WM_ * WN_ + NP_) * 64), SM, (hipStream_t)stream, p);                  \
   }
-  if (use_tall) {
+  static int prod = -1;                              // CSAM_GEMM_PROD=1: two producer waves for the 64- / 96-row tiles
+  if (prod < 0) {
+    const char* e = getenv("CSAM_GEMM_PROD");
+    prod = e ? atoi(e) : 0;
+  }
+  if (prod && mid && !use_tall && !use_deep) {
+    CSAM_GEMM_LAUNCH_P(3, 4, 2, 2, 2, 64, 4)
+  } else if (prod && small_f && !mid && !use_tall && !use_deep && variant == 0) {
+    CSAM_GEMM_LAUNCH_P(2, 4, 2, 2, 3, 64, 4)
+  } else if (use_tall) {
     CSAM_GEMM_LAUNCH(6, 4, 2, 2, 3, 64)
   } else if (use_deep) {
     CSAM_GEMM_LAUNCH(4, 4, 2, 2, 4, 64)
