@@ -173,7 +173,9 @@ def mask_to_rle_arrays(tensor, idx=None, boxes=None):
         # boxes instead of the frames
         pos, offs = hip.rle_encode(m8, idx, None if boxes is None else boxes.to(torch.int32).contiguous())
         pos = hip.to_host_numpy(pos).astype(np.int64)              # pinned staging buffer; astype copies out of it
-        first = (m8[:, 0, 0] if idx is None else m8[idx.long(), 0, 0]).cpu().numpy().astype(bool)
+        # first pixel of every mask: a strided view of the store's first column, then n bytes gathered (pinned staging buffer)
+        col0 = m8.view(m8.shape[0], -1)[:, 0]
+        first = hip.to_host_numpy(col0 if idx is None else col0.index_select(0, idx.long())).astype(bool)
         # run lengths of ALL masks in one pass (a crowded frame keeps hundreds of masks: per-mask numpy calls were the
         # tail's largest host cost): per mask the sequence [0 if the first pixel is set] 0 pos... hw, differenced
         offs = np.asarray(offs, dtype=np.int64)
