@@ -65,3 +65,22 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_fragment_order_is_the_layout_the_header_documents():
+    """hip.frag_order (plan-time permutation of the weights csam_token_block_* / csam_token_heads stream) against the index formula
+    in include/csam.h: element (n, k) of a row-major [N][K] matrix at ((n / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + n % 16) * 8
+    + k % 8 -- for one matrix and for a stack of matrices."""
+    from crowdsam_amd import hip
+    for lead, N, K in (((), 48, 96), ((3,), 32, 64)):
+        w = torch.arange(int(torch.tensor(lead + (N, K)).prod()), dtype=torch.float32).reshape(*lead, N, K).to(torch.float16)
+        f = hip.frag_order(w).reshape(*lead, -1)
+        n = torch.arange(N)[:, None].expand(N, K)
+        k = torch.arange(K)[None, :].expand(N, K)
+        pos = ((n // 16 * (K // 32) + k // 32) * 64 + (k % 32 // 8) * 16 + n % 16) * 8 + k % 8
+        assert sorted(pos.reshape(-1).tolist()) == list(range(N * K))
+        if lead:
+            for i in range(lead[0]):
+                assert torch.equal(f[i][pos.reshape(-1)], w[i].reshape(-1))
+        else:
+            assert torch.equal(f[pos.reshape(-1)], w.reshape(-1))

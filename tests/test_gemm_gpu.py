@@ -155,3 +155,31 @@ def test_gemm_ln_fold_matches_layernorm_then_gemm(cuda, M, D, N2):
     out2 = torch.empty_like(out)
     hip.gemm_f16_ln(x16, wf, out2, bias=bf, stats_in=st, colsum=cs, eps=1e-6)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(224, 256, 2048, 8), (128, 256, 5376, 12), (7, 256, 2048, 8), (1785, 256, 2048, 8)])
+def test_gemm_splitk_matches_single_pass(cuda, M, N, K, S):
+    """hip.gemm_f16_splitk (K-slices through csam_gemm_f16_batched + csam_splitk_reduce, round 4: the skinny long-K products of
+    small decoder batches): against the fp32 matmul like every GEMM here, equal to the single-pass kernel up to the reordered
+    fp32 sum, bit-repeatable, with bias + residual and with the pooling product's row scale."""
+    from crowdsam_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).half().to(cuda)
+    w = (torch.randn(N, K, generator=g) * 0.05).half().to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    stats = (torch.rand(M, 2, generator=g) + 0.5).to(cuda)
+    scratch = torch.empty(S * M * N, dtype=torch.float32, device=cuda)
+    ref = a.float() @ w.float().t()
+    scale = ref.abs().mean().item()
+    out = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    hip.gemm_f16_splitk(a, w, out, S, scratch, bias=bias, residual=res)
+    first = out.clone()
+    assert (out - (ref + bias + res)).abs().max().item() < 2e-3 * scale
+    one = torch.empty(M, N, dtype=torch.float32, device=cuda)
+    hip.gemm_f16(a, w, out=one, bias=bias, residual=res)
+    assert (out - one).abs().max().item() < 1e-4 * scale                       # fp32 reordering only
+    hip.gemm_f16_splitk(a, w, out, S, scratch, bias=bias, residual=res)
+    assert torch.equal(out, first)
+    hip.gemm_f16_splitk(a, w, out, S, scratch, bias=bias, rowstats=stats)
+    assert (out - (ref / stats[:, 1:2] + bias)).abs().max().item() < 2e-3 * scale

@@ -41,6 +41,36 @@ def test_pipelined_generate_equals_serial_small_model(cuda):
     _same(b, serial[1])
 
 
+def test_work_stream_and_caller_streams_give_the_same_results(cuda):
+    """generate() runs the frame on its own high-priority stream (CSAM_WORK_STREAM, round 4): the results must equal those on the
+    caller's stream bit for bit -- from the default stream, from a caller-side stream context, and with look-ahead."""
+    import crowdsam.model as cm
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG
+    from tests.test_pipeline_gpu import ARCH, GpuStandInDino, _config
+    m = CrowdSAM(_config(dict(PIPE_CFG)), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    frames = [synth.synthetic_crowd_frame(i, 1024, 60)[:768] for i in range(3)]
+    assert cm._WORK_STREAM
+    try:
+        cm._WORK_STREAM = False
+        np.random.seed(5)
+        plain = [m.generate(f) for f in frames]
+        cm._WORK_STREAM = True
+        np.random.seed(5)
+        own = [m.generate(f) for f in frames]
+        np.random.seed(5)
+        with torch.cuda.stream(torch.cuda.Stream(device=cuda)):
+            inside = list(m.generate_stream(frames))
+        torch.cuda.synchronize()
+    finally:
+        cm._WORK_STREAM = True
+    assert any(len(o["boxes"]) for o in plain)
+    for a, b, c in zip(plain, own, inside):
+        _same(a, b)
+        _same(a, c)
+
+
 def test_pipelined_generate_equals_serial_full_model(cuda):
     """The bench's model (ViT-L + DINOv2-L x 24, 64 x 64 dense sweep, crowded thresholds): 4 frames, pipelined == serial."""
     from crowdsam.model import CrowdSAM
