@@ -1415,7 +1415,10 @@ constexpr int US_SMEM = US_WMX + 64;
 #ifndef US_MG
 #define US_MG 2                               /* 16-token sub-tiles that share one pass over W2' */
 #endif
-__global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArgs p, int B, int prompts_per_wg) {
+// tiles_per_wg > 0 (round 4, batches that cannot give every workgroup whole prompts): the workgroup walks a RANGE of 32-token
+// tiles that may start and end inside a prompt; the per-plane maxima then go to stats by atomic max (csam_upscale_fused's
+// protocol: the launcher initialises stats first)
+__global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArgs p, int B, int prompts_per_wg, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1425,10 +1428,15 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
   constexpr int PIECE = 256 * 16;
   const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
   constexpr int TPP = 4096 / US_TOK;                 // 128 tiles per prompt
-  const int b_first = blockIdx.x * prompts_per_wg;
-  const int b_last = min(b_first + prompts_per_wg, B);
-  if (b_first >= b_last) return;
-  const int first = b_first * TPP, last = b_last * TPP;
+  int first, last;
+  if (tiles_per_wg > 0) {
+    first = blockIdx.x * tiles_per_wg;
+    last = min(first + tiles_per_wg, B * TPP);
+  } else {
+    first = blockIdx.x * prompts_per_wg * TPP;
+    last = min(blockIdx.x * prompts_per_wg + prompts_per_wg, B) * TPP;
+  }
+  if (first >= last) return;
 
   // ---- launch-resident: W1 slice in registers, W2' and the small parameter vectors in LDS
   half8_t w1[4][US_KS];
@@ -1472,7 +1480,8 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
     const char* xb = smem + cur * US_BUF;
     const int b = t / TPP, tp = t - b * TPP;
     const int i0 = tp >> 1, half = tp & 1;
-    if (tp == 0 && tid < 64) {                       // new prompt: hyper-network A fragments (hi/lo fp16 split)
+    const bool newp = tp == 0 || t == first;         // first tile of a prompt for this workgroup
+    if (newp && tid < 64) {                          // new prompt: hyper-network A fragments (hi/lo fp16 split)
       half8_t hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
       const int i = tid & 15, g = tid >> 4;
       if (i < 4) {
@@ -1491,7 +1500,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
     I2S_BARRIER();
     if (t + 1 < last) issue_x(t + 1, cur ^ 1);
 #ifndef CSAM_UP_RANKPROBE
-    if (tp == 0) {
+    if (newp) {
       hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
       hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
     }
@@ -1673,7 +1682,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
         else pmax1 = fmaxf(pmax1, mxv);
       }
     }
-    if (tp == TPP - 1 && p.stats) {                  // prompt complete: per-plane max (planes l0 = tid>>7 and l0 + 2)
+    if ((tp == TPP - 1 || t == last - 1) && p.stats) {   // prompt (or this workgroup's part of it) complete: per-plane max (planes l0 = tid>>7 and l0 + 2)
       const float m0 = csam_wave_max(pmax0), m1 = csam_wave_max(pmax1);
       if (lane == 0) {
         wmx[wave * 2] = m0;
@@ -1683,8 +1692,12 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
       if (tid < 4) {   // plane tid: waves (tid & 1) * 2 and +1 hold it, slot tid >> 1
         const int w0 = (tid & 1) * 2, sl = tid >> 1;
         const float m = fmaxf(wmx[w0 * 2 + sl], wmx[(w0 + 1) * 2 + sl]);
-        p.stats[((long)b * 4 + tid) * 2] = m;
-        p.stats[((long)b * 4 + tid) * 2 + 1] = 0.f;
+        if (tiles_per_wg > 0) {
+          atomic_max_float(p.stats + ((long)b * 4 + tid) * 2, m);
+        } else {
+          p.stats[((long)b * 4 + tid) * 2] = m;
+          p.stats[((long)b * 4 + tid) * 2 + 1] = 0.f;
+        }
       }
       pmax0 = -INFINITY;
       pmax1 = -INFINITY;
@@ -2062,8 +2075,15 @@ extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const voi
     const int per = csam_cdiv(B, n_cu);               // ONE 8-wave workgroup per CU (4 matrix + 4 VALU waves)
     hipLaunchKernelGGL(upscale_ws_kernel, dim3(csam_cdiv(B, per)), dim3(512), UW_SMEM, (hipStream_t)stream, a, B, per);
   } else {
-    const int per = csam_cdiv(B, US_WG_PER_CU * n_cu);
-    hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per);
+    if (B < US_WG_PER_CU * n_cu) {                     // fewer prompts than resident workgroups: ranges of tiles instead
+      const int tiles = B * (4096 / US_TOK), tpw = csam_cdiv(tiles, US_WG_PER_CU * n_cu);
+      if (stats_or_null)
+        hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null, B * 4);
+      hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(tiles, tpw)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, 0, tpw);
+    } else {
+      const int per = csam_cdiv(B, US_WG_PER_CU * n_cu);
+      hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per, 0);
+    }
   }
   CSAM_LAUNCH_CHECK("csam_upscale_stream");
   return CSAM_OK;

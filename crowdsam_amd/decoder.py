@@ -137,6 +137,7 @@ class DecoderPlan:
         # block + norm1 + q projection; out projection + norm2 + MLP + norm3 + k / v projections).  CSAM_TOKEN_BLOCK=0: the
         # separate GEMM / LayerNorm / attention launches
         self.token_block = os.environ.get("CSAM_TOKEN_BLOCK", "1") != "0"
+        self.up_stream_small = os.environ.get("CSAM_UP_STREAM_SMALL", "1") != "0"
         self._tb = None                              # fragment-ordered copies of the token-side weights (built on first use)
         self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
@@ -666,7 +667,9 @@ class DecoderPlan:
                                    128, 32, B, 32, 256, 4)
         masks = ws["masks"][:B]
         if self.fused:
-            up = hip.upscale_stream if (self.up_stream and B >= 256) else hip.upscale_fused
+            # the weight-stationary stream kernel; below 2 x CU-count prompts its workgroups walk ranges of tiles instead of whole
+            # prompts (round 4; CSAM_UP_STREAM_SMALL=0: the tile-per-workgroup kernel for batches < 256, as before)
+            up = hip.upscale_stream if (self.up_stream and (B >= 256 or self.up_stream_small)) else hip.upscale_fused
             up(keys_in, self.up1_w_fold if keys_plain else self.up1_w, self.up1_b_fold if keys_plain else self.up1_b,
                self.up_ln_g, self.up_ln_b, 1e-6, self.up2_w_perm, self.up2_b, ws["hyper"], masks, B, stats=ws["stats"])
         else:

@@ -306,7 +306,9 @@ int csam_upscale_fused(void* stream, const void* keys_f16, const void* W1_f16, c
                        const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
                        const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
 /* same as a persistent, weight-stationary stream: 4-wave workgroups walk whole prompts in 32-token tiles, W1 slices in
- * registers, key tiles LDS-DMA'd a tile ahead; stats column 0 (per-plane max) written once per prompt, no atomics */
+ * registers, key tiles LDS-DMA'd a tile ahead; stats column 0 (per-plane max) written once per prompt, no atomics.  With fewer
+ * prompts than resident workgroups (B < 2 x CUs) the workgroups walk RANGES of tiles instead and the maxima go to stats by atomic
+ * max after an initialising launch (csam_upscale_fused's protocol) */
 int csam_upscale_stream(void* stream, const void* keys_f16, const void* W1_f16, const float* b1,
                         const float* ln_gamma, const float* ln_beta, float eps, const void* W2_perm_f16,
                         const float* b2, const float* hyper, float* masks, float* stats_or_null, int B);
