@@ -297,7 +297,8 @@ class CrowdSAM:
             # ... the encoders' workspaces were last used by this stream (the previous prefetch) or by the main stream's
             # set_image before this point; the inactive decoder slot was last read by the frame before the current one
             side.wait_stream(main)
-            bundle = self.predictor.prefetch_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32))
+            bundle = self.predictor.prefetch_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32),
+                                                   two_streams=not early)
         state = {k: getattr(self, k) for k in self._CROP_STATE}
         for t in (state["_frame_u8"], state["_frame_f32"]):
             if torch.is_tensor(t):

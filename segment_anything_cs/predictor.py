@@ -83,7 +83,7 @@ class SamPredictor:
         if transformed_mask is not None:
             return self.model.preprocess(transformed_mask)
 
-    def _encode(self, transformed_image, original_image_size, prefetch):
+    def _encode(self, transformed_image, original_image_size, prefetch, two_streams=True):
         """SAM encoder || DINOv2 + the decoder's per-image constants for one frame -> a bundle for _adopt().
         ``prefetch``: the constants go into the decoder plan's INACTIVE slot and nothing of the predictor's current image
         is touched (the look-ahead frame of CrowdSAM's depth-2 pipeline: the current frame's prompt batches keep decoding
@@ -91,7 +91,7 @@ class SamPredictor:
         raw = transformed_image[0].to(self.device).float().contiguous()      # [3,h,w], 0..255
         if self._dtok16 is None or self._dtok16.device != raw.device:
             self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
-        if isinstance(self.dino_model, DinoV2) and not _TWO_STREAMS:
+        if isinstance(self.dino_model, DinoV2) and not (_TWO_STREAMS and two_streams):
             feat = self.model.image_encoder.forward_tokens(raw)
             self.dino_model.patch_tokens16(raw, self._dtok16)
         elif isinstance(self.dino_model, DinoV2):
@@ -126,12 +126,14 @@ class SamPredictor:
         self.is_image_set = True
 
     @torch.no_grad()
-    def prefetch_image(self, image):
+    def prefetch_image(self, image, two_streams=True):
         """Build extension (depth-2 image pipeline): encode a frame that is already on the device -- uint8 HWC tensor or the
         (uint8, fp32 CHW) pair of crowdsam.utils.resize_frame_device -- WITHOUT making it the current image.  Returns a
         bundle for adopt_prefetched(), or None when the frame needs the general set_image route (then nothing is done).
         The encoder's own output buffer is shared, so ``features`` of the current image is not meaningful afterwards; the
-        decoder reads its per-slot copies."""
+        decoder reads its per-slot copies.  ``two_streams`` False: SAM encoder, then DINOv2, on the calling stream -- beside the
+        latency chain of an EPS sweep one stream of full-chip launches disturbs it less than two (round 4: 20.7-21.3 -> 19.5-19.8
+        ms per frame in the shipped configuration; the dense sweep prefers two: 36.6 vs 38.1 ms)."""
         f32 = None
         if isinstance(image, tuple):
             image, f32 = image
@@ -150,7 +152,7 @@ class SamPredictor:
                                                 pil_bilinear_tables_device(h, th, dev))
         else:
             return None
-        return self._encode(f32[None], (h, w), prefetch=True)
+        return self._encode(f32[None], (h, w), prefetch=True, two_streams=two_streams)
 
     def adopt_prefetched(self, bundle):
         self.reset_image()
