@@ -42,6 +42,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
 _WORK_STREAM = os.environ.get("CSAM_WORK_STREAM", "1") != "0"
+_PREFETCH_EARLY = os.environ.get("CSAM_PREFETCH_EARLY", "0") == "1"     # developer A/B: look-ahead before the dense sweep too
 _WINDOWED_REGIONS = os.environ.get("CSAM_CC_WINDOWED", "1") != "0"      # small-region clean-up inside the masks' boxes
 
 
@@ -334,7 +335,7 @@ class CrowdSAM:
         t0 = self._tick("sample_prompts", t0)
         store = self._result_store(*self.predictor.original_size)
         store["counter"].zero_()
-        early = self._next_image is not None and (prune or self.points_per_batch < 256)
+        early = self._next_image is not None and (prune or self.points_per_batch < 256 or _PREFETCH_EARLY)
         if early:
             # EPS sweep: small prompt batches with the GPU mostly idle -> the next frame's encoders run beside the whole sweep
             self._prefetch(self._next_image, early=True)
