@@ -68,8 +68,16 @@ def encoder_only(args, rank, world, dev, sam_sd):
     x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
     raw = (x[0] * sam.pixel_std.cpu() + sam.pixel_mean.cpu()).to(dev).contiguous()      # forward_tokens re-normalises
     enc = sam.image_encoder
+    NB = max(1, args.batch) if args.batch_given else 1
+    if NB > 1:
+        # B images per pass (image_encoder.py:106-116 with B > 1): B DIFFERENT random tensors, one [B * 4096, D] token matrix
+        raws = [raw] + [(torch.from_numpy(np.random.RandomState(b).standard_normal((3, 1024, 1024)).astype(np.float32))
+                         * sam.pixel_std.cpu() + sam.pixel_mean.cpu()).to(dev).contiguous() for b in range(1, NB)]
+        fwd = lambda: enc.plan().forward_batch_static(raws)
+    else:
+        fwd = lambda: enc.forward_tokens(raw)
     for _ in range(max(args.warmup, 1)):
-        enc.forward_tokens(raw)
+        fwd()
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -78,11 +86,11 @@ def encoder_only(args, rank, world, dev, sam_sd):
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
-        enc.forward_tokens(raw)
+        fwd()
     e1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / args.steps
+    dev_ms = e0.elapsed_time(e1) / (args.steps * NB)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -94,24 +102,33 @@ def encoder_only(args, rank, world, dev, sam_sd):
     timer = hip.KernelTimer(names)
     hip.set_timer(timer)
     for _ in range(min(args.steps, 5)):
-        enc.plan().forward(raw)
+        if NB > 1:
+            pl = enc.plan()
+            vs = pl.load_images(raws)
+            pl.embed(vs, NB)
+            pl.run_blocks(0, pl.depth, NB)
+            pl.neck(pl.ws["feat"][:NB], NB)
+        else:
+            enc.plan().forward(raw)
     torch.cuda.synchronize()
     hip.set_timer(None)
-    n_rep = min(args.steps, 5)
+    n_rep = min(args.steps, 5) * NB
     fam = {k: {"us_per_image": 1e3 * v["ms"] / n_rep, "launches_per_image": v["calls"] // n_rep,
                **({"tflops": v["work"] / (v["ms"] * 1e-3) / 1e12} if v["work"] > 0 else {})}
            for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0:
-        value = args.steps * world / elapsed
+        value = args.steps * NB * world / elapsed
         gf = REF_GFLOP.get(args.arch, enc.plan().flops() / 1e9)
         ach = gf * 1e9 / (dev_ms * 1e-3) / 1e12
         print(json.dumps({
             "metric": "images/sec (SAM %s image encoder only, 1024^2 input)" % args.arch, "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SAM %s encoder-only forward (patch embed, %d blocks, neck) on a random "
-                                   "normalised 1024x1024 tensor, seeded weights, hipGraph replay" % (args.arch, enc.depth),
-                       "device_ms_per_image": dev_ms, "kernel_families": fam},
+            "config": {"workload": "BASELINE configs[1]: SAM %s encoder-only forward (patch embed, %d blocks, neck) on random "
+                                   "normalised 1024x1024 tensors, seeded weights, hipGraph replay; a step is ONE pass over %d "
+                                   "image(s) -- one [%d x 4096, D] token matrix through every projection"
+                                   % (args.arch, enc.depth, NB, NB),
+                       "images_per_pass": NB, "device_ms_per_image": dev_ms, "kernel_families": fam},
             "roofline": {"bound": "mfma", "kernel": "whole encoder (GEMMs + windowed / global attention)", "achieved": ach,
                          "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
                          "note": "%.1f GFLOP per image (FlopCounter on the reference module: every matmul incl. pad tokens; the "
@@ -225,10 +242,15 @@ def main():
                     help="launcher self-test (tests/test_bench_launcher_cpu.py): gloo ranks, a step is a host no-op")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial", action="store_true",
-                    help="generate() without the one-frame look-ahead (A/B of the depth-2 pipeline)")
+                    help="generate() without any look-ahead (A/B of the pipelined loops)")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="frames per image-batched encoder pass of the look-ahead (CrowdSAM.generate_stream(batch=B)); 1 = the "
+                         "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  With --encoder-only: images "
+                         "per encoder pass")
     ap.add_argument("--no-cpu-e2e", action="store_true",
                     help="skip the measured end-to-end oracle image (64 prompts, ~1.5 min of host time) of the cpu_baseline leg")
     args = ap.parse_args()
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way
@@ -309,35 +331,50 @@ def main():
             model.pred_iou_thresh = float(cut.item())
             crowd_how = "calibrated on rank 0's warm-up frame, broadcast to all ranks"
 
+    B_AHEAD = max(1, args.batch)
+    if args.serial:
+        loop = "serial: generate(frame_i), no look-ahead"
+    elif B_AHEAD == 1:
+        loop = "depth-2 pipeline: generate(frame_i, next_image=frame_i+1), batch-of-one encoders beside the previous tail"
+    else:
+        loop = ("image-batched look-ahead: generate_stream(frames, batch=%d) -- SAM encoder + DINOv2 of the NEXT group of %d frames "
+                "as one pass each, a quarter-pass queued beside each frame's tail; the first group is encoded cold inside "
+                "the timed region" % (B_AHEAD, B_AHEAD))
+
+    def frame_stream(idx):
+        """The per-image loop under test over frames[idx]: every frame of the timed region is encoded, decoded and
+        post-processed INSIDE it (the first group starts cold, the last frames have no successor to overlap)."""
+        fs = [frames[i] for i in idx]
+        if args.serial:
+            return (model.generate(f) for f in fs)
+        return model.generate_stream(fs, batch=B_AHEAD)
+
     def timed_leg(collect_rows):
         step_trace = [] if os.environ.get("CSAM_BENCH_TRACE") else None
         kept = pre = 0
         rws = [np.zeros((0, 6), np.float32)]
+        timed = list(range(args.warmup, args.warmup + args.steps))
         if not args.serial:
-            # one-time setup of the depth-2 pipeline, outside every timed region: the decoder keeps per-image constants in
-            # two slots, each with its own captured hipGraphs -- this pair of calls captures the second slot's
-            model.generate(frames[0], next_image=frames[0])
-            model.generate(frames[0])
+            # one-time setup of the pipelined loop, outside every timed region: the decoder keeps per-image constants in
+            # two slots, each with its own captured hipGraphs, and every chunk of the image-batched encoder passes is a
+            # hipGraph keyed by (group size, chunk, buffer set) -- a rehearsal over as many frames captures them all
+            for _ in frame_stream([0] * args.steps):
+                pass
         for i in range(args.warmup):
             model.generate(frames[i])            # no look-ahead: nothing of a timed frame may run outside the timed region
         barrier()
         t0 = time.perf_counter()
-        last = args.warmup + args.steps - 1
-        for i in range(args.warmup, args.warmup + args.steps):
-            # depth-2 pipeline of the per-image loop: frame i+1's upload + encoders are queued beside
-            # frame i's tail; the first timed frame starts cold and the last one has no successor, so the region holds
-            # exactly K whole images
-            out = model.generate(frames[i], next_image=frames[i + 1] if (i < last and not args.serial) else None)
+        for k, out in enumerate(frame_stream(timed)):
             if step_trace is not None:
                 step_trace.append(time.perf_counter() - t0)
                 if getattr(model, "timings", None):    # CSAM_TIMING=1: device-synchronised stage times of this step
-                    print("step %d stages: " % (i - args.warmup) + " ".join("%s %.1f" % kv for kv in model.timings.items())
+                    print("step %d stages: " % k + " ".join("%s %.1f" % kv for kv in model.timings.items())
                           + " | kept %d" % len(out["boxes"]), file=sys.stderr, flush=True)
                     model.timings = {}
             kept += len(out["boxes"])
             pre += model.last_candidates
             if collect_rows:
-                rws.append(detections_to_rows(rank * args.steps + i - args.warmup, out["boxes"], out["scores"]))
+                rws.append(detections_to_rows(rank * args.steps + k, out["boxes"], out["scores"]))
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         barrier()
@@ -391,6 +428,21 @@ def main():
                      "ms_per_step": 1e3 * tc / args.steps, "images_per_sec": args.steps / tc,
                      "kept_masks_per_image": kept_c / args.steps}
         model.box_nms_thresh, model.crop_nms_thresh, model.pred_iou_thresh = keep_crowd
+    # serial leg (rank 0): the same frames, same thresholds, one generate() per frame with no look-ahead -- the loop rounds 1-3
+    # reported as the headline, so `value` can be compared across rounds from this line alone
+    serial_leg = None
+    if rank == 0 and not args.serial:
+        model.generate(frames[0])
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        kept_s = 0
+        for i in range(args.warmup, args.warmup + args.steps):
+            kept_s += len(model.generate(frames[i])["boxes"])
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - ts
+        serial_leg = {"what": "the timed frames again through generate(frame) one at a time, no look-ahead (rounds 1-3's loop)",
+                      "ms_per_step": 1e3 * ts / args.steps, "images_per_sec": args.steps / ts,
+                      "kept_masks_per_image": kept_s / args.steps}
     # third leg (rank 0): the tail alone on PERSON-SHAPED masks.  The random-weight masks of the timed
     # frames are noise-like blobs (worst case for connected components: every 64 x 64 tile is mixed); a real crowd frame keeps
     # compact person silhouettes.  The same number of kept masks as the timed frames, drawn as filled ellipses with a few
@@ -462,8 +514,12 @@ def main():
                        "csam_pool_adjoint_mfma", "csam_mask_post", "csam_mask_post_scored", "csam_mask_write"]
         timer = hip.KernelTimer(GEMM_NAMES + SWEEP_NAMES)
         hip.set_timer(timer)
-        for i in range(args.warmup, args.warmup + args.steps):
-            model.generate(frames[i])
+        # the SAME loop as the timed region (image-batched encoder passes when --batch > 1), eager, with the look-ahead work
+        # queued on the frame's own stream so that every launch is timed alone
+        model.inline_ahead = True
+        for _ in frame_stream(list(range(args.warmup, args.warmup + args.steps))):
+            pass
+        model.inline_ahead = False
         torch.cuda.synchronize()
         hip.set_timer(None)
         _pred._TWO_STREAMS = two
@@ -497,6 +553,10 @@ def main():
                                               "connected components, RLE and COCO string packing"
                                               % (model.box_nms_thresh, model.pred_iou_thresh, crowd_how, args.crowd_keep,
                                                  n_kept / args.steps))
+        res["config"]["loop"] = loop
+        res["config"]["encoder_batch"] = 0 if args.serial else B_AHEAD
+        if serial_leg is not None:
+            res["config"]["serial_leg"] = serial_leg
         if collapsed is not None:
             res["config"]["nms_collapsed_leg"] = collapsed
         if tail_person is not None:
@@ -533,8 +593,8 @@ def main():
                                     "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
                                     "gemm_ms_per_step": ms / args.steps,
                                     "note": ("algorithmic 2*M*N*K of every GEMM launch / HIP-event time on the launch stream, "
-                                             "measured on an instrumented repeat of the K timed steps (graph replay and the "
-                                             "DINOv2 side stream disabled)")}
+                                             "measured on an instrumented repeat of the K timed steps in the same loop (graph replay "
+                                             "off, look-ahead work on the frame's own stream so that no launch shares the chip)")}
             # the dominant single kernel of the timed region (rocprofv3 --stats: profiles/r02_bench_kernel_stats.txt):
             # the persistent upscaler.  Algorithmic bytes per launch = prompts x (2 MB fp16 key state read + 1 MB fp32
             # low-res logits written), SURVEY.md 8d passes R4 + the logits term.

@@ -28,7 +28,7 @@ import crowdsam.utils as utils
 from crowdsam_amd import hip
 from crowdsam_amd.dino import DinoV2
 from segment_anything_cs.utils.amg import (MaskData, coco_encode_rle, coco_encode_rles, generate_crop_boxes,
-                                           mask_to_rle_arrays)
+                                           mask_to_coco_rles, mask_to_rle_arrays)
 
 
 def box_area(b):
@@ -42,7 +42,6 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
 _WORK_STREAM = os.environ.get("CSAM_WORK_STREAM", "1") != "0"
-_PREFETCH_EARLY = os.environ.get("CSAM_PREFETCH_EARLY", "0") == "1"     # developer A/B: look-ahead before the dense sweep too
 _WINDOWED_REGIONS = os.environ.get("CSAM_CC_WINDOWED", "1") != "0"      # small-region clean-up inside the masks' boxes
 
 
@@ -116,10 +115,17 @@ class CrowdSAM:
             raise NotImplementedError("test.max_size > 4096 is not supported (csam_rle_count scans rows of <= 4096 pixels)")
         if self.apply_box_offsets:
             raise NotImplementedError("apply_box_offsets is off in the shipped config (the decoder has no offset head)")
+        # build extension: frames per image-batched encoder pass of generate_stream (1 = the depth-2 pipeline of round 4)
+        self.encoder_batch = int(t.get("encoder_batch", 4))
         self.timings = {}
         self.last_candidates = 0
         self._next_image = None      # depth-2 pipeline (generate(next_image=...)): see _prefetch
         self._prefetched = None
+        self.inline_ahead = False    # look-ahead work on the frame's own stream instead of the side stream (no overlap)
+        self._look = None            # image-batched look-ahead (generate_stream(batch=B)): see _lookahead_step
+        self._cur_group = None
+        self._next_group = None
+        self._group_parity = 0
         self._pf_stream = None
         self._hi_stream = None
         self._work_stream = None
@@ -189,23 +195,60 @@ class CrowdSAM:
         finally:
             self._next_image = None
 
-    def generate_stream(self, images):
-        """Iterator over generate(image) for an iterable of frames with one frame of look-ahead (depth-2 pipeline)."""
+    def generate_stream(self, images, batch=None):
+        """Iterator over generate(image) for an iterable of frames, pipelined (build extension; the per-image loop of
+        tools/test.py:62-82).
+
+        ``batch`` (default ``test.encoder_batch`` = 4) frames ahead are encoded TOGETHER: SAM's encoder and DINOv2 run one
+        image-batched pass per group of B frames ([B * 4096, D] / [B * 5330, D] token matrices: their GEMMs leave the
+        launch-shaped batch-of-one regime), and that pass is cut into len(group) chunks, one queued beside the tail of each
+        frame of the group before it.  Every frame's features are bit-identical to a pass of its own
+        (tests/test_encoder_batch_gpu.py), no random number is drawn before sample_prompts, so results equal serial
+        generate() calls (tests/test_pipelined_gpu.py).  The first group is encoded cold.  batch <= 1, multi-crop configs and
+        non-CUDA devices: the depth-2 pipeline of generate(image, next_image=...)."""
+        B = self.encoder_batch if batch is None else int(batch)
         it = iter(images)
-        try:
-            cur = next(it)
-        except StopIteration:
+        if B <= 1 or self.crop_n_layers > 0 or self.device.type != "cuda":
+            try:
+                cur = next(it)
+            except StopIteration:
+                return
+            for nxt in it:
+                yield self.generate(cur, next_image=nxt)
+                cur = nxt
+            yield self.generate(cur)
             return
-        for nxt in it:
-            yield self.generate(cur, next_image=nxt)
-            cur = nxt
-        yield self.generate(cur)
+        import itertools
+        cur = list(itertools.islice(it, B))
+        first = True
+        self._cur_group = self._next_group = None
+        self._group_parity = 0        # the groups' buffer sets alternate from the same start: same hipGraph keys every stream
+        try:
+            while cur:
+                nxt = list(itertools.islice(it, B))
+                for j, img in enumerate(cur):
+                    self._look = dict(cur=cur, j=j, nxt=nxt, cold=first and j == 0)
+                    try:
+                        out = self.generate(img)
+                    finally:
+                        self._look = None
+                    yield out
+                first = False
+                cur = nxt
+        finally:
+            self._cur_group = self._next_group = None
+            self._look = None
 
     def _generate_masks(self, image):
         img_size = np.array(image).shape[:2]
         crop_boxes, _ = generate_crop_boxes(img_size, self.crop_n_layers, self.crop_overlap_ratio)
         data = MaskData()
-        for crop_box in crop_boxes:
+        crops = self._encode_crops(image, crop_boxes) if len(crop_boxes) > 1 else None
+        for i, crop_box in enumerate(crop_boxes):
+            if crops is not None:
+                # the crop's decoder constants go into the inactive slot right before its sweep (the slots alternate)
+                self._prefetched = dict(src=image, crop_box=list(crop_box), state=crops["states"][i],
+                                        bundle=self.predictor.group_bundle(crops["group"], i))
             crop_data = self._process_crop(image, crop_box)
             if crop_data is not None:
                 data.cat(crop_data)
@@ -277,45 +320,128 @@ class CrowdSAM:
 
     _CROP_STATE = ("orig_image", "_frame_u8", "_frame_f32", "_image_np", "image_hw", "downscale")
 
+    def _upload_frames(self, frames, boxes=None):
+        """crop_image (the one H2D + device resize) of several frames / crops on the current stream -> their crop states,
+        with the current frame's state put back afterwards (its tail still needs ``downscale`` & co)."""
+        saved = {k: getattr(self, k, None) for k in self._CROP_STATE}
+        states = []
+        for i, f in enumerate(frames):
+            arr = f if isinstance(f, np.ndarray) else np.array(f, dtype=np.uint8)
+            h, w = arr.shape[:2]
+            self.crop_image(arr, [0, 0, w, h] if boxes is None else boxes[i])
+            states.append({k: getattr(self, k) for k in self._CROP_STATE})
+        for k, v in saved.items():
+            setattr(self, k, v)
+        return states
+
+    @staticmethod
+    def _device_frame(state):
+        return state["_frame_u8"] if state["_frame_f32"] is None else (state["_frame_u8"], state["_frame_f32"])
+
+    def _group_upload(self, frames, boxes=None, states=None):
+        """Upload a group of frames (unless ``states`` holds their crop states already) and hand them to the predictor's
+        image-batched encoder pass (SamPredictor.group_begin: copies into the encoders' static input buffers, so the stream
+        must be ordered behind the previous pass).  None when a frame needs the general set_image route."""
+        if states is None:
+            states = self._upload_frames(frames, boxes)
+        self._group_parity ^= 1
+        g = self.predictor.group_begin([self._device_frame(st) for st in states], bufset=self._group_parity)
+        if g is None:
+            return None
+        return dict(group=g, states=states, frames=list(frames))
+
+    def _encode_crops(self, image, crop_boxes):
+        """Multi-crop mode (crowdsam/model.py:151-178: every crop is resized to max_size and encoded): the crops of one image
+        as ONE image-batched pass of both backbones instead of len(crop_boxes) passes of one."""
+        if self.device.type != "cuda":
+            return None
+        arr = image if isinstance(image, np.ndarray) else np.array(image, dtype=np.uint8)
+        if self._pf_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._pf_stream)
+        rec = self._group_upload([arr] * len(crop_boxes), boxes=[list(b) for b in crop_boxes])
+        if rec is None:
+            return None
+        self.predictor.group_chunk(rec["group"], 0, 1)
+        return rec
+
+    def _mark_cross_stream(self, states, main):
+        for st in states:
+            for t in (st["_frame_u8"], st["_frame_f32"]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)           # allocated on the side stream, read on the main one later
+
+    def _lookahead_step(self, look):
+        """Image-batched look-ahead, called once per frame where _prefetch would be (EPS sweeps: before the sweep is queued;
+        dense sweeps: after): on the side stream, (1) at the first frame of a group the NEXT group's frames go up and into the
+        encoders' input buffers, (2) chunk j of len(group) of the next group's encoder passes, (3) the decoder constants of the
+        frame the caller processes next (frame j + 1 of this group, or frame 0 of the next one -- its pass has just ended) into
+        the decoder plan's inactive slot."""
+        main = torch.cuda.current_stream()
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+        side = main if self.inline_ahead else self._pf_stream      # inline_ahead: measurement aid (bench.py's per-launch timing leg)
+        cur, j, nxt = look["cur"], look["j"], look["nxt"]
+        with torch.cuda.stream(side):
+            states = None
+            if j == 0 and nxt:
+                states = self._upload_frames(nxt)                   # fresh tensors only: may start before the sweep ends
+                self._mark_cross_stream(states, main)
+            side.wait_stream(main)
+            if states is not None:
+                self._next_group = self._group_upload(nxt, states=states)
+            if self._next_group is not None:
+                self.predictor.group_chunk(self._next_group["group"], j, len(cur))
+            rec, b = (self._cur_group, j + 1) if j + 1 < len(cur) else (self._next_group, 0)
+            if rec is not None:
+                self._prefetched = dict(src=rec["frames"][b], crop_box=None, state=rec["states"][b],
+                                        bundle=self.predictor.group_bundle(rec["group"], b))
+        if j + 1 == len(cur):
+            self._cur_group, self._next_group = self._next_group, None
+
+    def _run_ahead(self, look, early):
+        if look is not None:
+            self._lookahead_step(look)
+        elif self._next_image is not None:
+            self._prefetch(self._next_image, early=early)
+        self._next_image = None
+
     def _prefetch(self, image, early):
         """Depth-2 pipeline: upload + resize + SAM encoder || DINOv2 + the decoder's per-image constants of the NEXT frame on
         a side stream, into the decoder plan's inactive slot (SamPredictor.prefetch_image), without touching anything the
         current frame still reads.  ``early`` (EPS sweeps: 16 small, latency-bound prompt batches that leave the GPU mostly
         idle): called BEFORE the sweep is queued, so the encoders run beside the whole sweep; otherwise (dense sweep: the
         persistent decoder kernels own every CU) AFTER the sweep is queued, beside the tail only.  The crop state of the
-        current frame is put back afterwards: its tail still needs ``downscale`` & co."""
+        current frame is put back afterwards: its tail still needs ``downscale`` & co.
+        The record remembers the caller's OBJECT (``src``): the next generate() adopts it only for that very object, which
+        therefore must not be mutated in between (a PIL image is converted once, here)."""
         main = torch.cuda.current_stream()
         if self._pf_stream is None:
             self._pf_stream = torch.cuda.Stream(device=self.device)
-        side = self._pf_stream
-        if not isinstance(image, np.ndarray):
-            image = np.array(image, dtype=np.uint8)
-        h, w = image.shape[:2]
-        saved = {k: getattr(self, k) for k in self._CROP_STATE}
+        side = main if self.inline_ahead else self._pf_stream
         with torch.cuda.stream(side):
             # the one H2D of the frame and its resize write fresh tensors only: they go up first ...
-            self.crop_image(image, [0, 0, w, h])
+            state = self._upload_frames([image])[0]
             # ... the encoders' workspaces were last used by this stream (the previous prefetch) or by the main stream's
             # set_image before this point; the inactive decoder slot was last read by the frame before the current one
             side.wait_stream(main)
-            bundle = self.predictor.prefetch_image(self._frame_u8 if self._frame_f32 is None else (self._frame_u8, self._frame_f32),
-                                                   two_streams=not early)
-        state = {k: getattr(self, k) for k in self._CROP_STATE}
-        for t in (state["_frame_u8"], state["_frame_f32"]):
-            if torch.is_tensor(t):
-                t.record_stream(main)           # allocated on the side stream, read on the main one later
-        self._prefetched = None if bundle is None else dict(shape=image.shape, crop_box=[0, 0, w, h], state=state, bundle=bundle)
-        for k, v in saved.items():
-            setattr(self, k, v)
+            bundle = self.predictor.prefetch_image(self._device_frame(state), two_streams=not early)
+        self._mark_cross_stream([state], main)
+        self._prefetched = None if bundle is None else dict(src=image, crop_box=None, state=state, bundle=bundle)
 
     def _process_crop(self, image, crop_box):
         t0 = time.perf_counter()
         pf, self._prefetched = self._prefetched, None
         if self._pf_stream is not None:
             torch.cuda.current_stream().wait_stream(self._pf_stream)     # a prefetch (used or not) owns the shared buffers
-        img_np = image if isinstance(image, np.ndarray) else None
-        if (pf is not None and img_np is not None and pf["crop_box"] == list(crop_box) and pf["shape"] == img_np.shape
-                and pf["state"]["orig_image"] is img_np):
+        look = self._look
+        if look is not None and look["cold"] and pf is None:
+            # first frame of a stream: its whole group is encoded now, in one image-batched pass (nothing to overlap it with)
+            self._cur_group = self._group_upload(look["cur"])
+            if self._cur_group is not None:
+                self.predictor.group_chunk(self._cur_group["group"], 0, 1)
+                pf = dict(src=image, crop_box=None, state=self._cur_group["states"][0],
+                          bundle=self.predictor.group_bundle(self._cur_group["group"], 0))
+        if pf is not None and pf["src"] is image and (pf["crop_box"] is None or pf["crop_box"] == list(crop_box)):
             for k, v in pf["state"].items():                             # the frame was prefetched: adopt its state
                 setattr(self, k, v)
             self.predictor.adopt_prefetched(pf["bundle"])
@@ -335,11 +461,11 @@ class CrowdSAM:
         t0 = self._tick("sample_prompts", t0)
         store = self._result_store(*self.predictor.original_size)
         store["counter"].zero_()
-        early = self._next_image is not None and (prune or self.points_per_batch < 256 or _PREFETCH_EARLY)
+        ahead = self._next_image is not None or look is not None
+        early = ahead and (prune or self.points_per_batch < 256)
         if early:
             # EPS sweep: small prompt batches with the GPU mostly idle -> the next frame's encoders run beside the whole sweep
-            self._prefetch(self._next_image, early=True)
-            self._next_image = None
+            self._run_ahead(look, early=True)
 
         # :230 truncation (already done, on the device, for the device-resident sampler)
         points = points_for_image if dev_sampler else points_for_image.astype("int")
@@ -374,75 +500,76 @@ class CrowdSAM:
             self._hi_stream.wait_stream(torch.cuda.current_stream())
             main_stream = torch.cuda.current_stream()
             sweep_ctx.enter_context(torch.cuda.stream(self._hi_stream))
-        if dev_sampler and len(points) > 0:
-            # Device-resident sampler (csam_eps_select / csam_occupancy_prune): the list and one alive flag per point stay
-            # on the GPU; a round takes the first batch_size alive points in list order -- the reference's
-            # points[:batch_size] -- and the pruning clears flags, so the sweep is a queue of kernels without a host round
-            # trip per batch.  The host does not see len(points): it runs the rounds count < max_prompts allows (a round
-            # whose list has run dry has zero valid slots and leaves no trace) and looks at the device's alive count every
-            # 4th round to stop early.  The reference's last round shrinks to the points that are left; here it keeps its
-            # width and reports how many slots are real (n_valid).
-            P = len(points)
-            all_pts_dev = points.contiguous()
-            alive_dev = torch.ones(P, dtype=torch.uint8, device=dev)
-            B = min(batch_size, P)
-            pts_b = torch.empty(B, 2, dtype=torch.int32, device=dev)
-            coords_b = torch.empty(B, 2, dtype=torch.float32, device=dev)
-            counts = torch.zeros(2, dtype=torch.int32, device=dev)
-            old_h, old_w = self.predictor.original_size
-            new_h, new_w = self.predictor.transform.get_preprocess_shape(old_h, old_w, self.predictor.transform.target_length)
-            max_rounds = -(-P // B)
-            while count < self.max_prompts and n_batches < max_rounds:
-                tb = time.perf_counter()
-                hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
-                if self.eps_trace is not None:          # debugging / parity aid: the prompts of every round (async copies)
-                    self.eps_trace.append((pts_b.clone(), counts[:1].clone()))
-                bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
-                                         device_batch=(pts_b, coords_b, counts[:1]))
-                if prune:
-                    hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
-                count += B
-                n_batches += 1
-                self._tick("eps.batch", tb)
-                if prune and n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
-                    # the alive flags AFTER this round's pruning (counts[1] is the selection's view, taken before it: a
-                    # prune that empties the list would cost up to four more full-width empty rounds)
-                    if int(alive_dev.count_nonzero().item()) == 0:
-                        break
-        else:
-            all_pts_dev = None
-            alive = np.arange(len(points))               # indices of the points still in play, in shuffled order
-            while len(alive) > 0 and count < self.max_prompts:
-                batch_size = min(len(alive), batch_size)
-                sel_idx, alive = alive[:batch_size], alive[batch_size:]
-                tb = time.perf_counter()
-                if self.eps_trace is not None:
-                    self.eps_trace.append((points[sel_idx].copy(), len(sel_idx)))
-                bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
-                tb = self._tick("eps.batch", tb)
-                if prune and len(alive) > 0:
-                    if all_pts_dev is None:
-                        all_pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
-                        occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
-                        tb = self._tick("eps.upload_points", tb)
-                    # occupancy of EVERY point under this batch's masks (the mask is replaced per batch, :246); only the
-                    # flags of the live points are looked at -- same pruning as points[~occupy_mask[y, x]] (:238-239)
-                    hip.occupancy_lookup(all_pts_dev, store["masks"], bd["occ"], batch_size, H, W, occupy_bits,
-                                         slot=bd["slot"])
-                    occ = occupy_bits.cpu().numpy().astype(bool)                  # the per-batch sync
-                    alive = alive[~occ[alive]]
-                    self._tick("eps.prune", tb)
-                count += batch_size
-                n_batches += 1
-        sweep_ctx.close()
-        if early_hi:
-            main_stream.wait_stream(self._hi_stream)
+        try:           # the side-stream state is restored even when a batch raises (CSAM error, OOM): ADVICE r4
+            if dev_sampler and len(points) > 0:
+                # Device-resident sampler (csam_eps_select / csam_occupancy_prune): the list and one alive flag per point stay
+                # on the GPU; a round takes the first batch_size alive points in list order -- the reference's
+                # points[:batch_size] -- and the pruning clears flags, so the sweep is a queue of kernels without a host round
+                # trip per batch.  The host does not see len(points): it runs the rounds count < max_prompts allows (a round
+                # whose list has run dry has zero valid slots and leaves no trace) and looks at the device's alive count every
+                # 4th round to stop early.  The reference's last round shrinks to the points that are left; here it keeps its
+                # width and reports how many slots are real (n_valid).
+                P = len(points)
+                all_pts_dev = points.contiguous()
+                alive_dev = torch.ones(P, dtype=torch.uint8, device=dev)
+                B = min(batch_size, P)
+                pts_b = torch.empty(B, 2, dtype=torch.int32, device=dev)
+                coords_b = torch.empty(B, 2, dtype=torch.float32, device=dev)
+                counts = torch.zeros(2, dtype=torch.int32, device=dev)
+                old_h, old_w = self.predictor.original_size
+                new_h, new_w = self.predictor.transform.get_preprocess_shape(old_h, old_w, self.predictor.transform.target_length)
+                max_rounds = -(-P // B)
+                while count < self.max_prompts and n_batches < max_rounds:
+                    tb = time.perf_counter()
+                    hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
+                    if self.eps_trace is not None:          # debugging / parity aid: the prompts of every round (async copies)
+                        self.eps_trace.append((pts_b.clone(), counts[:1].clone()))
+                    bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
+                                             device_batch=(pts_b, coords_b, counts[:1]))
+                    if prune:
+                        hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
+                    count += B
+                    n_batches += 1
+                    self._tick("eps.batch", tb)
+                    if prune and n_batches % 4 == 0 and count < self.max_prompts and n_batches < max_rounds:
+                        # the alive flags AFTER this round's pruning (counts[1] is the selection's view, taken before it: a
+                        # prune that empties the list would cost up to four more full-width empty rounds)
+                        if int(alive_dev.count_nonzero().item()) == 0:
+                            break
+            else:
+                all_pts_dev = None
+                alive = np.arange(len(points))               # indices of the points still in play, in shuffled order
+                while len(alive) > 0 and count < self.max_prompts:
+                    batch_size = min(len(alive), batch_size)
+                    sel_idx, alive = alive[:batch_size], alive[batch_size:]
+                    tb = time.perf_counter()
+                    if self.eps_trace is not None:
+                        self.eps_trace.append((points[sel_idx].copy(), len(sel_idx)))
+                    bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
+                    tb = self._tick("eps.batch", tb)
+                    if prune and len(alive) > 0:
+                        if all_pts_dev is None:
+                            all_pts_dev = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.int32).to(dev)
+                            occupy_bits = torch.empty(len(points), dtype=torch.uint8, device=dev)
+                            tb = self._tick("eps.upload_points", tb)
+                        # occupancy of EVERY point under this batch's masks (the mask is replaced per batch, :246); only the
+                        # flags of the live points are looked at -- same pruning as points[~occupy_mask[y, x]] (:238-239)
+                        hip.occupancy_lookup(all_pts_dev, store["masks"], bd["occ"], batch_size, H, W, occupy_bits,
+                                             slot=bd["slot"])
+                        occ = occupy_bits.cpu().numpy().astype(bool)                  # the per-batch sync
+                        alive = alive[~occ[alive]]
+                        self._tick("eps.prune", tb)
+                    count += batch_size
+                    n_batches += 1
+        finally:
+            sweep_ctx.close()
+            if early_hi:
+                main_stream.wait_stream(self._hi_stream)
         self.predictor.reset_image()
-        if self._next_image is not None:
+        if ahead and not early:
             # dense sweep: it is queued and nothing below reads the predictor -- the next frame's encoders start now, beside
             # this frame's tail
-            self._prefetch(self._next_image, early=False)
-            self._next_image = None
+            self._run_ahead(look, early=False)
         t0 = self._tick("eps_sweep", t0)
         if n_batches == 0:
             return None
@@ -480,8 +607,8 @@ class CrowdSAM:
             data["scores"] = data["iou_preds"]
         # run lengths -> C string packer; the passes read the masks' boxes (exact for the final masks: the statistics pass's for
         # untouched masks, the clean-up's for edited ones), not the frames
-        data["rles"] = mask_to_rle_arrays(mstore, idx=data["mask_slots"].contiguous(),
-                                          boxes=data["boxes"] if _WINDOWED_REGIONS else None)
+        data["rles"] = mask_to_coco_rles(mstore, idx=data["mask_slots"].contiguous(),
+                                         boxes=data["boxes"] if _WINDOWED_REGIONS else None)
         t0 = self._tick("rle", t0)
         data["rles_info"] = [crop_box, [orig_h, orig_w]]
         del data["mask_slots"]

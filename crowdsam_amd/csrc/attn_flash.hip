@@ -19,12 +19,6 @@
 // scalar per lane per tile) - reference: one v_add per accumulator register, zero extra MFMA/LDS work.
 #include "csam_common.h"
 
-#ifdef FLASH_DBG_DUMP
-__device__ float* g_flash_dbg = nullptr;     // [wg][tid][48]: s_init rt=1 (16), scaled twr rt=1 (16), reference twr*bmul + c0 (16)
-extern "C" int csam_dbg_set_flash(void* p) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_flash_dbg), &p, sizeof(p));
-}
-#endif
 namespace {
 
 constexpr int KT = 64;                 // keys per tile
@@ -42,11 +36,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // V^T per head: vt[h][d][t] = qkv[t][v_off + h*64 + d], t < T (columns T..Tpad-1 stay zero).
 // A 64x64 tile goes through LDS so that both the read (128 B per token) and the write (128 B per dim row)
 // are coalesced.  ~20 MB of traffic per DINOv2 block: a few microseconds.
-__global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restrict__ qkv, long ld, int v_off,
-                                                          half_t* __restrict__ vt, int T, int Tpad) {
+__global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* qkv, long ld, int v_off, half_t* vt, int T, int Tpad) {
   __shared__ half_t tile[64][66];
   const int t0 = blockIdx.x * 64, h = blockIdx.y;
   const int tid = threadIdx.x;
+  qkv += (long)blockIdx.z * T * ld;                        // image blockIdx.z of an image-batched pass
+  vt += (long)blockIdx.z * gridDim.y * 64 * Tpad;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = tid + i * 256;           // 512 16-B chunks: token c>>3, dims (c&7)*8..+7
@@ -207,7 +202,7 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const hal
                                                          const half_t* __restrict__ vt, int Tpad,
                                                          const float* __restrict__ traw,
                                                          half_t* __restrict__ out, long ldo, int T,
-                                                         float qmul, float bmul, int xcd_heads) {
+                                                         float qmul, float bmul, int xcd_heads, int nH) {
   // Scores live in BASE-2 units from the start: the caller's q already carries scale * log2(e) (folded into the qkv
   // projection, qmul == 1) or is multiplied by qmul here; the bias tables are multiplied by bmul.
   // traw (BIAS): [nH][T][256] fp32 = q . [rel_pos_h (127 rows) | 0 | rel_pos_w (127 rows) | 0] from one
@@ -219,15 +214,22 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const hal
   const int fr = lane & 15, fg = lane >> 4;
   // XCD-aware order (nH % 8 == 0): workgroup b runs on XCD b % 8, and all query blocks of a head share its K / V^T
   // (1.4 MB at T = 5330), so head h is served by XCD h % 8 only -- two heads' keys per 4 MB L2 instead of all sixteen
-  int head, qblk;
+  int head, qblk, img;
   if (xcd_heads) {
     const int b = blockIdx.x, x = b & 7, i = b >> 3, nqb = gridDim.x / (xcd_heads * 8);
     head = x + 8 * (i / nqb);
     qblk = i % nqb;
+    img = blockIdx.y;
   } else {
     head = blockIdx.y;
     qblk = blockIdx.x;
+    img = blockIdx.z;
   }
+  // image-batched pass: image `img` owns rows img*T .. img*T+T-1 of qkv / out, its own V^T block and bias tables
+  qkv += (long)img * T * ld;
+  out += (long)img * T * ldo;
+  vt += (long)img * nH * 64 * Tpad;
+  if constexpr (BIAS) traw += (long)img * nH * T * 256;
   const int q0 = qblk * QPB + wave * QPW;
   const half_t* qp = qkv + q_off + head * 64;
   const half_t* kp = qkv + k_off + head * 64;
@@ -366,23 +368,6 @@ __global__ __launch_bounds__(256, BIAS ? 2 : 3) void flash_attn_kernel(const hal
         }
       }
       // tied-accumulator MFMAs + their K fragment reads (see scores_mfma): VALU-initialised quads in, VALU-readable out
-#ifdef FLASH_DBG_DUMP
-      if constexpr (BIAS) {
-        if (t == 0 && g_flash_dbg) {
-          float* d = g_flash_dbg + ((long)blockIdx.x * 256 + tid) * 48;
-          const int qc1 = qrow[1] < T ? qrow[1] : T - 1;
-          const float* twq1 = traw + ((long)head * T + qc1) * 256 + 128 + (qc1 & 63) + 63;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              d[kt * 4 + j] = s[1][kt][j];
-              d[16 + kt * 4 + j] = twr[1][kt][j];
-              d[32 + kt * 4 + j] = __builtin_nontemporal_load(twq1 - ((kt >> 1) * 32 + 8 * fg + 4 * (kt & 1) + j)) * bmul + (thv[1] - mref[1]);
-            }
-        }
-      }
-#endif
       scores_mfma(s, qf, kaddr0 + kbase, kaddr1 + kbase);
       // lane holds keys t*64 + (kt>>1)*32 + 8 fg + 4 (kt&1) + j of query fr; out-of-range keys only on the last tile
       if ((t + 1) * KT > T) {
@@ -746,11 +731,12 @@ extern "C" long csam_flash_attn_workspace_bytes(int T, int nH) {
   return (long)nH * 64 * Tpad * 2;
 }
 
-extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
-                               const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
-                               void* vt_workspace, long vt_workspace_bytes, int q_prescaled) {
+extern "C" int csam_flash_attn_batched(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                                       const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
+                                       void* vt_workspace, long vt_workspace_bytes, int q_prescaled, int n_images) {
   CSAM_REQUIRE(qkv_f16 && out_f16 && vt_workspace && T > 0 && nH > 0, "csam_flash_attn: bad args");
-  if (vt_workspace_bytes < csam_flash_attn_workspace_bytes(T, nH)) {
+  CSAM_REQUIRE(n_images >= 1 && n_images <= 64, "csam_flash_attn: n_images = %d", n_images);
+  if (vt_workspace_bytes < n_images * csam_flash_attn_workspace_bytes(T, nH)) {
     csam_set_error("csam_flash_attn: V^T workspace too small (must also be zero-initialised once)");
     return CSAM_ERR_WORKSPACE;
   }
@@ -758,16 +744,12 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   CSAM_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0,
                "csam_flash_attn: alignment");
   CSAM_REQUIRE(!relpos_raw || T == 4096, "csam_flash_attn: rel-pos bias needs the 64x64 token grid");
-  hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, nH, n_images), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)qkv_f16, ld, v_off, (half_t*)vt_workspace, T, Tpad);
-  dim3 grid(csam_cdiv(T, QPB), nH), block(256);
-  static int use_xcd = -1;
-  if (use_xcd < 0) {
-    const char* e = getenv("CSAM_FLASH_XCD");          // 0: plain (query block, head) grid, for A/B
-    use_xcd = e ? atoi(e) : 1;
-  }
-  const int xcd_heads = (use_xcd && nH % 8 == 0) ? nH / 8 : 0;
-  if (xcd_heads) grid = dim3(csam_cdiv(T, QPB) * nH);
+  // XCD-aware order (nH % 8 == 0): head h is served by XCD h % 8 only; the image index rides in grid.y then
+  const int xcd_heads = (nH % 8 == 0) ? nH / 8 : 0;
+  dim3 grid(csam_cdiv(T, QPB), nH, n_images), block(256);
+  if (xcd_heads) grid = dim3(csam_cdiv(T, QPB) * nH, n_images);
   // q_prescaled: the caller folded scale * log2(e) into the q rows of the qkv projection (and relpos_raw was
   // computed from that q, so the bias tables carry the same factor and only 1/scale brings them to base-2 units)
   const float log2e = 1.4426950408889634f;
@@ -776,13 +758,20 @@ extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q
   if (relpos_raw)
     hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
                        q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul,
-                       xcd_heads);
+                       xcd_heads, nH);
   else
     hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, (const half_t*)qkv_f16, ld,
                        q_off, k_off, (const half_t*)vt_workspace, Tpad, relpos_raw, (half_t*)out_f16, ldo, T, qmul, bmul,
-                       xcd_heads);
+                       xcd_heads, nH);
   CSAM_LAUNCH_CHECK("csam_flash_attn");
   return CSAM_OK;
+}
+
+extern "C" int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                               const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale,
+                               void* vt_workspace, long vt_workspace_bytes, int q_prescaled) {
+  return csam_flash_attn_batched(stream, qkv_f16, ld, q_off, k_off, v_off, relpos_raw, out_f16, ldo, T, nH, scale, vt_workspace,
+                                 vt_workspace_bytes, q_prescaled, 1);
 }
 
 // head_dim 80 form (ViT-H): qkv heads are 80 wide, V^T workspace nH x 80 x Tpad fp16 (zero-initialised once); q is scaled

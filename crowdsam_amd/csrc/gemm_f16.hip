@@ -19,16 +19,10 @@
 //   * epilogue fused: +bias[n], GELU(erf)/ReLU, *colscale[n] (DINOv2 LayerScale),
 //     +residual[m,n] (f16 or f32), cast to f16 or f32.
 #include "csam_common.h"
-#include <stdlib.h>
 
 namespace {
 
-// developer A/B (CSAM_DEFS_gemm_f16=-DCSAM_GEMM_NT): output stores with the non-temporal hint
-#ifdef CSAM_GEMM_NT
-#define GEMM_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
 #define GEMM_ST(ptr, val) (*(ptr) = (val))
-#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
@@ -73,13 +67,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-#ifdef CSAM_GEMM_TS   /* developer timing build: where does a k-step of gemm_f16_kernel go?  tools/debug/gemm_kstep.py */
-__device__ long long* g_gemm_ts = nullptr;
-extern "C" int csam_dbg_set_gemm_ts(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &p, sizeof(p)); }
-#define GTS(k) do { if (ts_on) { const long long t__ = __builtin_amdgcn_s_memtime(); ts_acc[k] += t__ - ts_prev; ts_prev = t__; } } while (0)
-#else
-#define GTS(k) do {} while (0)
-#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -92,14 +79,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Shipped configurations:
 //   <4,4,2,2,2>  128-row tile, 4 waves, 2 x 32 KB: two workgroups per CU
 //   <2,4,2,2,3>   64-row tile, 4 waves, 3 x 24 KB: two workgroups per CU; for grids that would leave CUs idle
-//   <4,2,2,4,4>  128-row tile, 8 waves, 4 x 32 KB: one workgroup per CU, two waves per SIMD, 3 stages in flight
-// NP > 0 (round 4): NP extra PRODUCER waves do nothing but issue the LDS-DMA pieces (tools/debug/gemm_kstep.py: 370 of a k-step's
-// 1 220 cycles per wave went into issuing them in front of the MFMAs); the NW = WM x WN consumer waves only read fragments and
-// multiply.  Same ring, same barriers, same arithmetic: bit-identical results.
-template <int MI, int NI, int WM, int WN, int NS, int KB, int NP = 0>
-__global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs p) {
+//   <3,4,2,2,2>   96-row tile, 4 waves, 2 x 28 KB: two workgroups per CU; fills one round of 512 where 128 rows do not
+// (Round 4 measured producer waves, deeper rings, 192-row tiles, counted waits, interleaved LDS-DMA issue and non-temporal
+// stores on these shapes: all within +-3 % or slower, DESIGN.md 4.2f / profiles/r04_gemm_*.txt; the code is gone.)
+template <int MI, int NI, int WM, int WN, int NS, int KB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
-  constexpr int NL = NP ? NP : NW;               // waves that load
+  constexpr int NL = NW;                         // waves that load
   constexpr int TBM = WM * MI * 16;              // rows of the workgroup tile
   static_assert(WN * NI * 16 == BN, "tile is 128 columns wide");
   static_assert(KB == 64 || KB == 32, "K step");
@@ -123,10 +109,8 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
                                 : (void*)((half_t*)p.C + (long)blockIdx.z * p.sC);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const bool is_prod = NP > 0 && wave >= NW;       // wave-uniform
-  const bool loader = NP == 0 || is_prod;
-  const int lw = NP ? wave - NW : wave;          // index among the loading waves
-  const int wm = (wave % NW) / WN, wn = wave % WN;
+  const int lw = wave;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a contiguous run of row-major
   // tiles (N fastest): an XCD's L2 then sees few A row-tiles and A crosses the fabric about once instead of
   // 8 times.  Bijective for any tile count.
@@ -147,13 +131,13 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
   const half_t* w_src[LW];
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
-    const int row = ((loader ? lw : 0) * LW + i) * RPI + srow;
+    const int row = (lw * LW + i) * RPI + srow;
     const int chunk = sslot ^ swz(row);
     w_src[i] = p.W + (long)(bn0 + row) * p.ldw + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    const int row = ((loader ? lw : 0) * LA + i) * RPI + srow;
+    const int row = (lw * LA + i) * RPI + srow;
     const int chunk = sslot ^ swz(row);
     int gm = bm0 + row;
     gm = gm < p.M ? gm : p.M - 1;        // clamp: rows past M are loaded but never stored
@@ -186,35 +170,17 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
   const int nk = p.K / KB;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nk && loader) stage(s, s * KB);
+    if (s < nk) stage(s, s * KB);
 
-#ifdef CSAM_GEMM_TS
-  const bool ts_on = g_gemm_ts && blockIdx.x == 5 && lane == 0 && wave == 1;
-  long long ts_acc[5] = {0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime();
-  const long long ts_begin = ts_prev;
-#endif
   int cur = 0;                                         // kt % NS
   for (int kt = 0; kt < nk; ++kt) {
-    GTS(4);
     // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
     // done reading the buffer of stage kt-1, which the next prefetch overwrites
-#ifdef CSAM_GEMM_COUNTED
-    // A/B build: NS >= 3 keeps the stage issued in the previous iteration in flight (only LDS-DMA loads are outstanding in this
-    // loop, and they retire in order) -- two iterations of latency cover instead of one
-    if (NS >= 3 && kt + 1 < nk) wait_vmcnt<(NS >= 3 ? L : 0)>();
-    else wait_vmcnt<0>();
-#else
     wait_vmcnt<0>();     // NS >= 3: this also retires the stages issued ahead, one iteration before they are read
-#endif
-    GTS(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    GTS(1);
-#ifndef CSAM_GEMM_INTERLEAVE
-    if (kt + NS - 1 < nk && loader) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
-    GTS(2);
+    if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
     const char* base = smem + cur * STAGE;
-    if (!is_prod)
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       const int coff = ((kk * 4 + fg) ^ sw) << 4;
@@ -229,67 +195,11 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
-#else
-    // round-4 EXPERIMENT (-DCSAM_GEMM_INTERLEAVE; slower, not the default).  tools/debug/gemm_kstep.py (-DCSAM_GEMM_TS): of ~1 220
-    // cycles per k-step and wave, 370 go into ISSUING the next stage's six LDS-DMA pieces back to back in front of the first
-    // MFMA and 540 into fragment reads + 16 MFMAs (256 pipe cycles).  Here the pieces are issued BETWEEN groups of MFMAs and
-    // the fragments of the second half of the step are read before the first half's MFMAs -- and the k-loop takes 102 868 instead
-    // of 79 064 cycles (fc2 shape), the encoder 5.64 instead of 5.29 ms: a piece costs more between MFMAs than in front of them
-    GTS(2);
-    {
-      const char* base = smem + cur * STAGE;
-      const bool pf = kt + NS - 1 < nk;
-      const int nbuf = cur == 0 ? NS - 1 : cur - 1, k0n = (kt + NS - 1) * KB;
-      constexpr int KK = KB / 32, NM = MI * NI * KK;
-      constexpr int STRIDE = NM / L >= 1 ? NM / L : 1;
-      half8_t af[2][MI], wf[2][NI];
-      auto frags = [&](int kk, half8_t (&a)[MI], half8_t (&w)[NI]) {
-        const int coff = ((kk * 4 + fg) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) w[i] = *(const half8_t*)(base + w_off[i] + coff);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *(const half8_t*)(base + a_off[i] + coff);
-      };
-      auto piece = [&](int i) {
-        char* abase = smem + nbuf * STAGE;
-        if (i < LW) glds16(w_src[i] + k0n, abase + A_BYTES + (wave * LW + i) * 1024);
-        else glds16(a_src[i - LW] + k0n, abase + (wave * LA + (i - LW)) * 1024);
-      };
-      frags(0, af[0], wf[0]);
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        if (kk + 1 < KK) frags(kk + 1, af[(kk + 1) & 1], wf[(kk + 1) & 1]);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni], 0, 0, 0);
-            const int g = (kk * MI + mi) * NI + ni + 1;             // MFMAs issued so far (compile-time after unrolling)
-            if (g % STRIDE == 0 && g / STRIDE <= L) {
-              if (pf) piece(g / STRIDE - 1);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-      }
-    }
-#endif
-#ifdef CSAM_GEMM_TS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    GTS(3);
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
-#ifdef CSAM_GEMM_TS
-  if (ts_on) {
-    for (int i = 0; i < 5; ++i) g_gemm_ts[i] = ts_acc[i];
-    g_gemm_ts[5] = nk;
-    g_gemm_ts[6] = __builtin_amdgcn_s_memtime() - ts_begin;
-  }
-#endif
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
   float* stab = (float*)(smem + TBM * 512);            // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
   if (p.st_in) {
-    if (!is_prod)
     for (int r = tid; r < TBM; r += NT) {
       const int m = min(bm0 + r, p.M - 1);
       const float2_t ms = ln_row_stats(p.st_in + (long)m * p.st_np * 2, p.st_np, p.eps);
@@ -304,7 +214,6 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
   // tile is staged in the (now free) operand LDS with an XOR-swizzled slot index and written / residual-added
   // as whole coalesced rows, 16 B per lane.
   const bool res_late = p.R && p.c_dt == CSAM_DT_F32 && p.r_dt == CSAM_DT_F32;   // residual added at copy-out
-  if (!is_prod)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * MI * 16 + mi * 16 + fr;     // row inside the workgroup tile
@@ -354,7 +263,6 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void gemm_f16_kernel(GemmArgs 
     }
   }
   __syncthreads();
-  if (is_prod) return;
   if (p.c_dt == CSAM_DT_F32) {
 #pragma unroll
     for (int it = 0; it < TBM * 32 / NT; ++it) {
@@ -500,7 +408,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  const bool noload = (p.xcd & 2) != 0;                           // developer ablation
   int slot = 0;
   for (int s = 0; s < nst; ++s) {
     const char* base = smem + slot * G2_STAGE;
@@ -510,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) wf[j] = *(const half8_t*)(base + w_base + j * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
-    if (s + 2 < nst && !noload) stage_w((slot + 2) & 3, (s + 2) * 32);
+    if (s + 2 < nst) stage_w((slot + 2) & 3, (s + 2) * 32);
     // retire stage s+1 HERE, a full phase (two barriers) before either group reads it: a counted wait followed by
     // a read in the same phase is not safe for the other waves' LDS-DMA data.  A(s+2) and W(s+2) may stay in flight.
     if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -530,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // ---- phase b: rows 64..127, same W fragments
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + (4 + i) * 1024);
-    if (s + 3 < nst && !noload) stage_a((slot + 3) & 3, (s + 3) * 32);
+    if (s + 3 < nst) stage_a((slot + 3) & 3, (s + 3) * 32);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -640,103 +547,44 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   CSAM_REQUIRE(!st_in || (colsum && st_np > 0 && st_np * BN == K && batch == 1),
                "csam_gemm_f16_ln: row statistics must cover K = %d features in 128-column partials (got %d)", K, st_np);
   CSAM_REQUIRE(batch >= 1 && (batch == 1 || !residual), "csam_gemm_f16: batched call takes no residual");
-  // 64-row tiles when 128-row tiles would leave CUs without a workgroup (measured: pays at <= 256 tiles,
-  // loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU)
-  const bool small = (long)(N / BN) * csam_cdiv(M, BM) * batch <= 256;
-  // 96-row tiles when 128-row tiles would fill only part of ONE round of the 512 resident workgroups and 96-row tiles
-  // still fit that round (DINOv2 proj / fc2: M = 5376, N = 1024: 336 -> 448 workgroups)
+  // Tile height of the 128-column kernel.  64 rows when 128-row tiles would leave CUs without a workgroup (measured: pays at
+  // <= 256 tiles, loses at 336 because of the extra W re-reads and the uneven 2.6 workgroups/CU); 96 rows when 128-row tiles
+  // would fill only part of ONE round of the 512 resident workgroups and 96-row tiles still fit that round (DINOv2 proj / fc2
+  // at one image: M = 5330, N = 1024: 336 -> 448 workgroups); 128 rows otherwise (every image-batched shape)
   const long t128 = (long)(N / BN) * csam_cdiv(M, BM) * batch, t96 = (long)(N / BN) * csam_cdiv(M, 96) * batch;
-  static int use96 = -1;
-  if (use96 < 0) {
-    const char* e = getenv("CSAM_GEMM_96");
-    use96 = e ? atoi(e) : 1;
-  }
-  bool mid = use96 && !small && t128 < 512 && t96 <= 512;
-  // developer A/B (tools/debug/gemm_switch_ab.sh): CSAM_GEMM_ROWS=64|96|128 forces the tile height of the 128-column kernel
-  static int force_rows = -1;
-  if (force_rows < 0) {
-    const char* e = getenv("CSAM_GEMM_ROWS");
-    force_rows = e ? atoi(e) : 0;
-  }
-  // bytes in flight: one workgroup per CU with a deeper ring of a TALLER tile moves fewer operand bytes with as
-  // many of them in flight.  CSAM_GEMM_DEEP: 128-row tiles with 4 stages where 128-row tiles are one round of the chip (instead
-  // of two 64-row workgroups per CU with 3 stages); CSAM_GEMM_192: 192-row tiles with 3 stages where they are one round and
-  // 128-row tiles are not (instead of two 96-row workgroups per CU with 2 stages)
-  static int deep = -1, tall = -1;
-  if (deep < 0) {
-    const char* e = getenv("CSAM_GEMM_DEEP");
-    deep = e ? atoi(e) : 0;
-    const char* f = getenv("CSAM_GEMM_192");
-    tall = f ? atoi(f) : 0;
-  }
-  const long t192 = (long)(N / BN) * csam_cdiv(M, 192) * batch;
-  const bool use_deep = deep && small && t128 > 128;
-  const bool use_tall = tall && !small && t192 <= 256;
-  bool small_f = small;
-  if (force_rows == 64) { small_f = true; mid = false; }
-  else if (force_rows == 96) { small_f = false; mid = true; }
-  else if (force_rows == 128) { small_f = false; mid = false; }
-  static int variant = -1, xcd = 1;
-  if (variant < 0) {
-    const char* e = getenv("CSAM_GEMM_VARIANT");
-    variant = e ? atoi(e) : 0;
-    const char* x = getenv("CSAM_GEMM_XCD");
-    xcd = x ? atoi(x) : 1;
-  }
-  p.xcd = xcd;
-  // wide fp16-output projections whose 256x256 grid fits one round of workgroups: the ping-pong kernel
-  static int use256 = -1;
-  if (use256 < 0) {
-    const char* e = getenv("CSAM_GEMM_256");
-    use256 = e ? atoi(e) : 1;
-  }
+  const bool small = t128 <= 256;
+  const bool mid = !small && t128 < 512 && t96 <= 512;
+  p.xcd = 1;
+  // Wide fp16-output projections (qkv, fc1): the 256 x 256 ping-pong kernel, one workgroup per CU, when its grid is at most one
+  // round of the chip or fills its last round to >= 85 % (image-batched encoders: M = B x 4096 / B x 5330 rows; one image of
+  // DINOv2's fc1 -- 336 tiles, 1.3 rounds -- is cut into 4096 + 1234 rows by the plan instead)
   static csam_once_t set256;
   if (csam_first_call(set256))
     hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_ALL);
-  if (use256 && batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 &&
-      (N / 256) * csam_cdiv(M, 256) <= 256 && K >= 64 && (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
-    dim3 g256((N / 256) * csam_cdiv(M, 256));
+  const long t256 = (long)(N / 256) * csam_cdiv(M, 256);
+  const bool fills = t256 <= 256 || 100 * t256 >= 85 * 256 * csam_cdiv(t256, 256);
+  if (batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 && fills && K >= 64 &&
+      (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
+    dim3 g256((unsigned)t256);
     hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM_ALL, (hipStream_t)stream, p);
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }
-  dim3 grid((N / BN) * csam_cdiv(M, use_tall ? 192 : use_deep ? BM : mid ? 96 : small_f ? 64 : BM), 1, batch);
-#define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_) CSAM_GEMM_LAUNCH_P(MI_, NI_, WM_, WN_, NS_, KB_, 0)
-#define CSAM_GEMM_LAUNCH_P(MI_, NI_, WM_, WN_, NS_, KB_, NP_)                                                  \
+  dim3 grid((N / BN) * csam_cdiv(M, mid ? 96 : small ? 64 : BM), 1, batch);
+#define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
     constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
     constexpr int SM = (SM_RING > SM_OUT + 2048 ? SM_RING : SM_OUT + 2048);  /* + [TBM][2] LayerNorm table */  \
     static csam_once_t set;                                                                                    \
-    auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_, NP_>;                                            \
+    auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
     if (csam_first_call(set))                                                                                  \
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
-    hipLaunchKernelGGL(kern, grid, dim3((WM_ * WN_ + NP_) * 64), SM, (hipStream_t)stream, p);                  \
+    hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
   }
-  static int prod = -1;                              // CSAM_GEMM_PROD=1: two producer waves for the 64- / 96-row tiles
-  if (prod < 0) {
-    const char* e = getenv("CSAM_GEMM_PROD");
-    prod = e ? atoi(e) : 0;
-  }
-  if (prod && mid && !use_tall && !use_deep) {
-    CSAM_GEMM_LAUNCH_P(3, 4, 2, 2, 2, 64, 4)
-  } else if (prod && small_f && !mid && !use_tall && !use_deep && variant == 0) {
-    CSAM_GEMM_LAUNCH_P(2, 4, 2, 2, 3, 64, 4)
-  } else if (use_tall) {
-    CSAM_GEMM_LAUNCH(6, 4, 2, 2, 3, 64)
-  } else if (use_deep) {
-    CSAM_GEMM_LAUNCH(4, 4, 2, 2, 4, 64)
-  } else if (mid) {
-    CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
-  } else if (small_f) {
-    if (variant == 0) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
-    else if (variant == 1) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 4, 32)
-    else CSAM_GEMM_LAUNCH(2, 4, 2, 2, 6, 32)
-  } else {
-    if (variant == 0) CSAM_GEMM_LAUNCH(4, 4, 2, 2, 2, 64)
-    else if (variant == 1) CSAM_GEMM_LAUNCH(4, 4, 2, 2, 4, 32)
-    else CSAM_GEMM_LAUNCH(4, 4, 2, 2, 3, 32)
-  }
+  if (mid) CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
+  else if (small) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
+  else CSAM_GEMM_LAUNCH(4, 4, 2, 2, 2, 64)
   CSAM_LAUNCH_CHECK("csam_gemm_f16");
   return CSAM_OK;
 }

@@ -422,6 +422,190 @@ extern "C" int csam_mask_nms(void* stream, const void* masks_u8, const float* sc
   return CSAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// COCO compressed-RLE strings on the device (amg.py:294-300 coco_encode_rle -> pycocotools' rleFrPyObjects / rleToString):
+// the change positions never visit the host as integer arrays -- a frame of noise-like masks has 1e7+ of them (100+ MB of
+// uint32, then three int64 numpy passes and the C packer: the 20-40 ms "host stall" of single frames in rounds 3-4).
+// Run lengths of mask i: differences of  E = [0, (0 if its first pixel is set), positions..., h*w];  count k is coded as
+// x = cnt[k] - (k > 2 ? cnt[k-2] : 0) in 5-bit groups, low group first, bit 5 = "more", + 48 (rleToString).
+// Three passes over the counts of ALL masks back to back (1024 counts per workgroup): characters per block, scan of the block
+// sums, write.  Every thread recomputes its counts from four neighbouring positions (L2-resident: just written).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int coco_nchar(long x) {
+  int n = 0;
+  bool more = true;
+  while (more) {
+    const int c = (int)(x & 0x1f);
+    x >>= 5;
+    more = (c & 0x10) ? (x != -1) : (x != 0);
+    ++n;
+  }
+  return n;
+}
+
+struct CocoSrc {
+  const uint32_t* pos; const long* pos_off; const uint8_t* first; const long* cnt_off; int N; long hw;
+};
+
+// mask of global count index g (cnt_off[i] <= g < cnt_off[i + 1]); cnt_off is tiny and L1 / L2 resident
+__device__ __forceinline__ int coco_find_mask(const long* __restrict__ cnt_off, int N, long g) {
+  int lo = 0, hi = N;                  // invariant: cnt_off[lo] <= g < cnt_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cnt_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// x of count k of mask i (k < number of counts of the mask)
+__device__ __forceinline__ long coco_x(const CocoSrc& s, int i, long k) {
+  const long p0 = s.pos_off[i], np = s.pos_off[i + 1] - p0;
+  const long f = s.first[i] ? 1 : 0;
+  auto E = [&](long j) -> long {       // j = 0 .. np + 1 + f
+    if (j <= f) return 0;
+    const long q = j - 1 - f;
+    return q < np ? (long)s.pos[p0 + q] : s.hw;
+  };
+  const long c = E(k + 1) - E(k);
+  return k > 2 ? c - (E(k - 1) - E(k - 2)) : c;
+}
+
+__global__ __launch_bounds__(1024) void coco_cnt_off_kernel(const long* __restrict__ pos_off, const uint8_t* __restrict__ first,
+                                                            int N, long* __restrict__ cnt_off) {
+  __shared__ long part[1024];
+  __shared__ long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + threadIdx.x;
+    const long v = i < N ? pos_off[i + 1] - pos_off[i] + 1 + (first[i] ? 1 : 0) : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const long t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < N) cnt_off[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt_off[N] = carry;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void coco_pack_kernel(CocoSrc s, int* __restrict__ block_sums, const long* __restrict__ block_off,
+                                                        char* __restrict__ out, long out_cap, long* __restrict__ str_off) {
+  __shared__ int wsum[4];
+  const long total = s.cnt_off[s.N];
+  const long g0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  long x[4];
+  int nc[4], mi[4];
+  long kk[4];
+  int mine = 0;
+  int i = g0 < total ? coco_find_mask(s.cnt_off, s.N, g0) : 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long g = g0 + e;
+    nc[e] = 0; x[e] = 0; mi[e] = -1; kk[e] = 0;
+    if (g < total) {
+      while (g >= s.cnt_off[i + 1]) ++i;                // consecutive counts: at most a few steps (every mask has >= 1 count)
+      const long k = g - s.cnt_off[i];
+      x[e] = coco_x(s, i, k);
+      nc[e] = coco_nchar(x[e]);
+      mi[e] = i; kk[e] = k;
+      mine += nc[e];
+    }
+  }
+  // exclusive scan of `mine` over the 256 threads: wave shuffles + 4 wave sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wsum[w];
+  if (!WRITE) {
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = wbase + incl;
+    return;
+  }
+  long p = block_off[blockIdx.x] + wbase + incl - mine;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (mi[e] < 0) continue;
+    if (kk[e] == 0) str_off[mi[e]] = p;
+    long v = x[e];
+    for (int c = 0; c < nc[e]; ++c) {
+      int ch = (int)(v & 0x1f);
+      v >>= 5;
+      if (c + 1 < nc[e]) ch |= 0x20;
+      if (p < out_cap) out[p] = (char)(ch + 48);
+      ++p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void coco_block_scan_kernel(const int* __restrict__ block_sums, long nblocks,
+                                                               long* __restrict__ block_off, long* __restrict__ total_out) {
+  __shared__ long part[1024];
+  __shared__ long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (long base = 0; base < nblocks; base += 1024) {
+    const long i = base + threadIdx.x;
+    const long v = i < nblocks ? block_sums[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const long t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_off[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+extern "C" long csam_coco_rle_pack_workspace_bytes(int N, long max_counts) {
+  const long nb = (max_counts + 1023) / 1024 + 1;
+  return (long)(N + 1) * 8 + nb * 4 + nb * 8 + 64;
+}
+
+extern "C" int csam_coco_rle_pack(void* stream, const uint32_t* positions, const long* pos_offsets, const uint8_t* first_pixel,
+                                  int N, long hw, long max_counts, void* workspace, long workspace_bytes, char* out_chars,
+                                  long out_cap, long* str_offsets) {
+  CSAM_REQUIRE(positions && pos_offsets && first_pixel && workspace && out_chars && str_offsets && N > 0 && hw > 0 &&
+               max_counts > 0 && out_cap > 0, "csam_coco_rle_pack: bad args");
+  if (workspace_bytes < csam_coco_rle_pack_workspace_bytes(N, max_counts)) {
+    csam_set_error("csam_coco_rle_pack: workspace too small");
+    return CSAM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long nb = (max_counts + 1023) / 1024;
+  long* cnt_off = (long*)workspace;
+  long* block_off = cnt_off + (N + 1);
+  int* block_sums = (int*)(block_off + nb + 1);
+  CocoSrc src{positions, pos_offsets, first_pixel, cnt_off, N, hw};
+  hipLaunchKernelGGL(coco_cnt_off_kernel, dim3(1), dim3(1024), 0, s, pos_offsets, first_pixel, N, cnt_off);
+  hipLaunchKernelGGL(coco_pack_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, src, block_sums, (const long*)block_off,
+                     out_chars, out_cap, str_offsets);
+  hipLaunchKernelGGL(coco_block_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)block_sums, nb, block_off, str_offsets + N);
+  hipLaunchKernelGGL(coco_pack_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, src, block_sums, (const long*)block_off,
+                     out_chars, out_cap, str_offsets);
+  CSAM_LAUNCH_CHECK("csam_coco_rle_pack");
+  return CSAM_OK;
+}
+
 // masks_u8[idx[i]] for i < N when idx is given (store slots of the kept masks: no gather before the encoder), else masks_u8[i]
 extern "C" int csam_rle_count_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N,
                                   int H, int W, int* col_offsets, int* totals) {

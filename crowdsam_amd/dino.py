@@ -7,7 +7,6 @@ cls token, learned 37x37 pos-embed bicubic-resized to 73x73, 24 pre-LN blocks wi
 GELU MLP, final LayerNorm.  Sequence = 1 + 5329 tokens, rows padded to 5376 in HBM.
 """
 import math
-import os
 
 import torch
 import torch.nn.functional as F
@@ -36,7 +35,7 @@ def interpolate_pos_embed(pos_embed, gh, gw, offset=0.1):
 
 
 class DinoPlan:
-    def __init__(self, sd, device, depth=24, heads=16, pos_offset=0.1):
+    def __init__(self, sd, device, depth=24, heads=16, pos_offset=0.1, ln_fold=True):
         D = sd["cls_token"].shape[-1]
         assert D // heads == 64 and D % 128 == 0
         self.D, self.depth, self.heads, self.device = D, depth, heads, device
@@ -66,9 +65,7 @@ class DinoPlan:
                 ls2=f32(sd[B + "ls2.gamma"])))
         # round 4: LayerNorm folded into the qkv / fc1 projections (csam_gemm_f16_ln); block 0's first LayerNorm stays a
         # kernel (its input's cls row comes from a copy, not from a projection)
-        self.ln_fold = os.environ.get("CSAM_LN_FOLD", "1") != "0"
-        # fc1 in two launches (4096 + 1234 rows), both on the ping-pong kernel; CSAM_DINO_FC1_SPLIT=0: one 336-tile launch
-        self.fc1_split = 4096 if os.environ.get("CSAM_DINO_FC1_SPLIT", "1") != "0" else 1 << 30
+        self.ln_fold = bool(ln_fold)
         if self.ln_fold:
             for i, bl in enumerate(self.blocks):
                 B = f"blocks.{i}."
@@ -77,47 +74,100 @@ class DinoPlan:
                 bl["fc1_wf"], bl["fc1_bf"], bl["fc1_cs"] = hip.fold_layernorm(f32(sd[B + "mlp.fc1.weight"]), bl["fc1_b"],
                                                                                bl["ln2_g"], bl["ln2_b"])
         self.norm_g, self.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
-        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
-        TP = 5376
-        self.ws = dict(col=e(5329, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
-                       attn=e(TP, D), mlp=e(TP, 4 * D), img=e(3 * 1024 * 1024, dt=torch.float32),
-                       x16=e(TP, D), st=e(TP, D // 128, 2, dt=torch.float32))
+        self.cap = 0
+        self.ws = {}
+        self._alloc(1)
         self.graphs = hip.GraphCache()
+
+    def _alloc(self, cap):
+        """Static workspaces for passes of up to ``cap`` images: token matrices [cap * 5330 (+ slack), .], image b = rows
+        b * 5330 .. b * 5330 + 5329 (cls token first)."""
+        if cap <= self.cap:
+            return
+        D, device = self.D, self.device
+        e = lambda *s, dt=torch.float16: torch.empty(*s, dtype=dt, device=device)
+        TP = cap * T_DINO + 46                 # one image: 5376 rows as before
+        self.ws = dict(col=e(cap * N_PATCH, 640), x=e(TP, D, dt=torch.float32), h=e(TP, D), qkv=e(TP, 3 * D),
+                       attn=e(TP, D), mlp=e(TP, 4 * D), img=e(cap, 3 * 1024 * 1024, dt=torch.float32),
+                       x16=e(TP, D), st=e(TP, D // 128, 2, dt=torch.float32))
+        self.cap = cap
+        if hasattr(self, "graphs"):
+            self.graphs.clear()
 
     def forward_static(self, img_chw_f32, out):
         """Graph-replayed forward into the caller's static ``out`` buffer (one graph per (h, w, out))."""
         _, h, w = img_chw_f32.shape
-        buf = self.ws["img"][: 3 * h * w].view(3, h, w)
+        buf = self.ws["img"][0, : 3 * h * w].view(3, h, w)
         buf.copy_(img_chw_f32)
         return self.graphs.run((h, w, out.data_ptr()), lambda: self.forward(buf, out=out))
 
     def forward(self, img_chw_f32, out=None, normalized_1022=False):
         """raw f32 [3,h,w] image (0..255) -> x_norm_patchtokens f16 [5329, D]."""
-        D, nH, T = self.D, self.heads, T_DINO
+        self.embed([img_chw_f32], 1, normalized_1022)
+        self.run_blocks(0, self.depth, 1)
+        if out is None:
+            out = torch.empty(N_PATCH, self.D, dtype=torch.float16, device=self.device)
+        return self.final_norm([out], 1)[0]
+
+    # ---- image-batched pass: B frames as ONE [B * 5330, D] token matrix through every projection, attention per image
+    # (csam_flash_attn_batched); cut at block boundaries like EncoderPlan's
+    def load_images(self, imgs):
+        self._alloc(len(imgs))
+        views = []
+        for b, im in enumerate(imgs):
+            _, h, w = im.shape
+            v = self.ws["img"][b, : 3 * h * w].view(3, h, w)
+            v.copy_(im)
+            views.append(v)
+        return views
+
+    def forward_batch_static(self, imgs, outs):
+        """B raw frames -> x_norm_patchtokens f16 into outs[b][:5329] (static buffers of the caller); one graph per
+        (B, frame shapes, outs)."""
+        B = len(imgs)
+        views = self.load_images(imgs)
+        key = ("batch", B, tuple(tuple(v.shape[1:]) for v in views), tuple(o.data_ptr() for o in outs))
+
+        def run():
+            self.embed(views, B)
+            self.run_blocks(0, self.depth, B)
+            return self.final_norm(outs, B)
+        return self.graphs.run(key, run)
+
+    def embed(self, imgs, B, normalized_1022=False):
+        """preprocess + 1024 -> 1022 bilinear + patch embedding + cls token + position embedding of B frames."""
+        self._alloc(B)
+        ws, x = self.ws, self.ws["x"]
+        for b, im in enumerate(imgs):
+            col = ws["col"][b * N_PATCH:(b + 1) * N_PATCH]
+            hip.dino_im2col(im, col, normalized_1022)
+            x[b * T_DINO:b * T_DINO + 1].copy_(self.cls_row)
+            hip.gemm_f16(col, self.patch_w, out=x[b * T_DINO + 1:], bias=self.patch_b, residual=self.pos[1:], M=N_PATCH)
+
+    def run_blocks(self, lo, hi, B):
+        D, nH = self.D, self.heads
+        T = B * T_DINO
         ws = self.ws
-        x = ws["x"]
+        x, x16, st = ws["x"], ws["x16"], ws["st"]
         scale = (D // nH) ** -0.5
-        hip.dino_im2col(img_chw_f32, ws["col"], normalized_1022)
-        x[0:1].copy_(self.cls_row)
-        hip.gemm_f16(ws["col"], self.patch_w, out=x[1:], bias=self.patch_b, residual=self.pos[1:], M=5329)
         fold = self.ln_fold
-        x16, st = ws["x16"], ws["st"]
-        for i, b in enumerate(self.blocks):
+        for i in range(lo, hi):
+            b = self.blocks[i]
             if fold and i > 0:
                 hip.gemm_f16_ln(x16, b["qkv_wf"], ws["qkv"], bias=b["qkv_bf"], M=T, stats_in=st, colsum=b["qkv_cs"], eps=1e-6)
             else:
                 hip.layernorm(x, b["ln1_g"], b["ln1_b"], 1e-6, out=ws["h"], M=T)
                 hip.gemm_f16(ws["h"], b["qkv_w"], out=ws["qkv"], bias=b["qkv_b"], M=T)
-            hip.flash_attn(ws["qkv"], ws["attn"], T, nH, scale, D, q_prescaled=True)
+            hip.flash_attn(ws["qkv"], ws["attn"], T_DINO, nH, scale, D, q_prescaled=True, n_images=B)
             if fold:
                 hip.gemm_f16_ln(ws["attn"], b["proj_w"], x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T, out16=x16,
                                 stats_out=st)
-                # fc1 in two row ranges: 4096 rows are exactly ONE round of the 256 x 256 ping-pong kernel (16 x 16 tiles on
-                # 256 CUs, as in the SAM encoder); all 5330 rows would be 336 tiles = 1.3 rounds and fall back to the
-                # 128 x 128 kernel (77 us at 580 TFLOP/s alone, 127 us beside the SAM encoder's stream).  The remaining 1234
-                # rows are 80 more tiles of the same kernel.  Serial trace: -1.4 ms of GEMM time per frame
-                # (profiles/r04_dino_fc1_split.txt).
-                S = min(self.fc1_split, T)
+                # ONE image: fc1 in two row ranges.  4096 rows are exactly one round of the 256 x 256 ping-pong kernel (16 x 16
+                # tiles on 256 CUs, as in the SAM encoder); all 5330 rows would be 336 tiles = 1.3 rounds and fall back to the
+                # 128 x 128 kernel (77 us at 580 TFLOP/s alone, 127 us beside the SAM encoder's stream); the remaining 1234 rows
+                # are 80 more tiles of the same kernel: -1.4 ms of GEMM time per frame (profiles/r04_dino_fc1_split.txt).
+                # B >= 2 images: 672 / 1008 / 1344 tiles fill their last round to >= 87 % -- one launch.
+                S = 4096 if B == 1 else T
                 hip.gemm_f16_ln(x16[:S], b["fc1_wf"], ws["mlp"][:S], bias=b["fc1_bf"], act=hip.ACT_GELU, M=S, stats_in=st[:S],
                                 colsum=b["fc1_cs"], eps=1e-6)
                 if T > S:
@@ -130,10 +180,13 @@ class DinoPlan:
                 hip.layernorm(x, b["ln2_g"], b["ln2_b"], 1e-6, out=ws["h"], M=T)
                 hip.gemm_f16(ws["h"], b["fc1_w"], out=ws["mlp"], bias=b["fc1_b"], act=hip.ACT_GELU, M=T)
                 hip.gemm_f16(ws["mlp"], b["fc2_w"], out=x, bias=b["fc2_b"], colscale=b["ls2"], residual=x, M=T)
-        if out is None:
-            out = torch.empty(5329, D, dtype=torch.float16, device=self.device)
-        hip.layernorm(x[1:], self.norm_g, self.norm_b, 1e-6, out=out, M=5329)
-        return out
+
+    def final_norm(self, outs, B):
+        """LayerNorm of the patch tokens of image b -> outs[b][:5329] (f16)."""
+        x = self.ws["x"]
+        for b in range(B):
+            hip.layernorm(x[b * T_DINO + 1:], self.norm_g, self.norm_b, 1e-6, out=outs[b], M=N_PATCH)
+        return outs
 
     def flops(self):
         D, T = self.D, T_DINO

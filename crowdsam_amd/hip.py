@@ -31,7 +31,9 @@ SIGNATURES = {
     "csam_im2col3x3": [_P, _P, _P, _I],
     "csam_add_cast": [_P, _P, _P, _L, _P, _P, _L, _I],
     "csam_win_attn": [_P, _P, _P, _P, _P, _I, _I, _F],
+    "csam_win_attn_batched": [_P, _P, _P, _P, _P, _I, _I, _F, _I],
     "csam_flash_attn": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L, _I],
+    "csam_flash_attn_batched": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L, _I, _I],
     "csam_flash_attn80": [_P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _F, _P, _L],
     "csam_gemm_f16_resmod": [_P, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I],
     "csam_gemm_f16_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P, _L, _I, _I, _I, _I, _I],
@@ -69,6 +71,7 @@ SIGNATURES = {
     "csam_rle_write_idx": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "csam_rle_count_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "csam_coco_rle_pack": [_P, _P, _P, _P, _I, _L, _L, _P, _L, _P, _L, _P],
     "csam_mask_nms": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _L],
     "csam_caltech_match": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_double, _P, _P],
     "csam_mask_mean_bilinear": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P],
@@ -104,6 +107,7 @@ LONG_RETURNS = {
     "csam_coco_rle_string": [_P, _L, _P, _L],
     "csam_coco_rle_strings": [_P, _P, _L, _P, _L, _P],
     "csam_attn_t2i_workspace_bytes": [_I, _I],
+    "csam_coco_rle_pack_workspace_bytes": [_I, _L],
     "csam_box_nms_workspace_bytes": [_I],
     "csam_mask_nms_workspace_bytes": [_I],
     "csam_small_regions_workspace_bytes": [_I, _I, _I],
@@ -233,6 +237,10 @@ class GraphCache:
 def set_timer(timer):
     global _timer
     _timer = timer
+
+
+def timer_active():
+    return _timer is not None
 
 
 def call(name, *args):
@@ -389,25 +397,28 @@ def relcat_global(rel_h, rel_w):
     return r
 
 
-def win_attn(qkv, qkv_bias, relcat, out, D, nH, scale):
-    call("csam_win_attn", _stream(), _ptr(qkv), _ptr(qkv_bias), _ptr(relcat), _ptr(out), D, nH, float(scale))
+def win_attn(qkv, qkv_bias, relcat, out, D, nH, scale, n_images=1):
+    """qkv f16 [n_images*4096, 3D] -> out f16 [n_images*4096, D]: one launch for all images of an encoder pass."""
+    call("csam_win_attn_batched", _stream(), _ptr(qkv), _ptr(qkv_bias), _ptr(relcat), _ptr(out), D, nH, float(scale), n_images)
     return out
 
 
-def relpos_raw(qkv, relcat_g, out, nH):
-    """out f32 [nH,4096,256] = q_h @ relcat_g^T for every head (one batched MFMA GEMM, K = 64)."""
-    gemm_f16_batched(qkv, qkv.stride(0), 64, relcat_g, 64, 0, out, 256, 4096 * 256, 4096, 256, 64, nH)
+def relpos_raw(qkv, relcat_g, out, nH, n_images=1):
+    """out f32 [n_images,nH,4096,256] = q_h @ relcat_g^T for every head (one batched MFMA GEMM, K = 64, per image)."""
+    for b in range(n_images):
+        gemm_f16_batched(qkv[b * 4096:], qkv.stride(0), 64, relcat_g, 64, 0, out[b] if n_images > 1 else out, 256, 4096 * 256,
+                         4096, 256, 64, nH)
     return out
 
 
 _vt_ws = {}
 
 
-def flash_vt_workspace(T, nH, device):
-    """Zero-initialised per-head V^T scratch [nH,64,Tpad] f16 (cached per shape/device; static for graphs)."""
-    key = (T, nH, str(device))
+def flash_vt_workspace(T, nH, device, n_images=1):
+    """Zero-initialised per-head V^T scratch [n_images,nH,64,Tpad] f16 (cached per shape/device; static for graphs)."""
+    key = (T, nH, str(device), n_images)
     if key not in _vt_ws:
-        n = lib().csam_flash_attn_workspace_bytes(T, nH)
+        n = lib().csam_flash_attn_workspace_bytes(T, nH) * n_images
         _vt_ws[key] = torch.zeros(n // 2, dtype=torch.float16, device=device)
     return _vt_ws[key]
 
@@ -415,13 +426,13 @@ def flash_vt_workspace(T, nH, device):
 FLASH_QMUL = 1.4426950408889634     # x scale: what a plan folds into the q rows of its qkv projection (q_prescaled)
 
 
-def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None, q_prescaled=False):
-    """qkv f16 [T, 3*D] laid out [3][nH][64] per row -> out f16 [T, D]; relpos = relpos_raw(...) or None.
-    q_prescaled: the q columns (and relpos) already carry scale * log2(e)."""
+def flash_attn(qkv, out, T, nH, scale, D, relpos=None, vt=None, q_prescaled=False, n_images=1):
+    """qkv f16 [n_images*T, 3*D] laid out [3][nH][64] per row -> out f16 [n_images*T, D]; relpos = relpos_raw(...) or None.
+    q_prescaled: the q columns (and relpos) already carry scale * log2(e).  Images are independent sequences of T rows."""
     if vt is None:
-        vt = flash_vt_workspace(T, nH, qkv.device)
-    call("csam_flash_attn", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out),
-         out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2, int(bool(q_prescaled)))
+        vt = flash_vt_workspace(T, nH, qkv.device, n_images)
+    call("csam_flash_attn_batched", _stream(), _ptr(qkv), qkv.stride(0), 0, D, 2 * D, _ptr(relpos), _ptr(out),
+         out.stride(0), T, nH, float(scale), _ptr(vt), vt.numel() * 2, int(bool(q_prescaled)), n_images)
     return out
 
 
@@ -817,23 +828,70 @@ def mask_nms(masks, scores, thr):
 
 
 _D2H = {"buf": None}
+_D2H_CHUNK = 1 << 24
 
 
 def to_host_numpy(t):
-    """Device tensor -> numpy array through a reusable PINNED staging buffer (grown geometrically).  A pageable ``.cpu()`` of
-    the change positions of a frame with noise-like masks (100+ MB) runs at a few GB/s and was a 30-70 ms stall of single
-    frames (bench.py CSAM_BENCH_TRACE=1); pinned, the same copy runs at PCIe speed.  The returned array is a VIEW of the
-    staging buffer: consume (or copy) it before the next call."""
+    """Device tensor -> a NEW numpy array through a fixed 16 MB PINNED staging buffer, in chunks (a pageable ``.cpu()`` of a
+    100 MB result runs at a few GB/s; a staging buffer that GROWS with the largest result re-pins memory in the middle of a
+    stream -- the 20-40 ms stall of single frames that rounds 3-4 chased).  The result owns its memory."""
     import numpy as np
     n = t.numel() * t.element_size()
+    np_dtype = torch.empty(0, dtype=t.dtype).numpy().dtype
     if n == 0:
-        return np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
-    if _D2H["buf"] is None or _D2H["buf"].numel() < n:
-        _D2H["buf"] = torch.empty(max(2 * n, 1 << 24), dtype=torch.uint8).pin_memory()
-    host = _D2H["buf"][:n].view(t.dtype).view(t.shape)
-    host.copy_(t.contiguous(), non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return host.numpy()
+        return np.empty(tuple(t.shape), dtype=np_dtype)
+    if _D2H["buf"] is None:
+        _D2H["buf"] = torch.empty(_D2H_CHUNK, dtype=torch.uint8).pin_memory()
+    src = t.contiguous().view(-1).view(torch.uint8)
+    out = np.empty(n, dtype=np.uint8)
+    stream = torch.cuda.current_stream(t.device)
+    for off in range(0, n, _D2H_CHUNK):
+        m = min(_D2H_CHUNK, n - off)
+        host = _D2H["buf"][:m]
+        host.copy_(src[off:off + m], non_blocking=True)
+        stream.synchronize()
+        out[off:off + m] = host.numpy()
+    return out.view(np_dtype).reshape(tuple(t.shape))
+
+
+def rle_coco_strings(masks, idx=None, boxes=None):
+    """COCO compressed-RLE strings (list of str) of u8 masks without the change positions ever visiting the host:
+    csam_rle_count_box -> [D2H of N totals: sizes the position buffer] -> csam_rle_write_box -> csam_coco_rle_pack ->
+    D2H of the N + 1 string offsets and of exactly the string bytes.  Arguments as for rle_encode."""
+    cap_, H, W = masks.shape
+    dev = masks.device
+    N = cap_ if idx is None else int(idx.shape[0])
+    if N == 0:
+        return []
+    col = torch.empty((N, W), dtype=torch.int32, device=dev)
+    totals = torch.empty(N, dtype=torch.int32, device=dev)
+    assert boxes is None or (boxes.dtype == torch.int32 and boxes.is_contiguous() and tuple(boxes.shape) == (N, 4))
+    call("csam_rle_count_box", _stream(), _ptr(masks), _ptr(idx), _ptr(boxes), N, H, W, _ptr(col), _ptr(totals))
+    pos_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(totals, 0, out=pos_off[1:])
+    # pixel (0, 0) of every mask: a strided view of the store's first column, N bytes gathered on the device
+    col0 = masks.view(cap_, -1)[:, 0]
+    first = (col0 if idx is None else col0.index_select(0, idx.long())).contiguous()
+    n_pos = int(pos_off[-1].item())                      # the one small synchronising D2H before the strings
+    pos = torch.empty(max(n_pos, 1), dtype=torch.int32, device=dev)
+    call("csam_rle_write_box", _stream(), _ptr(masks), _ptr(idx), _ptr(boxes), N, H, W, _ptr(col), _ptr(pos_off), _ptr(pos))
+    max_counts = n_pos + 2 * N
+    nws = lib().csam_coco_rle_pack_workspace_bytes(N, max_counts)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    cap = 5 * max_counts + 16
+    while True:
+        chars = torch.empty(cap, dtype=torch.uint8, device=dev)
+        str_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        call("csam_coco_rle_pack", _stream(), _ptr(pos), _ptr(pos_off), _ptr(first), N, H * W, max_counts, _ptr(ws), nws,
+             _ptr(chars), cap, _ptr(str_off))
+        o = to_host_numpy(str_off)
+        total = int(o[-1])
+        if total <= cap:
+            break
+        cap = total + 16                               # H * W > 2^24: more than 5 characters per count
+    raw = to_host_numpy(chars[:total]).tobytes().decode("ascii")
+    o = o.tolist()
+    return [raw[o[i]:o[i + 1]] for i in range(N)]
 
 
 def rle_encode(masks, idx=None, boxes=None):

@@ -128,6 +128,11 @@ int csam_u8hwc_to_f32chw(void* stream, const uint8_t* src_hwc, int h, int w, flo
 /* relcat_f16 [64,hd]: rows 0..26 rel_pos_h, 27..53 rel_pos_w, rest zero (fp16 like the other weights) */
 int csam_win_attn(void* stream, const void* qkv_f16, const float* qkv_bias, const void* relcat_f16, void* out_f16,
                   int D, int nH, float scale);
+/* the same over n_images images in one launch (image b = rows b*4096 .. b*4096+4095 of qkv_f16 / out_f16): the batch axis of
+ * ImageEncoderViT.forward's x [B,H,W,C] (image_encoder.py:106-116), which the reference's multi-crop loop
+ * (crowdsam/model.py:151-178) feeds one crop at a time */
+int csam_win_attn_batched(void* stream, const void* qkv_f16, const float* qkv_bias, const void* relcat_f16, void* out_f16,
+                          int D, int nH, float scale, int n_images);
 /* generic head_dim (<= 128, multiple of 8; ViT-H: 80) attention = gather / batched GEMMs / softmax / scatter, the
  * reference's materialised formulation (image_encoder.py:224-289,325-361).  Groups G = nH (global, Tp = 4096) or
  * 25 windows x nH (Tp = 256, T_valid = 196); operands zero-padded to 128 dims; window pad tokens take the qkv bias. */
@@ -148,6 +153,12 @@ long csam_flash_attn_workspace_bytes(int T, int nH); /* per-head V^T scratch; ze
 int csam_flash_attn(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
                     const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
                     long vt_workspace_bytes, int q_prescaled);
+/* the same over n_images sequences of T tokens each in one launch (image b = rows b*T .. b*T+T-1 of qkv_f16 / out_f16;
+ * relpos_raw [n_images][nH][4096][256]; V^T scratch n_images x csam_flash_attn_workspace_bytes(T, nH)): the batch axis B of
+ * Attention.forward (image_encoder.py:224-240) and of DINOv2's blocks */
+int csam_flash_attn_batched(void* stream, const void* qkv_f16, long ld, int q_off, int k_off, int v_off,
+                            const float* relpos_raw, void* out_f16, long ldo, int T, int nH, float scale, void* vt_workspace,
+                            long vt_workspace_bytes, int q_prescaled, int n_images);
 /* the same at head_dim 80 (ViT-H global blocks): qkv heads 80 wide, V^T scratch nH x 80 x Tpad, q scaled in-kernel; relpos_raw
  * as above, from plain q (e.g. one batched GEMM with K = 128 over a [256,128] table whose columns 80.. are zero). */
 long csam_flash_attn80_workspace_bytes(int T, int nH);
@@ -405,6 +416,17 @@ int csam_rle_count_box(void* stream, const void* masks_u8, const int* idx_or_nul
                        int* col_offsets, int* totals);
 int csam_rle_write_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N, int H, int W,
                        const int* col_offsets, const long* mask_offsets, uint32_t* out_positions);
+/* COCO compressed-RLE strings of N masks ON THE DEVICE from the change positions above (amg.py:294-300 coco_encode_rle ->
+ * pycocotools rleToString: run k coded as cnt[k] - (k > 2 ? cnt[k-2] : 0) in 5-bit groups + 48): positions uint32, mask i =
+ * [pos_offsets[i], pos_offsets[i+1]) (device, N + 1 entries); first_pixel u8 [N] = the mask's pixel (0, 0) (a set first pixel
+ * = a leading zero-length run); hw = H * W.  max_counts >= total positions + 2 N bounds the launch.  Strings go to out_chars
+ * back to back, string i = [str_offsets[i], str_offsets[i+1]) (device, N + 1 entries; [N] = total length -- when it exceeds
+ * out_cap the characters past out_cap were dropped and the caller must retry with a larger buffer; 5 bytes per count suffice
+ * up to H * W = 2^24).  No host synchronisation. */
+long csam_coco_rle_pack_workspace_bytes(int N, long max_counts);
+int csam_coco_rle_pack(void* stream, const uint32_t* positions, const long* pos_offsets, const uint8_t* first_pixel, int N,
+                       long hw, long max_counts, void* workspace, long workspace_bytes, char* out_chars, long out_cap,
+                       long* str_offsets);
 
 /* ---- small-region clean-up (amg.py:267-291 remove_small_regions mode "holes" then "islands", 8-connected,
  * as driven by crowdsam/model.py:394-443): masks u8 [n,H,W] -> out u8 (may alias masks), changed int32 [n]

@@ -28,6 +28,8 @@ class SamPredictor:
         self.transform = ResizeLongestSide(sam_model.image_encoder.img_size)
         self._dtok16 = None
         self._side_stream = None
+        self._group_bufs = {}
+        self._group_graphs = {}
         self.reset_image()
 
     # ------------------------------------------------------------------------------------------
@@ -115,8 +117,10 @@ class SamPredictor:
         plan = self.model.decoder_plan()
         slot = (1 - plan.slot) if prefetch else plan.slot
         plan.set_image(feat, self._dtok16, slot=slot, activate=not prefetch)      # copies both into the slot's own buffers
-        return dict(original_size=tuple(original_image_size), input_size=tuple(transformed_image.shape[-2:]), feat=feat,
-                    plan=plan, slot=slot)
+        # the API views (features / dino_feats) are served from the slot's OWN copies: the encoders' output buffers are
+        # overwritten by the next look-ahead frame while this one is still the current image
+        return dict(original_size=tuple(original_image_size), input_size=tuple(transformed_image.shape[-2:]),
+                    feat=plan.states[slot]["feat"], plan=plan, slot=slot)
 
     def _adopt(self, b):
         """Make an _encode() bundle the predictor's current image."""
@@ -125,15 +129,10 @@ class SamPredictor:
         self._plan.activate(b["slot"])
         self.is_image_set = True
 
-    @torch.no_grad()
-    def prefetch_image(self, image, two_streams=True):
-        """Build extension (depth-2 image pipeline): encode a frame that is already on the device -- uint8 HWC tensor or the
-        (uint8, fp32 CHW) pair of crowdsam.utils.resize_frame_device -- WITHOUT making it the current image.  Returns a
-        bundle for adopt_prefetched(), or None when the frame needs the general set_image route (then nothing is done).
-        The encoder's own output buffer is shared, so ``features`` of the current image is not meaningful afterwards; the
-        decoder reads its per-slot copies.  ``two_streams`` False: SAM encoder, then DINOv2, on the calling stream -- beside the
-        latency chain of an EPS sweep one stream of full-chip launches disturbs it less than two (round 4: 20.7-21.3 -> 19.5-19.8
-        ms per frame in the shipped configuration; the dense sweep prefers two: 36.6 vs 38.1 ms)."""
+    def _frame_to_input(self, image):
+        """A frame that is already on the device -- uint8 HWC tensor or the (uint8, fp32 CHW) pair of
+        crowdsam.utils.resize_frame_device -- as the encoders' input: (fp32 CHW with long side == img_size, (h, w)), or None
+        when it needs the general set_image route (host resize)."""
         f32 = None
         if isinstance(image, tuple):
             image, f32 = image
@@ -152,7 +151,101 @@ class SamPredictor:
                                                 pil_bilinear_tables_device(h, th, dev))
         else:
             return None
+        return f32, (h, w)
+
+    @torch.no_grad()
+    def prefetch_image(self, image, two_streams=True):
+        """Build extension (depth-2 image pipeline): encode a frame that is already on the device -- uint8 HWC tensor or the
+        (uint8, fp32 CHW) pair of crowdsam.utils.resize_frame_device -- WITHOUT making it the current image.  Returns a
+        bundle for adopt_prefetched(), or None when the frame needs the general set_image route (then nothing is done).
+        ``two_streams`` False: SAM encoder, then DINOv2, on the calling stream -- beside the
+        latency chain of an EPS sweep one stream of full-chip launches disturbs it less than two (round 4: 20.7-21.3 -> 19.5-19.8
+        ms per frame in the shipped configuration; the dense sweep prefers two: 36.6 vs 38.1 ms)."""
+        inp = self._frame_to_input(image)
+        if inp is None:
+            return None
+        f32, (h, w) = inp
         return self._encode(f32[None], (h, w), prefetch=True, two_streams=two_streams)
+
+    # ---- image-batched look-ahead (round 5): B frames -- the next frames of a stream, or the crops of one image -- go
+    # through SAM's encoder and DINOv2 as ONE pass each (EncoderPlan / DinoPlan: [B * tokens, D] token matrices), cut into
+    # chunks at block boundaries so that crowdsam.model can queue one chunk beside each frame's tail.
+    @torch.no_grad()
+    def group_begin(self, images, bufset=0):
+        """images: device frames as for prefetch_image.  Copies them into the encoders' static input buffers and returns the
+        group record, or None when a frame needs the general route.  A third-party DINO object (anything but
+        crowdsam_amd.dino.DinoV2) is fed one frame at a time through its own forward_features at the end of the pass."""
+        inputs = [self._frame_to_input(im) for im in images]
+        if any(i is None for i in inputs):
+            return None
+        B = len(inputs)
+        enc = self.model.image_encoder.plan()
+        dino = self.dino_model.plan() if isinstance(self.dino_model, DinoV2) else None
+        raws = [f.contiguous() for f, _ in inputs]
+        dev = raws[0].device
+        key = (bufset, str(dev))
+        bufs = self._group_bufs.get(key)
+        if bufs is None or bufs["feat"].shape[0] < B:
+            bufs = dict(feat=torch.empty(B, 4096, 256, dtype=torch.float32, device=dev),
+                        dtok=[torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=dev) for _ in range(B)])
+            self._group_bufs[key] = bufs
+        return dict(B=B, sizes=[hw for _, hw in inputs], input_sizes=[tuple(f.shape[-2:]) for f in raws],
+                    sam_views=enc.load_images(raws), dino_views=dino.load_images(raws) if dino is not None else raws,
+                    feat=bufs["feat"], dtok=bufs["dtok"], bufset=bufset, enc=enc, dino=dino)
+
+    @torch.no_grad()
+    def group_chunk(self, g, c, n):
+        """Chunk c of n of the group's encoder passes on the current stream: blocks [c * depth / n, (c + 1) * depth / n) of
+        both backbones; chunk 0 starts with the patch embeddings, chunk n - 1 ends with SAM's neck and DINOv2's final norm
+        (features into the group's buffers).  One hipGraph per (group shape, c, n).  A chunk continues the residual streams
+        the previous chunk left in the plans' workspaces, so it is NOT idempotent: the first call for a key executes eagerly
+        and is then captured WITHOUT the replay hip.GraphCache.run would add."""
+        enc, dino, B = g["enc"], g["dino"], g["B"]
+        lo_s, hi_s = c * enc.depth // n, (c + 1) * enc.depth // n
+        if dino is not None:
+            lo_d, hi_d = c * dino.depth // n, (c + 1) * dino.depth // n
+
+        def run():
+            if c == 0:
+                enc.embed(g["sam_views"], B)
+                if dino is not None:
+                    dino.embed(g["dino_views"], B)
+            enc.run_blocks(lo_s, hi_s, B)
+            if dino is not None:
+                dino.run_blocks(lo_d, hi_d, B)
+            if c == n - 1:
+                enc.neck(g["feat"][:B], B)
+                if dino is not None:
+                    dino.final_norm([t[:N_DINO] for t in g["dtok"][:B]], B)
+                else:   # third-party DINO object: the reference's tensor, one frame at a time (predictor.py:104-106)
+                    for b, raw in enumerate(g["dino_views"]):
+                        x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
+                        tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
+                        g["dtok"][b][:N_DINO].copy_(tok.reshape(N_DINO, -1))
+
+        if dino is None or not hip.GRAPHS_ENABLED or hip.timer_active():
+            return run()
+        key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap)
+        ent = self._group_graphs.get(key)
+        if ent is None:
+            run()                                   # this call's execution (also sets kernel attributes)
+            torch.cuda.synchronize()
+            ent = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent):
+                run()                               # recorded, not executed
+            self._group_graphs[key] = ent
+            return
+        ent.replay()
+
+    @torch.no_grad()
+    def group_bundle(self, g, b):
+        """The decoder's per-image constants of frame b of a finished group, into the decoder plan's INACTIVE slot -> a bundle
+        for adopt_prefetched()."""
+        plan = self.model.decoder_plan()
+        slot = 1 - plan.slot
+        plan.set_image(g["feat"][b], g["dtok"][b], slot=slot, activate=False)
+        return dict(original_size=tuple(g["sizes"][b]), input_size=tuple(g["input_sizes"][b]), feat=plan.states[slot]["feat"],
+                    plan=plan, slot=slot)
 
     def adopt_prefetched(self, bundle):
         self.reset_image()
@@ -173,7 +266,7 @@ class SamPredictor:
     def dino_feats(self):
         if not self.is_image_set:
             return None
-        return self._dtok16[:N_DINO].float().view(1, 73, 73, -1)
+        return self._plan.state["dtok"][:N_DINO].float().view(1, 73, 73, -1)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

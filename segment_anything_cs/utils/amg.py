@@ -172,7 +172,7 @@ def mask_to_rle_arrays(tensor, idx=None, boxes=None):
         # ``boxes`` (build extension): XYXY boxes of the masks (inclusive maxima, batched_mask_to_box) -- the encoder then reads the
         # boxes instead of the frames
         pos, offs = hip.rle_encode(m8, idx, None if boxes is None else boxes.to(torch.int32).contiguous())
-        pos = hip.to_host_numpy(pos).astype(np.int64)              # pinned staging buffer; astype copies out of it
+        pos = hip.to_host_numpy(pos).astype(np.int64)
         # first pixel of every mask: a strided view of the store's first column, then n bytes gathered (pinned staging buffer)
         col0 = m8.view(m8.shape[0], -1)[:, 0]
         first = hip.to_host_numpy(col0 if idx is None else col0.index_select(0, idx.long())).astype(bool)
@@ -261,9 +261,35 @@ def coco_rle_string(counts):
 
 
 def coco_encode_rles(uncompressed_rles):
-    """coco_encode_rle for a list of masks with one call into the C string packer."""
-    strings = hip.coco_rle_strings([r["counts"] for r in uncompressed_rles])
-    return [{"size": list(r["size"]), "counts": st} for r, st in zip(uncompressed_rles, strings)]
+    """coco_encode_rle for a list of masks with one call into the C string packer; entries whose counts are a string already
+    (mask_to_coco_rles: packed on the device) pass through."""
+    todo = [i for i, r in enumerate(uncompressed_rles) if not isinstance(r["counts"], str)]
+    strings = hip.coco_rle_strings([uncompressed_rles[i]["counts"] for i in todo])
+    out = [{"size": list(r["size"]), "counts": r["counts"]} for r in uncompressed_rles]
+    for i, st in zip(todo, strings):
+        out[i]["counts"] = st
+    return out
+
+
+def mask_to_coco_rles(tensor, idx=None, boxes=None):
+    """mask_to_rle_pytorch + coco_encode_rle (amg.py:107-135, 294-300) in one device pass: COCO compressed-RLE dicts of the
+    masks tensor[idx] (a (cap, h, w) uint8 mask store of strict 0 / 1 bytes, or bool masks) with the run-length arithmetic and
+    the string packing on the GPU (csam_coco_rle_pack) -- one D2H of the string bytes per image instead of the change
+    positions.  ``boxes``: XYXY boxes of the masks (inclusive maxima): the scan then reads the boxes instead of the frames."""
+    b, h, w = tensor.shape
+    if idx is not None:
+        b = int(idx.shape[0])
+    if b == 0:
+        return []
+    assert tensor.is_cuda
+    if tensor.dtype == torch.bool:
+        m8 = tensor.view(torch.uint8).contiguous()
+    elif tensor.dtype == torch.uint8 and idx is not None:
+        m8 = tensor.contiguous()
+    else:
+        m8 = (tensor != 0).view(torch.uint8).contiguous()
+    strings = hip.rle_coco_strings(m8, idx, None if boxes is None else boxes.to(torch.int32).contiguous())
+    return [{"size": [h, w], "counts": st} for st in strings]
 
 
 def coco_encode_rle(uncompressed_rle):

@@ -256,9 +256,7 @@ def test_encoder_real_width_vs_oracle(cuda, D, heads, generic, monkeypatch):
     from oracle import sam_oracle as so
     specs = [s for s in synth.sam_param_specs(D, 2, heads, (1,)) if s[0].startswith("image_encoder.")]
     sd = synth.make_state_dict(specs, 5)
-    if generic:
-        monkeypatch.setenv("CSAM_WIN_HD80", "0")
-    plan = EncoderPlan(sd, "image_encoder.", D, 2, heads, (1,), cuda)
+    plan = EncoderPlan(sd, "image_encoder.", D, 2, heads, (1,), cuda, fused_win=not generic)
     assert plan.fused_attn == (D // heads == 64) and plan.fused_win == (D // heads in (64, 80) and not generic)
     x = torch.from_numpy(np.random.RandomState(1).standard_normal((1, 3, 1024, 1024)).astype(np.float32))
     mean = torch.tensor([123.675, 116.28, 103.53]).view(3, 1, 1)

@@ -28,11 +28,12 @@ def test_pipelined_generate_equals_serial_small_model(cuda):
              [synth.synthetic_crowd_frame(8, 1366, 80)[:700]]
     np.random.seed(11)
     serial = [m.generate(f) for f in frames]
-    np.random.seed(11)
-    piped = list(m.generate_stream(frames))
-    assert len(piped) == len(serial) and any(len(o["boxes"]) for o in serial)
-    for a, b in zip(serial, piped):
-        _same(a, b)
+    for batch in (1, 2, 4):        # depth-2 pipeline; image-batched look-ahead in groups of 2 / 4 (mixed frame shapes in a group)
+        np.random.seed(11)
+        piped = list(m.generate_stream(frames, batch=batch))
+        assert len(piped) == len(serial) and any(len(o["boxes"]) for o in serial)
+        for a, b in zip(serial, piped):
+            _same(a, b)
     # a look-ahead that does not come true: the prefetched state must be dropped, not used
     np.random.seed(11)
     a = m.generate(frames[0], next_image=frames[3])
@@ -72,7 +73,8 @@ def test_work_stream_and_caller_streams_give_the_same_results(cuda):
 
 
 def test_pipelined_generate_equals_serial_full_model(cuda):
-    """The bench's model (ViT-L + DINOv2-L x 24, 64 x 64 dense sweep, crowded thresholds): 4 frames, pipelined == serial."""
+    """The bench's model (ViT-L + DINOv2-L x 24, 64 x 64 dense sweep, crowded thresholds): 7 frames, pipelined == serial --
+    the depth-2 pipeline (batch 1) and the image-batched look-ahead in groups of 2, 3 and 4 frames (last group ragged)."""
     from crowdsam.model import CrowdSAM
     from crowdsam.utils import DEFAULT_TEST_CONFIG
     from crowdsam_amd import synth
@@ -82,12 +84,38 @@ def test_pipelined_generate_equals_serial_full_model(cuda):
     cfg = {"environ": {"device": "cuda"}, "model": {"sam_model": "vit_l", "sam_arch": "crowdsam", "n_class": 1,
                                                      "trainfree": False}, "test": t}
     m = CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict("vit_l"), dino_state_dict=synth.make_dino_state_dict())
-    frames = [synth.synthetic_crowd_frame(i, 1024, 150) for i in range(4)]
+    frames = [synth.synthetic_crowd_frame(i, 1024, 150) for i in range(7)]
     np.random.seed(3)
     serial = [m.generate(f) for f in frames]
-    np.random.seed(3)
-    piped = list(m.generate_stream(frames))
     assert sum(len(o["boxes"]) for o in serial) > 200
-    for a, b in zip(serial, piped):
-        _same(a, b)
+    for batch in (1, 2, 3, 4):
+        np.random.seed(3)
+        piped = list(m.generate_stream(frames, batch=batch))
+        assert len(piped) == len(serial)
+        for a, b in zip(serial, piped):
+            _same(a, b)
     torch.cuda.synchronize()
+
+
+def test_pil_look_ahead_is_adopted(cuda):
+    """generate() takes PIL images (crowdsam/model.py:133-140): the look-ahead record remembers the caller's OBJECT, so a PIL
+    next_image is adopted by the next call (the ndarray identity check threw its encode away)."""
+    from PIL import Image
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG
+    from tests.test_pipeline_gpu import ARCH, GpuStandInDino, _config
+    m = CrowdSAM(_config(dict(PIPE_CFG)), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    frames = [Image.fromarray(synth.synthetic_crowd_frame(i, 1024, 60)[:768]) for i in range(2)]
+    np.random.seed(2)
+    serial = [m.generate(np.array(f)) for f in frames]
+    np.random.seed(2)
+    a = m.generate(frames[0], next_image=frames[1])
+    assert m._prefetched is not None and m._prefetched["src"] is frames[1]
+    adopted = []
+    orig = m.predictor.adopt_prefetched
+    m.predictor.adopt_prefetched = lambda b: (adopted.append(1), orig(b))[1]
+    b = m.generate(frames[1])
+    assert adopted == [1]
+    _same(a, serial[0])
+    _same(b, serial[1])

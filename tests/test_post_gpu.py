@@ -196,6 +196,45 @@ def test_rle_with_boxes_equals_full_scan(cuda):
     assert torch.equal(offs_c, offs_d) and torch.equal(pos_c[: int(offs_c[-1])], pos_d[: int(offs_d[-1])])
 
 
+@pytest.mark.parametrize("H,W", [(300, 512), (333, 517), (1024, 1024)])
+def test_device_coco_strings_equal_the_host_packer(cuda, H, W):
+    """csam_coco_rle_pack (round 5): COCO compressed-RLE strings packed on the device from the change positions must equal,
+    character for character, the host chain they replace -- run lengths from the positions (mask_to_rle_arrays, pinned to the
+    oracle's mask_to_rle by test_rle_matches_oracle) through the C string packer (pinned to hand-computed pycocotools strings
+    by test_host_logic_cpu).  Noise (1e5+ runs per mask: the frame that stalled rounds 3-4's host path), blobs, an empty and a
+    full mask, masks whose pixel (0, 0) is set (leading zero-length run), a single pixel at either end, slot lists, boxes."""
+    from oracle import pipeline_oracle as po
+    from segment_anything_cs.utils.amg import coco_encode_rles, mask_to_coco_rles, mask_to_rle_arrays
+    rs = np.random.RandomState(H + W)
+    masks = np.zeros((11, H, W), bool)
+    masks[0] = rs.rand(H, W) > 0.5                                            # salt and pepper
+    masks[1] = rs.rand(H, W) > 0.97
+    low = _smooth_logits(1, 33)
+    masks[2:5] = (torch.nn.functional.interpolate(low, (H, W), mode="bilinear")[0, :3] > 0.3).numpy()
+    masks[3, 0, 0] = True
+    masks[5] = True                                                           # 4: blob, 5: full, 6: empty
+    masks[7, 0, 0] = True                                                     # one pixel at the very start ...
+    masks[8, H - 1, W - 1] = True                                             # ... and at the very end
+    masks[9, H // 3: 2 * H // 3, W // 4: W // 2] = True                       # a rectangle: long equal runs (the k - 2 differencing)
+    masks[10] = ~masks[0]
+    m8 = torch.as_tensor(masks).to(torch.uint8).to(cuda).contiguous()
+    ref = [r["counts"] for r in coco_encode_rles(mask_to_rle_arrays(m8))]
+    got = mask_to_coco_rles(m8)
+    assert [r["size"] for r in got] == [[H, W]] * 11
+    assert [r["counts"] for r in got] == ref
+    assert sum(len(c) for c in ref) > 50000
+    boxes = po.batched_mask_to_box(torch.as_tensor(masks)).to(cuda)
+    assert [r["counts"] for r in mask_to_coco_rles(m8, boxes=boxes)] == ref
+    idx = torch.as_tensor(np.array([10, 3, 6, 5, 0, 7], np.int32)).to(cuda)
+    sub = mask_to_coco_rles(m8, idx=idx, boxes=boxes[idx.long()])
+    assert [r["counts"] for r in sub] == [ref[i] for i in idx.tolist()]
+    # already-packed entries pass through coco_encode_rles unchanged (crowdsam.model hands them over like that)
+    assert coco_encode_rles(got) == got
+    # decodes to the mask (oracle's own decoder of the COCO string)
+    for i in (2, 3, 7, 8):
+        assert np.array_equal(po.coco_rle_decode(got[i]["counts"], H, W), masks[i])
+
+
 @pytest.mark.parametrize("w", [516, 517])
 def test_rle_of_non_boolean_bytes_is_the_rle_of_their_truth_value(cuda, w):
     """the 4-column kernels (W % 4 == 0) compare bit 0 of packed bytes, the scalar ones raw bytes; both are only

@@ -4,7 +4,7 @@
 #   bash tools/dev_pipeline_timeline.sh [--serial]   -> gpurun_out/r04_pipeline_timeline[_serial].txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$R TMPDIR=/tmp
-TAG=r04_pipeline_timeline$( [ "$1" == "--serial" ] && echo _serial )
+TAG=r05_pipeline_timeline$( [ "$1" == "--serial" ] && echo _serial )$( [ "$1" == "--batch" ] && echo _b$2 )
 cd /tmp && rm -rf /tmp/ptl && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/ptl -o t -- \
   python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timer --crowd-keep 720 "$@" > /tmp/ptl.log 2>&1
 F=$(find /tmp/ptl -name "*kernel_trace.csv" | head -1)
@@ -22,7 +22,10 @@ qkey = "Queue_Id" if "Queue_Id" in rows[0] else ("Stream_Id" if "Stream_Id" in r
 ups = [i for i, r in enumerate(rows) if r["n"] == "upscale_stream_kernel"]
 print("images traced:", len(ups))
 TAIL = ("cc2_", "cc_", "rle_", "nms_", "mask_pack", "mask_cov")
-for k in range(len(ups) - 6, len(ups) - 1):            # timed, pipelined frames (not the first, not the last)
+# launches 0-7 = rehearsal of the pipelined loop, 8-10 = warm-up, 11-18 = the 8 timed frames, then the serial / collapsed legs
+for k in range(11, 19):                                # the timed frames
+    if k + 1 >= len(ups):
+        break
     a, b = ups[k], ups[k + 1]
     seg = rows[a:b]
     t0, t1 = seg[0]["s"], rows[b]["s"]
@@ -50,7 +53,7 @@ for k in range(len(ups) - 6, len(ups) - 1):            # timed, pipelined frames
     agg = collections.defaultdict(float)
     for r in seg:
         agg[r["n"]] += (r["e"] - r["s"]) / 1e6
-    if k == len(ups) - 3:
+    if k == 15:
         for n, v in sorted(agg.items(), key=lambda kv: -kv[1])[:22]:
             print("      %-36s %7.3f ms" % (n, v))
 PY
