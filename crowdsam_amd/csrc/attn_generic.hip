@@ -187,10 +187,7 @@ extern "C" int csam_softmax_relpos(void* stream, const float* S, const float* re
                                    int T_valid, int side, float inv_scale) {
   CSAM_REQUIRE(S && relpos_raw && P_f16 && G > 0 && G <= 65535 && Tp > 0 && T_valid <= Tp && side > 0,
                "csam_softmax_relpos: bad args");
-  static const bool three_pass = [] {                  // developer A/B: CSAM_SOFTMAX_RELPOS=0 -> the three-pass kernel
-    const char* e = getenv("CSAM_SOFTMAX_RELPOS");
-    return e && e[0] == '0';
-  }();
+  const bool three_pass = false;                         // the row-in-registers kernels where they exist (round 3)
   if (!three_pass && Tp == 256)                          // a padded 14 x 14 window: 4 scores per lane, 4 rows per wave
     hipLaunchKernelGGL((softmax_relpos_reg_kernel<4, false, 4>), dim3(csam_cdiv(Tp, 16), G), dim3(256), 0, (hipStream_t)stream, S,
                        relpos_raw, (half_t*)P_f16, Tp, T_valid, side, inv_scale);

@@ -17,7 +17,6 @@
 // feed needs the out-proj weight columns permuted on the host:
 //     k' = s*32 + g*8 + e   <->   k = (2s + (e>=4))*16 + g*4 + (e&3).
 #include "csam_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -675,21 +674,10 @@ extern "C" int csam_i2t_stream(void* stream, const void* X_f16, long x_prompt_st
   a.Wo = (const half_t*)Wo_f16; a.bo = bo; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out = (half_t*)out_f16; a.T = T;
   const int n_cu = csam_cu_count();
-  static int nw_q = 0, nw_p = 4;
-  if (!nw_q) {
-    nw_q = 4;
-    const char* e = getenv("CSAM_I2T_NW");            // "<hoisted-Q form><projected form>", e.g. 48
-    if (e && (e[0] == '4' || e[0] == '8' || e[0] == '2')) nw_q = e[0] - '0';   // '2' = 4 waves, 32-token tiles
-    if (e && e[0] && (e[1] == '4' || e[1] == '8')) nw_p = e[1] - '0';
-  }
-  if (Wq_f16) {
-    if (nw_p == 4) i2t_stream_launch<1, 4, 2>(a, B, n_cu, (hipStream_t)stream);       // 32-token tiles (Wq + Wo = 128 VGPRs)
-    else i2t_stream_launch<1, 8, 8>(a, B, n_cu, (hipStream_t)stream);
-  } else {
-    if (nw_q == 2) i2t_stream_launch<0, 4, 2>(a, B, n_cu, (hipStream_t)stream);
-    else if (nw_q == 4) i2t_stream_launch<0, 4, 4>(a, B, n_cu, (hipStream_t)stream);
-    else i2t_stream_launch<0, 8, 8>(a, B, n_cu, (hipStream_t)stream);
-  }
+  // 4 waves: 32-token tiles in the projected form (Wq + Wo = 128 VGPRs), 64-token tiles with the hoisted Q (the 8-wave and
+  // 32-token hoisted variants measured slower: profiles/r02_*; they remain template instances of the tests only)
+  if (Wq_f16) i2t_stream_launch<1, 4, 2>(a, B, n_cu, (hipStream_t)stream);
+  else i2t_stream_launch<0, 4, 4>(a, B, n_cu, (hipStream_t)stream);
   CSAM_LAUNCH_CHECK("csam_i2t_stream");
   return CSAM_OK;
 }
@@ -1012,15 +1000,7 @@ extern "C" int csam_i2t_rank(void* stream, const void* X_f16, long x_prompt_stri
   a.X = (const half_t*)X_f16; a.x_bstride = x_prompt_stride; a.Q = (const half_t*)Q_f16; a.q_bstride = q_prompt_stride;
   a.ks = (const half_t*)k_scaled_f16; a.M = (const half_t*)workspace; a.Kp = nullptr; a.bo = bo; a.gamma = gamma;
   a.beta = beta; a.eps = eps; a.out = (half_t*)out_f16; a.B = B; a.T = T;
-  static const int nw = [] {                          // developer A/B: 8 = one 8-wave workgroup per CU
-    const char* e = getenv("CSAM_I2T_RANK_NW");
-    return e && e[0] == '8' ? 8 : 4;
-  }();
-  if (nw == 8) {
-    const int per = csam_cdiv(B, n_cu);
-    constexpr int smem = IR<false, 8>::SMEM;
-    hipLaunchKernelGGL((i2t_rank_kernel<false, 8>), dim3(csam_cdiv(B, per)), dim3(512), smem, (hipStream_t)stream, a, per);
-  } else {
+  {
     const int per = csam_cdiv(B, 2 * n_cu);
     constexpr int smem = IR<false, 4>::SMEM;
     hipLaunchKernelGGL((i2t_rank_kernel<false, 4>), dim3(csam_cdiv(B, per)), dim3(256), smem, (hipStream_t)stream, a, per);
@@ -1110,8 +1090,6 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // wave owns 64 channels x 64 tokens.  Two workgroups are co-resident per CU (LDS 78.5 KB, 2 waves/SIMD), so
 // one's GEMM1 load latency and store tail hide behind the other's LN/GELU/GEMM2 phases (the single 8-wave
 // workgroup per CU this replaces idled there: measured 3.35 -> ms per 1024 prompts).
-// ABL: developer ablation (compile-time, CSAM_DBG env picks the instantiation): 1 = no phases 2-4, 2 = no GEMM1
-template <int ABL>
 __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1173,11 +1151,9 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) a1[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int coff = (fg ^ (3 * ((fr >> 2) & 1))) << 4;
-  if (ABL != 2) {
-    stage(0, 0);
-    stage(1, 32);
-  }
-  if (ABL != 2) {
+  stage(0, 0);
+  stage(1, 32);
+  {
     int cur = 0;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -1292,9 +1268,7 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
       }
     }
   };
-  if (ABL == 1) {
-    outs[tid] = a1[0][0][0] + a1[1][1][1] + a1[2][2][2] + a1[3][3][3];
-  } else {
+  {
     half8_t xfa[2], xfb[2];
     floatx4 a2a[8], a2b[8];
     ln_gelu(0, xfa);
@@ -1354,43 +1328,10 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
 // =====================================================================================================
 namespace {
 
-// GELU of 4 channel pairs: packed (v_pk_fma_f32) or, with -DCSAM_SCALAR_GELU (+ -fno-slp-vectorize), 8 scalar chains
-#if defined(CSAM_UP_NOGELU)      /* developer ablation builds (CSAM_DEFS_decoder_fused, crowdsam_amd/build.py) */
-#define CSAM_UP_GELU4(z) do { } while (0)
-#elif defined(CSAM_SCALAR_GELU)
-#define CSAM_UP_GELU4(z)                                                        \
-  do {                                                                          \
-    float zz__[8];                                                              \
-    _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__) {                       \
-      zz__[2 * q__] = (z)[q__][0];                                              \
-      zz__[2 * q__ + 1] = (z)[q__][1];                                          \
-    }                                                                           \
-    csam_gelu_poly1_n<8>(zz__);                                                 \
-    _Pragma("unroll") for (int q__ = 0; q__ < 4; ++q__)(z)[q__] = float2_t{zz__[2 * q__], zz__[2 * q__ + 1]}; \
-  } while (0)
-#else
-#define CSAM_UP_GELU4(z) csam_gelu_poly2_n<4>(z)
-#endif
-
-#ifndef CSAM_UP_XDEPTH
+// GELU of 4 channel pairs at once: four interleaved packed Horner chains (csam_common.h).  Scalar chains, wave priorities by
+// phase and a rank-112 first conv at three waves per SIMD were measured in round 4 and are gone: profiles/r04_valu_rate.txt,
+// r04_upscale_prio.txt, r04_upscale_rank_probe.txt
 #define CSAM_UP_XDEPTH 3
-#endif
-// developer A/B (CSAM_DEFS_decoder_fused=-DCSAM_UP_PRIO=n): wave priority by phase.  1: the MFMA groups (both convs) run at
-// s_setprio 2 and the LayerNorm / GELU streams at 0, so the co-resident wave's matrix work is issued the moment it is ready
-// and the VALU stream fills what is left; 2: the inverse.  Measured: profiles/r04_upscale_prio.txt
-#ifndef CSAM_UP_PRIO
-#define CSAM_UP_PRIO 0
-#endif
-#if CSAM_UP_PRIO == 1
-#define UP_PRIO_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(2); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define UP_PRIO_V() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif CSAM_UP_PRIO == 2
-#define UP_PRIO_M() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define UP_PRIO_V() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(2); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define UP_PRIO_M() do { } while (0)
-#define UP_PRIO_V() do { } while (0)
-#endif
 constexpr int US_TOK = 32;
 constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
 constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
@@ -1404,17 +1345,9 @@ constexpr int US_SMEM = US_WMX + 64;
 // with K = 128 (the rank-112 form of DESIGN.md §8(7): 64 registers of per-prompt operand instead of 128 of W1) plus the per-image
 // table added to the accumulators, at THREE workgroups per CU.  Numerically meaningless (it multiplies half the key channels
 // and adds the other half): it answers "does a third wave per SIMD pay" before the producer chain is rebuilt for it.
-#ifdef CSAM_UP_RANKPROBE
-#define US_WG_PER_CU CSAM_UP_RANKPROBE        /* -DCSAM_UP_RANKPROBE=3 (or 2: the mix alone, at today's occupancy) */
-#define US_KS 4
-#define US_MG 1                               /* one 16-token sub-tile through BOTH convs at a time: half the live accumulators */
-#else
 #define US_WG_PER_CU 2
 #define US_KS 8
-#endif
-#ifndef US_MG
 #define US_MG 2                               /* 16-token sub-tiles that share one pass over W2' */
-#endif
 // tiles_per_wg > 0 (round 4, batches that cannot give every workgroup whole prompts): the workgroup walks a RANGE of 32-token
 // tiles that may start and end inside a prompt; the per-plane maxima then go to stats by atomic max (csam_upscale_fused's
 // protocol: the launcher initialises stats first)
@@ -1468,9 +1401,6 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
     for (int i = 0; i < 4; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
   };
 
-#if CSAM_UP_PRIO == 3   /* static priority by dispatch round: the two workgroups of a CU stop competing symmetrically */
-  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(2);
-#endif
   half8_t hhi, hlo;
   float pmax0 = -INFINITY, pmax1 = -INFINITY;        // running max of the planes this thread stores (l0, l0 + 2)
   issue_x(first, 0);
@@ -1499,12 +1429,10 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
     // (a) tile t landed (retired at barrier (b) of the previous tile, before its stores); outs free again
     I2S_BARRIER();
     if (t + 1 < last) issue_x(t + 1, cur ^ 1);
-#ifndef CSAM_UP_RANKPROBE
     if (newp) {
       hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
       hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
     }
-#endif
 
     // ---- GEMM1 + LayerNorm2d + GELU per 16-token sub-tile: [64 co of this position] x [16 tokens], K = 256.
     // The ablation (r02) showed the GEMM1 phase at twice its MFMA time: with one fragment set in flight the
@@ -1520,8 +1448,6 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
       floatx4 a1[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
-#ifndef CSAM_UP_NOG1
-      UP_PRIO_M();
       {
         constexpr int XD = CSAM_UP_XDEPTH;              // fragment sets in flight
         half8_t xf[XD];
@@ -1536,30 +1462,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
             a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
           asm volatile("" ::: "memory");
         }
-#ifdef CSAM_UP_RANKPROBE
-        {
-          const half8_t tf0 = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((16 + fg * 2) ^ fr) << 4));
-          const half8_t tf1 = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((17 + fg * 2) ^ fr) << 4));
-          const float r0 = 1.0f + 1e-3f * (float)tf0[0];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              a1[ni][e] = __builtin_fmaf((float)(ni < 2 ? tf0 : tf1)[(ni & 1) * 4 + e], r0, a1[ni][e]);
-        }
-#endif
       }
-#else
-#ifdef CSAM_UP_NOG1_PIN      /* ablation: no GEMM1, but the 128 registers of the W1 slice stay live */
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        asm volatile("" ::"v"(w1[ni][0]), "v"(w1[ni][1]), "v"(w1[ni][2]), "v"(w1[ni][3]), "v"(w1[ni][4]), "v"(w1[ni][5]),
-                     "v"(w1[ni][6]), "v"(w1[ni][7]));
-#else
-      asm volatile("" ::"v"(w1[0][0]), "v"(w1[3][7]), "v"(xb));
-#endif
-#endif
-      UP_PRIO_V();
       // LayerNorm2d statistics over the 64 channels of a pixel: in-lane partial sums (16 channels, packed), the
       // four lane groups reduced by an fp32 ones-MFMA (every lane of the token receives the totals)
       float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
@@ -1593,7 +1496,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
             z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
           }
         }
-        CSAM_UP_GELU4(z);
+        csam_gelu_poly2_n<4>(z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
           xf2[m][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
@@ -1612,7 +1515,6 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
 #pragma unroll
         for (int m = 0; m < US_MG; ++m) a2[m][n2] = b2v;
       }
-      UP_PRIO_M();
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -1623,11 +1525,6 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
           for (int m = 0; m < US_MG; ++m) a2[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[m][s2], a2[m][n2], 0, 0, 0);
         }
       }
-      UP_PRIO_V();
-#ifdef CSAM_UP_RANKPROBE
-      hhi = *(const half8_t*)(smem + US_HFR + lane * 16);
-      hlo = *(const half8_t*)(smem + US_HFR + 1024 + lane * 16);
-#endif
 #pragma unroll
       for (int p2 = 0; p2 < 2; ++p2) {
         const int pos2 = ph * 2 + p2;
@@ -1639,19 +1536,15 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
           for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int e = 0; e < 4; e += 2) z[h2 * 2 + (e >> 1)] = (float2_t){a2[m][p2 * 2 + h2][e], a2[m][p2 * 2 + h2][e + 1]};
-          CSAM_UP_GELU4(z);
+          csam_gelu_poly2_n<4>(z);
           half8_t ub;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             ub[q * 2] = (half_t)z[q][0];
             ub[q * 2 + 1] = (half_t)z[q][1];
           }
-#ifndef CSAM_UP_NOHYP
           floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
-#else
-          floatx4 m4 = {(float)ub[0], (float)ub[2], (float)ub[4], (float)ub[6]};
-#endif
           if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
             const int yy = (pos >> 1) * 2 + (pos2 >> 1);
             const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
@@ -1672,11 +1565,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
         const int l = rowid >> 2, yy = rowid & 3;
         char* dst = (char*)(p.masks + (((long)b * 4 * 256) + 4 * i0) * 256 + half * 128);     // uniform base
         const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
-#ifndef CSAM_UP_NOSTORE
         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");   // see i2s_store16
-#else
-        asm volatile("" ::"v"(voff), "s"(dst));
-#endif
         const float mxv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
         if (it == 0) pmax0 = fmaxf(pmax0, mxv);
         else pmax1 = fmaxf(pmax1, mxv);
@@ -1707,310 +1596,8 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
 
 
 // -----------------------------------------------------------------------------------------------------
-// upscale_ws_kernel (round 4): csam_upscale_stream with SPECIALISED waves.  PMC / ablations of upscale_stream_kernel:
-// VALU-pipe-bound on the two polynomial GELUs, the MFMA time of its two mixed waves per SIMD is not hidden (every
-// component costs its own pipe time).  Here ONE 8-wave workgroup per CU: waves 0-3 are the MATRIX waves (the stream
-// kernel's wave: first-conv position, W1 slice in registers, both convs, LayerNorm2d + the first GELU, hyper product),
-// waves 4-7 are VALU waves that evaluate the SECOND GELU (2/3 of the evaluations) for the matrix wave on their SIMD.
-// Hand-over = a lane-private LDS mailbox: matrix lane L writes its 64 second-conv outputs of a 32-token tile as fp16
-// (8 x 16 B, conflict-free), VALU lane L turns them into GELU values IN PLACE, matrix lane L reads back exactly the fp16
-// B fragments of the hyper product.  No layout change, no exchange between lanes; 2 x 32 KB of mailbox for tiles t, t+1.
-// Software pipeline per step s (one workgroup barrier pair per 32-token tile, as before):
-//     matrix wave:  conv2(s) -> mailbox[s&1] | conv1 + LayerNorm2d + GELU(s+1) | hyper product(s-1) <- mailbox[(s-1)&1]
-//     VALU wave  :  GELU of mailbox[(s-1)&1] (tile s-1), then its done-flag
-// so the VALU wave always works on data that was complete at the step's first barrier and has the matrix wave's whole
-// step to finish; the matrix wave polls the done-flag before it reads back (normally long set).  The second conv's
-// output crosses the mailbox as fp16 (one more rounding before the GELU, which rounds to fp16 anyway).
-// -----------------------------------------------------------------------------------------------------
-constexpr int UW_W2S = 2 * US_BUF;                 // W2' 16 KB
-constexpr int UW_OUT = UW_W2S + 16 * 1024;         // [16 rows][128 px] fp32 = 8 KB
-constexpr int UW_PAR = UW_OUT + 8 * 1024;          // b2 [128] | b1 [256] | ln_g [64] | ln_b [64] fp32 = 2 KB
-constexpr int UW_WMX = UW_PAR + 2048;              // [4 waves][2]
-constexpr int UW_FLG = UW_WMX + 64;                // int [2 regions][4 positions]: tile whose GELU is complete
-constexpr int UW_MBX = UW_FLG + 64;                // mailbox [2 regions][4 positions][8 chunks][64 lanes][16 B]
-constexpr int UW_SMEM = UW_MBX + 2 * 4 * 8192;
-
-__global__ __launch_bounds__(512, 1) void upscale_ws_kernel(UpArgs p, int B, int prompts_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_m = wave < 4;
-  const int pos = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-  constexpr int TPP = 4096 / US_TOK;                 // 128 tiles per prompt
-  const int b_first = blockIdx.x * prompts_per_wg;
-  const int b_last = min(b_first + prompts_per_wg, B);
-  if (b_first >= b_last) return;
-  const int first = b_first * TPP, last = b_last * TPP;
-  volatile int* flags = (volatile int*)(smem + UW_FLG);
-  if (tid < 8) flags[tid] = -1;
-  char* mbx = smem + UW_MBX + pos * 8192 + lane * 16;          // + region * 32768 + chunk * 1024
-
-  if (!is_m) {
-    // ================================ VALU wave: second GELU of tile s-1, in place =================================
-    for (int s = first - 1; s <= last; ++s) {
-      I2S_BARRIER();                                            // (a)
-      const int t = s - 1;
-      if (t >= first && t < last) {
-        char* mb = mbx + (t & 1) * 32768;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {                        // two chunks (8 channel pairs) in flight
-          half8_t h0 = *(const half8_t*)(mb + j * 1024);
-          half8_t h1 = *(const half8_t*)(mb + (j + 1) * 1024);
-          float2_t z0[4], z1[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            z0[q] = float2_t{(float)h0[2 * q], (float)h0[2 * q + 1]};
-            z1[q] = float2_t{(float)h1[2 * q], (float)h1[2 * q + 1]};
-          }
-#if !defined(CSAM_WS_ABL) || CSAM_WS_ABL != 1   /* developer ablation 1: the VALU waves only move the bytes */
-          CSAM_UP_GELU4(z0);
-          CSAM_UP_GELU4(z1);
-#endif
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            h0[2 * q] = (half_t)z0[q][0];
-            h0[2 * q + 1] = (half_t)z0[q][1];
-            h1[2 * q] = (half_t)z1[q][0];
-            h1[2 * q + 1] = (half_t)z1[q][1];
-          }
-          *(half8_t*)(mb + j * 1024) = h0;
-          *(half8_t*)(mb + (j + 1) * 1024) = h1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) flags[(t & 1) * 4 + pos] = t;
-      }
-      I2S_BARRIER();                                            // (b)
-      if (t >= first && p.stats && (t % TPP) == TPP - 1) I2S_BARRIER();   // the matrix waves' per-prompt max exchange
-    }
-    return;
-  }
-
-  // ===================================== matrix wave (first-conv position pos) ====================================
-  const unsigned xoff = ((tid >> 5) * 256 + (((tid & 31) ^ ((tid >> 5) & 15)) * 8)) * 2;   // see i2t_stream_kernel
-  constexpr int PIECE = 256 * 16;
-  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
-  half8_t w1[4][US_KS];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int ks = 0; ks < US_KS; ++ks)
-      w1[ni][ks] = *(const half8_t*)(p.W1 + (long)(pos * 64 + ni * 16 + fr) * 256 + ks * 32 + fg * 8);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {                   // W2': 128 rows x 8 slots, 128-B rows, slot ^= row & 7
-    const int cc = tid + it * 256;
-    const int row = cc >> 3, sl = cc & 7;
-    glds16(p.W2 + (long)row * 64 + ((sl ^ (row & 7)) * 8), smem + UW_W2S + (cc & ~63) * 16);
-  }
-  float* par = (float*)(smem + UW_PAR);
-  if (tid < 128) par[tid] = p.b2[tid];
-  par[128 + tid] = p.b1[tid];
-  if (tid < 64) {
-    par[384 + tid] = p.ln_g[tid];
-    par[448 + tid] = p.ln_b[tid];
-  }
-  float* outs = (float*)(smem + UW_OUT);
-  float* wmx = (float*)(smem + UW_WMX);
-
-  auto issue_x = [&](int t, int buf) {
-    const char* src = (const char*)(p.X + (long)t * US_TOK * 256);
-    const unsigned dst = lds0 + buf * US_BUF + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) i2s_glds16(src + i * PIECE, xoff ^ ((i & 1) << 7), dst + i * PIECE);
-  };
-
-  half8_t hhi = {0, 0, 0, 0, 0, 0, 0, 0}, hlo = hhi;
-  half8_t xf2[2][2];
-  float pmax0 = -INFINITY, pmax1 = -INFINITY;        // running max of the planes this thread stores (l0, l0 + 2)
-  issue_x(first, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int s = first - 1; s <= last; ++s) {
-    // (a) tile s+1 landed (retired before barrier (b) of the previous step); outs and mailbox[s&1] are free again
-    I2S_BARRIER();
-    if (s + 2 < last) issue_x(s + 2, (s + 2 - first) & 1);
-
-    // ---- (1) second conv of tile s (its fp16 activations xf2 were made in the previous step) -> mailbox[s&1]
-    if (s >= first && s < last) {
-      char* mb = mbx + (s & 1) * 32768;
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        floatx4 a2[2][4];                                 // seeded with the second conv's bias
-#pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) {
-          const floatx4 b2v = *(const floatx4*)(par + (ph * 4 + n2) * 16 + fg * 4);
-          a2[0][n2] = b2v;
-          a2[1][n2] = b2v;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-          for (int n2 = 0; n2 < 4; ++n2) {
-            const int row = (ph * 4 + n2) * 16 + fr;
-            const half8_t wf = *(const half8_t*)(smem + UW_W2S + row * 128 + (((s2 * 4 + fg) ^ (row & 7)) << 4));
-            a2[0][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[0][s2], a2[0][n2], 0, 0, 0);
-            a2[1][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf2[1][s2], a2[1][n2], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            half8_t hv;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) hv[h2 * 4 + e] = (half_t)a2[mi][p2 * 2 + h2][e];
-            *(half8_t*)(mb + (ph * 4 + p2 * 2 + mi) * 1024) = hv;
-          }
-      }
-    }
-
-    // ---- (2) first conv + LayerNorm2d + GELU of tile s+1 -> xf2 (registers)
-#if defined(CSAM_WS_ABL) && CSAM_WS_ABL == 2      /* developer ablation 2: no first conv / LayerNorm / first GELU */
-    if (s + 1 < last) {
-      xf2[0][0] = w1[0][0]; xf2[0][1] = w1[1][1]; xf2[1][0] = w1[2][2]; xf2[1][1] = w1[3][3];
-    } else
-#endif
-    if (s + 1 < last) {
-      const char* xb = smem + ((s + 1 - first) & 1) * US_BUF;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        floatx4 a1[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) a1[ni] = *(const floatx4*)(par + 128 + pos * 64 + ni * 16 + fg * 4);
-        {
-          constexpr int XD = CSAM_UP_XDEPTH;              // fragment sets in flight
-          half8_t xf[XD];
-#pragma unroll
-          for (int ks = 0; ks < XD - 1; ++ks) xf[ks] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
-#pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            if (ks + XD - 1 < 8)
-              xf[(ks + XD - 1) % XD] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + ((((ks + XD - 1) * 4 + fg) ^ fr) << 4));
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-              a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
-            asm volatile("" ::: "memory");
-          }
-        }
-        float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const float2_t lo = {a1[ni][0], a1[ni][1]}, hi = {a1[ni][2], a1[ni][3]};
-          s2 += lo;
-          q2 = __builtin_elementwise_fma(lo, lo, q2);
-          s2 += hi;
-          q2 = __builtin_elementwise_fma(hi, hi, q2);
-        }
-        const floatx4 ssum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, s2[0] + s2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const float mean = ssum[0] * (1.f / 64.f);
-        const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + p.eps);
-        const float nmr = -mean * rstd;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time
-          float2_t z[4];
-#pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) {
-            const int ni = nh * 2 + n2;
-            const floatx4 gv = *(const floatx4*)(par + 384 + ni * 16 + fg * 4);
-            const floatx4 bv = *(const floatx4*)(par + 448 + ni * 16 + fg * 4);
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-              const float2_t av = {a1[ni][e], a1[ni][e + 1]};
-              const float2_t g2 = {gv[e], gv[e + 1]}, b2 = {bv[e], bv[e + 1]};
-              const float2_t nrm = __builtin_elementwise_fma(av, (float2_t){rstd, rstd}, (float2_t){nmr, nmr});
-              z[n2 * 2 + (e >> 1)] = __builtin_elementwise_fma(nrm, g2, b2);
-            }
-          }
-          CSAM_UP_GELU4(z);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {                 // ni = nh*2 + (q>>1), e = (q&1)*2 -> xf2[nh][(ni&1)*4 + e ..]
-            xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2] = (half_t)z[q][0];
-            xf2[mi][nh][(q >> 1) * 4 + (q & 1) * 2 + 1] = (half_t)z[q][1];
-          }
-        }
-      }
-    }
-
-    // ---- (3) hyper product of tile s-1 from the mailbox the VALU wave has turned into GELU values
-    const int th = s - 1;
-    const int bh = th / TPP, tph = th - bh * TPP;
-    if (th >= first) {
-      if (th == first || tph == 0) {                 // new prompt: hyper-network A fragments (hi / lo fp16 split)
-        half8_t hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (fr < 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int cch = ((e >= 4) ? 16 : 0) + fg * 4 + (e & 3);
-            const float h = p.hyper[((long)bh * 4 + fr) * 32 + cch];
-            hi[e] = (half_t)h;
-            lo[e] = (half_t)(h - (float)hi[e]);
-          }
-        }
-        hhi = hi;
-        hlo = lo;
-      }
-#if !defined(CSAM_WS_ABL) || CSAM_WS_ABL != 3   /* developer ablation 3: the matrix wave does not wait for the VALU wave */
-      while (flags[(th & 1) * 4 + pos] != th) __builtin_amdgcn_s_sleep(1);
-#endif
-      const char* mb = mbx + (th & 1) * 32768;
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2) {
-          const int pos2 = ph * 2 + p2;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const half8_t ub = *(const half8_t*)(mb + (ph * 4 + p2 * 2 + mi) * 1024);
-            floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
-            if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
-              const int yy = (pos >> 1) * 2 + (pos2 >> 1);
-              const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
-#pragma unroll
-              for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
-            }
-          }
-        }
-    }
-    // (b) output half-rows complete; also retires the LDS-DMA of tile s+2 BEFORE this step's stores
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (th >= first) {
-      const int i0 = tph >> 1, half = tph & 1;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int rowid = it * 8 + (tid >> 5), x4 = tid & 31;      // rowid = l*4 + yy
-        const floatx4 v = *(const floatx4*)(outs + rowid * 128 + x4 * 4);
-        const int l = rowid >> 2, yy = rowid & 3;
-        char* dst = (char*)(p.masks + (((long)bh * 4 * 256) + 4 * i0) * 256 + half * 128);    // uniform base
-        const unsigned voff = (unsigned)(l * 65536 + yy * 256 + x4 * 4) * 4u;                 // plane, row, pixel
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");   // see i2s_store16
-        const float mxv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (it == 0) pmax0 = fmaxf(pmax0, mxv);
-        else pmax1 = fmaxf(pmax1, mxv);
-      }
-      if (tph == TPP - 1 && p.stats) {               // prompt complete: per-plane max (planes l0 = tid>>7 and l0 + 2)
-        const float m0 = csam_wave_max(pmax0), m1 = csam_wave_max(pmax1);
-        if (lane == 0) {
-          wmx[wave * 2] = m0;
-          wmx[wave * 2 + 1] = m1;
-        }
-        I2S_BARRIER();
-        if (tid < 4) {   // plane tid: waves (tid & 1) * 2 and +1 hold it, slot tid >> 1
-          const int w0 = (tid & 1) * 2, sl = tid >> 1;
-          const float m = fmaxf(wmx[w0 * 2 + sl], wmx[(w0 + 1) * 2 + sl]);
-          p.stats[((long)bh * 4 + tid) * 2] = m;
-          p.stats[((long)bh * 4 + tid) * 2 + 1] = 0.f;
-        }
-        pmax0 = -INFINITY;
-        pmax1 = -INFINITY;
-      }
-    }
-  }
-}
-
+// (Round 4 built this kernel with SPECIALISED waves -- 4 matrix waves + 4 GELU waves per CU, lane-private LDS mailbox -- and
+// measured it slower, 4.55 vs 3.87 ms per 2048 prompts: profiles/r04_upscale_wave_specialised.txt, DESIGN.md 4.2e.  The code is gone.)
 }  // namespace
 
 __global__ void stats_init_kernel(float* stats, int rows) {
@@ -2033,20 +1620,10 @@ extern "C" int csam_upscale_fused(void* stream, const void* keys_f16, const void
   if (stats_or_null)
     hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null,
                        B * 4);
-  static int abl = -1;
-  if (abl < 0) {
-    const char* e = getenv("CSAM_DBG");
-    abl = e ? atoi(e) : 0;
-  }
   static csam_once_t attr_set;
-  if (csam_first_call(attr_set)) {
-    hipFuncSetAttribute((const void*)upscale_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
-    hipFuncSetAttribute((const void*)upscale_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
-    hipFuncSetAttribute((const void*)upscale_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
-  }
-  if (abl == 1) hipLaunchKernelGGL(upscale_fused_kernel<1>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
-  else if (abl == 2) hipLaunchKernelGGL(upscale_fused_kernel<2>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(upscale_fused_kernel<0>, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
+  if (csam_first_call(attr_set))
+    hipFuncSetAttribute((const void*)upscale_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_SMEM);
+  hipLaunchKernelGGL(upscale_fused_kernel, dim3(64, B), dim3(256), UP_SMEM, (hipStream_t)stream, a);
   CSAM_LAUNCH_CHECK("csam_upscale_fused");
   return CSAM_OK;
 }
@@ -2062,28 +1639,16 @@ extern "C" int csam_upscale_stream(void* stream, const void* keys_f16, const voi
   a.stats = stats_or_null;
   static csam_once_t once;
   const int n_cu = csam_cu_count();
-  if (csam_first_call(once)) {
+  if (csam_first_call(once))
     (void)hipFuncSetAttribute((const void*)upscale_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, US_SMEM);
-    (void)hipFuncSetAttribute((const void*)upscale_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UW_SMEM);
-  }
-  static int ws = -1;                                 // CSAM_UP_WS=1: the wave-specialised kernel (round-4 experiment, measured
-  if (ws < 0) {                                       // slower: profiles/r04_upscale_wave_specialised.txt); default = mixed waves
-    const char* e = getenv("CSAM_UP_WS");
-    ws = e ? atoi(e) : 0;
-  }
-  if (ws) {
-    const int per = csam_cdiv(B, n_cu);               // ONE 8-wave workgroup per CU (4 matrix + 4 VALU waves)
-    hipLaunchKernelGGL(upscale_ws_kernel, dim3(csam_cdiv(B, per)), dim3(512), UW_SMEM, (hipStream_t)stream, a, B, per);
+  if (B < US_WG_PER_CU * n_cu) {                       // fewer prompts than resident workgroups: ranges of tiles instead
+    const int tiles = B * (4096 / US_TOK), tpw = csam_cdiv(tiles, US_WG_PER_CU * n_cu);
+    if (stats_or_null)
+      hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null, B * 4);
+    hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(tiles, tpw)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, 0, tpw);
   } else {
-    if (B < US_WG_PER_CU * n_cu) {                     // fewer prompts than resident workgroups: ranges of tiles instead
-      const int tiles = B * (4096 / US_TOK), tpw = csam_cdiv(tiles, US_WG_PER_CU * n_cu);
-      if (stats_or_null)
-        hipLaunchKernelGGL(stats_init_kernel, dim3(csam_cdiv(B * 4, 256)), dim3(256), 0, (hipStream_t)stream, stats_or_null, B * 4);
-      hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(tiles, tpw)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, 0, tpw);
-    } else {
-      const int per = csam_cdiv(B, US_WG_PER_CU * n_cu);
-      hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per, 0);
-    }
+    const int per = csam_cdiv(B, US_WG_PER_CU * n_cu);
+    hipLaunchKernelGGL(upscale_stream_kernel, dim3(csam_cdiv(B, per)), dim3(256), US_SMEM, (hipStream_t)stream, a, B, per, 0);
   }
   CSAM_LAUNCH_CHECK("csam_upscale_stream");
   return CSAM_OK;
@@ -2680,9 +2245,7 @@ __global__ __launch_bounds__(256) void t2i_rank_prep_kernel(const half_t* __rest
   }
 }
 
-#ifndef T2R_OCC
 #define T2R_OCC 2
-#endif
 __global__ __launch_bounds__(256, T2R_OCC) void t2i_rank_kernel(T2rArgs p, int prompts_per_wg) {
   constexpr int MI = T2S_MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2876,22 +2439,8 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
 // =====================================================================================================
 namespace {
 
-#ifndef FUSE_RING
 #define FUSE_RING 8       // M fragments in flight in the P . M phase
-#endif
-#ifndef FUSE_PF_EARLY
 #define FUSE_PF_EARLY -1  // next tile's q / residual loads before P . M: 1 yes, 0 no, -1 = only in the projected form
-#endif
-#ifndef FUSE_ABL
-#define FUSE_ABL 0        // developer ablation: 1 = readers idle, 2 = producers do not store
-#endif
-#ifdef FUSE_TS            // developer timing: s_memtime stamps of one producer tile and one reader step (workgroup 0)
-__device__ long long* g_fuse_ts = nullptr;
-#define FTS(role, k) do { if (g_fuse_ts && blockIdx.x == 0 && g == 40 && lane == 0 && (wave & 3) == 1) \
-    g_fuse_ts[(role) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FTS(role, k) do {} while (0)
-#endif
 template <bool PROJ>
 struct IF {
   static constexpr int KP = IR_M_BYTES;
@@ -2987,7 +2536,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         const int tile = st * 4 + wave;
         const int t0 = tile * 16;
         char* slice = smem + G::TILES + (g & 1) * G::STEP + wave * IR_SLICE;
-        FTS(0, 0);
         floatx4 sc[4];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
@@ -3008,7 +2556,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
             }
           }
         }
-        FTS(0, 1);
         half8_t pf[2];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
@@ -3027,7 +2574,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           pf[pr >> 1][o + 2] = (half_t)(p2 * inv);
           pf[pr >> 1][o + 3] = (half_t)(p3 * inv);
         }
-        FTS(0, 2);
         floatx4 acc[16];
 #pragma unroll
         for (int nj = 0; nj < 8; ++nj) {
@@ -3042,7 +2588,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           acc[2 * nj + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eye_hi, xf, b1, 0, 0, 0);
         }
         asm volatile("" ::: "memory");
-        FTS(0, 3);
         constexpr bool PF_EARLY = FUSE_PF_EARLY >= 0 ? FUSE_PF_EARLY != 0 : PROJ;
         if (PF_EARLY && st + 1 < spp) prefetch(tile + 4);
         // next tile's q / residual fragments: the hoisted-Q layer reads them from L2 (shared by all prompts) and issues them
@@ -3065,7 +2610,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           }
         }
         if (!PF_EARLY && st + 1 < spp) prefetch(tile + 4);   // lands under LayerNorm + stores
-        FTS(0, 4);
         float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int ni = 0; ni < 16; ++ni) {
@@ -3081,7 +2625,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         const float var = fmaxf(qsum[0] * (1.f / 256.f) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + p.eps);
         const float2_t rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
-        FTS(0, 5);
 #pragma unroll
         for (int ni = 0; ni < 16; ++ni) {
           if ((ni & 3) == 0) asm volatile("" ::: "memory");
@@ -3098,16 +2641,13 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           *(half4_t*)(slice + fr * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
               half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
         }
-        FTS(0, 6);
         // next tile's operands land here; the asm RE-DEFINES them, so whatever copies the register allocator places on
         // the loop edge move landed data (an in-flight asm load result must never reach a compiler-made copy)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(xres[0]), "+v"(xres[1]), "+v"(xres[2]),
                        "+v"(xres[3]), "+v"(xres[4]), "+v"(xres[5]), "+v"(xres[6]), "+v"(xres[7])
                      :: "memory");
-        FTS(0, 7);
         char* obase = (char*)(p.out + ((long)b * p.T + t0) * 256);
-#if !(FUSE_ABL & 2)
         {
           half8_t rb[8];                               // all eight read-backs in flight (the accumulators are dead), then the stores
 #pragma unroll
@@ -3118,10 +2658,7 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
             i2s_store16(obase, (unsigned)(row * 512 + ((sl ^ (row & 15)) << 4)), rb[i]);
           }
         }
-#endif
-        FTS(0, 8);
         I2S_BARRIER();                               // (T) step g is in LDS; the readers are done with step g - 1
-        FTS(0, 9);
       }
     }
     I2S_BARRIER();                                   // (E) pairs with the readers' drain step
@@ -3173,9 +2710,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
     // fragments are requested now (never request registers nobody waits for: the compiler would recycle them in flight)
     auto consume = [&](int k, bool more) {
       const int st = k % spp, b = b_first + k / spp;
-      const int g = k;                               // (FTS)
-      (void)g;
-      FTS(1, 0);
       if (st == 0) new_prompt(b);
       floatx4 kcur[2][MI];                           // this step's key_pe fragments (landed: see land_kpe)
 #pragma unroll
@@ -3209,7 +2743,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
             for (int mi = 0; mi < MI; ++mi)
               sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks][mi], qp[ks], sa[mi], 0, 0, 0);
         }
-        FTS(1, 1 + 3 * h);
         float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
                          fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -3232,7 +2765,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
 #pragma unroll
           for (int n = 0; n < 16; ++n) y[n] *= alpha;
         }
-        FTS(1, 2 + 3 * h);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
           const half4_t a0 = ds_tr_b64(xb + troff[0] + (((2 * n + tsub) ^ trow[0]) << 4));
@@ -3240,7 +2772,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
           y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
         }
-        FTS(1, 3 + 3 * h);
       }
       if (more) land_kpe();                          // requested a whole step ago: no exposed latency
       if (st == spp - 1) {
@@ -3267,9 +2798,7 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
     for (int b = b_first; b < b_last; ++b) {
       I2S_BARRIER();                                 // (P)
       for (int st = 0; st < spp; ++st, ++g) {
-#if !(FUSE_ABL & 1)
         if (g > 0) consume(g - 1, true);
-#endif
         I2S_BARRIER();                               // (T)
       }
     }
@@ -3283,9 +2812,6 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
 // image->token half-block + the next block's token->image attention.  Wq_f16 == null: the hoisted-Q layer-0 form
 // (csam_i2t_rank's operands, Q_f16 = the shared image-side queries); else the projected form (csam_i2t_rank_proj's, Q_f16 =
 // qpe16).  The reader operands are csam_t2i_rank's.  workspace: csam_i2t_t2i_workspace_bytes(B) = M_b | Kp_b | Qp_b.
-#ifdef FUSE_TS
-extern "C" int csam_dbg_set_fuse_ts(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_ts), &p, sizeof(p)); }
-#endif
 extern "C" long csam_i2t_t2i_workspace_bytes(int B) { return (long)B * (IR_M_BYTES + IR_KP_BYTES + 64 * 256 * 2); }
 
 static int i2t_t2i_launch(void* stream, const void* X_f16, long x_prompt_stride, const void* Q_f16, long q_prompt_stride,

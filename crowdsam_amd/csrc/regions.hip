@@ -1092,10 +1092,7 @@ extern "C" int csam_small_regions_idx(void* stream_, const uint8_t* masks_base, 
   const dim3 mgrid(std::min(16, std::max(1, tiles / 4)), n);
   hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);
   // pass 1: holes (components of the complement), masks -> out
-  static const int no_trivial = [] {                   // developer A/B: label trivial tiles like any other
-    const char* e = getenv("CSAM_CC_NO_TRIVIAL");
-    return e && e[0] == '1' ? 1 : 0;
-  }();
+  const int no_trivial = 0;                            // (1 = label trivial tiles like any other: the round-3 A/B)
   hipLaunchKernelGGL(cc2_scan_kernel<1>, tgrid, block, C2_LDS, stream, masks_base, idx, R16, RP, RA, RF, RT, RFT, meta, H, W,
                      min_area, no_trivial);
   hipLaunchKernelGGL(cc2_border_kernel<1>, bgrid, block, 0, stream, masks_base, idx, RP, H, W);
@@ -1206,11 +1203,7 @@ extern "C" int csam_small_regions(void* stream_, const uint8_t* masks, uint8_t* 
   // chunked reductions (flags, extents): enough blocks to fill the chip whatever n is
   const dim3 rgrid(std::min(std::min(std::max(1024 / n, 16), 256), std::max(1, segs / 8)), n);
   const dim3 cgrid(csam_cdiv(csam_cdiv(H, CC_ROWS) * ((W + 63) >> 6), 4), n);
-  static int tiled = -1;
-  if (tiled < 0) {
-    const char* e = getenv("CSAM_CC_TILE");            // 0: per-pixel global union-find (init + merge kernels), for A/B
-    tiled = e ? atoi(e) : 1;
-  }
+  const int tiled = 1;                                 // two-level labelling (tiles in LDS + cross-edge links)
   const dim3 tgrid(csam_cdiv(H, 64) * ((W + 63) >> 6), n);
   const dim3 bgrid(csam_cdiv(2 * (int)tgrid.x, 4), n);
   hipLaunchKernelGGL(cc_prepare_kernel, dim3(csam_cdiv(2 * n, 256)), dim3(256), 0, stream, meta, ext, n, H, W);

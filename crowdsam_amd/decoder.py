@@ -14,7 +14,6 @@ import ctypes
 import math
 
 import numpy as np
-import os
 
 import torch
 
@@ -109,37 +108,29 @@ class DecoderPlan:
     def __init__(self, sd, device, n_class=1, max_batch=256, fused=True):
         self.device, self.n_class, self.maxB = device, n_class, max_batch
         self.fused = fused     # False: round-1 unfused kernel chain (kept as an A/B and debugging reference)
-        # persistent weight-stationary i2t kernel (csam_i2t_stream); 0 = tile-per-workgroup kernel
-        self.i2t_stream = os.environ.get("CSAM_I2T_STREAM", "1") != "0"
-        self.t2i_stream = os.environ.get("CSAM_T2I_STREAM", "1") != "0"   # persistent token->image kernel (B >= 256)
-        self.up_stream = os.environ.get("CSAM_UP_STREAM", "1") != "0"     # persistent upscaler (B >= 256)
-        self.i2t_rank = os.environ.get("CSAM_I2T_RANK", "1") != "0"       # rank-56 layer-0 image->token (B >= 256)
-        self.i2t_rank_l1 = os.environ.get("CSAM_I2T_RANK_L1", "1") != "0"  # ... and layer 1 (csam_i2t_rank_proj)
-        self.t2i_rank = os.environ.get("CSAM_T2I_RANK", "1") != "0"       # rank-56 token->image, layers 1 / final (B >= 256)
-        # image->token of layer L + token->image of the next block in one pass over the key state (csam_i2t_t2i, B >= 256)
-        self.i2t_t2i = os.environ.get("CSAM_I2T_T2I", "1") != "0"
+        # Kernel routes (all on; parity tests switch single attributes off to pin a route against the one it replaced -- these
+        # are plan attributes, not environment switches):
+        self.i2t_stream = True       # persistent weight-stationary image->token kernel (csam_i2t_stream); False: tile-per-workgroup
+        self.t2i_stream = True       # persistent token->image kernel (B >= 256)
+        self.up_stream = True        # persistent upscaler
+        self.up_stream_small = True  # ... also below 256 prompts (ranges of tiles per workgroup)
+        self.i2t_rank = True         # rank-56 layer-0 image->token (B >= 256)
+        self.i2t_rank_l1 = True      # ... and layer 1 (csam_i2t_rank_proj)
+        self.t2i_rank = True         # rank-56 token->image, layers 1 / final (B >= 256)
+        self.i2t_t2i = True          # image->token of layer L + token->image of the next block in one pass (csam_i2t_t2i, B >= 256)
         # round 4: constants folded out of csam_i2t_t2i's producer loop (csam_i2t_t2i_fold): the out-projection bias into M_b
         # (both layers), layer 1's norm4 gamma / beta into the consumers of the final key state (upscaler first conv, final
-        # attention).  Only on the csam_i2t_t2i path (B >= 256); CSAM_I2T_FOLD=0 keeps the plain kernel.
-        self.i2t_fold = os.environ.get("CSAM_I2T_FOLD", "1") != "0"
-        # small batches (the shipped EPS configuration: 32 prompts) are a chain of ~65 launches that each fill a few CUs: the
-        # independent branches of the chain -- image->token pass of layer l beside the token-side prologue of layer l + 1, the
-        # IoU heads beside the hyper-network / upscaler / classifier branch -- are captured on a second stream (fork / join
-        # inside the hipGraph).  Same kernels on the same operands: bit-identical -- and SLOWER: the shipped EPS frame takes
-        # 38.0 ms with the forked graphs against 28.1 ms with one stream (profiles/r04_eps_fork_join.txt): a hipGraph with
-        # parallel branches is replayed through cross-stream events that cost more than the ~100 us per batch the branches
-        # overlap.  Kept as a measured experiment (CSAM_DEC_FORK=1), off by default
-        self.fork = os.environ.get("CSAM_DEC_FORK", "0") == "1"
+        # attention).  Only on the csam_i2t_t2i path (B >= 256)
+        self.i2t_fold = True
         # small batches: the two skinny GEMMs with a long K (MLP second layer K = 2048: 26 us on 4 workgroups; PWD-Net pooling
-        # product K = 5376: 54 us) as split-K launches summed in slice order (hip.gemm_f16_splitk).  CSAM_DEC_SPLITK=0: single pass
-        self.splitk = os.environ.get("CSAM_DEC_SPLITK", "1") != "0"
+        # product K = 5376: 54 us) as split-K launches summed in slice order (hip.gemm_f16_splitk)
+        self.splitk = True
         # small batches: the token side of a block in two launches instead of fourteen (csam_token_block_a / _b: self-attention
-        # block + norm1 + q projection; out projection + norm2 + MLP + norm3 + k / v projections).  CSAM_TOKEN_BLOCK=0: the
-        # separate GEMM / LayerNorm / attention launches
-        self.token_block = os.environ.get("CSAM_TOKEN_BLOCK", "1") != "0"
-        self.up_stream_small = os.environ.get("CSAM_UP_STREAM_SMALL", "1") != "0"
+        # block + norm1 + q projection; out projection + norm2 + MLP + norm3 + k / v projections)
+        self.token_block = True
+        # (Round 4 also captured the independent branches of the small-batch chain on a second stream -- fork / join inside the
+        # hipGraph: bit-identical and 10 ms per frame SLOWER, profiles/r04_eps_fork_join.txt.  The code is gone.)
         self._tb = None                              # fragment-ordered copies of the token-side weights (built on first use)
-        self._fork_stream = None
         f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         M, T = "mask_decoder.", "mask_decoder.transformer."
@@ -296,7 +287,7 @@ class DecoderPlan:
             kv=u(BT, 256), qi=u(BT, 128), att=u(BT, 128), up2=u(BT * 4, 128),
             hyper=e(B, 4, 32, dt=f), h1=e(B * 4, 256, dt=f), h2=e(B * 4, 256, dt=f),
             iou=e(B, 4, dt=f), res_iou=e(B * 4, 1, dt=f), fused_tok=e(B * 4, 512), cls=e(B * 4, self.n_class, dt=f),
-            hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f), g1b=e(B * 4, 256), g2b=e(B * 4, 256, dt=f),
+            hs16=e(B * 7, 256), hh1=e(4, B, 256), hh2=e(4, B, 256, dt=f), g1=e(B * 4, 256), g2=e(B * 4, 256, dt=f),
             splitk=e(12 * min(B, 256) * 7 * 256, dt=f),
             pooled16=e(B * 4, 256),
             stats=e(B * 4, 2, dt=f), wadj=torch.zeros(B * 4, N_DINO_PAD, dtype=torch.float16, device=dev),
@@ -468,15 +459,7 @@ class DecoderPlan:
                      and self.t2i_stream and self.i2t_t2i and B >= 256)
         y_ready = False
         keys_plain = False
-        forked = self.fork and B < 256 and self.fused and self.i2t_stream and not fuse_next
-        main_s = side_s = None
-        if forked:
-            main_s = torch.cuda.current_stream()
-            if self._fork_stream is None:
-                self._fork_stream = torch.cuda.Stream(device=coords_f32.device)
-            side_s = self._fork_stream
-        sa_done, joined = False, True               # next layer's self-attention already issued / side stream joined
-        tok = self.token_block and B < 256 and self.fused and self.i2t_stream and not fuse_next and not forked
+        tok = self.token_block and B < 256 and self.fused and self.i2t_stream and not fuse_next
         final_q_ready = False
         for li, L in enumerate(self.layers):
             if tok:
@@ -509,12 +492,8 @@ class DecoderPlan:
                                    qpe=L["i2t_q_peb"])
                 keys_in, keys_out = keys_out, ws["keysB"]
                 continue
-            if not y_ready and not sa_done:
+            if not y_ready:
                 self_attn(li, L)
-            sa_done = False
-            if not joined:                          # the keys of the previous layer's image->token pass (side stream)
-                main_s.wait_stream(side_s)
-                joined = True
             # ---- token -> image cross attention (:173-177)
             if li == 0:
                 t2i(L["t2i_q_w"], L["t2i_q_b"], st["kv0"], 256, 0, L["t2i_o_w"], L["t2i_o_b"], L["norm2_g"], L["norm2_b"],
@@ -558,19 +537,6 @@ class DecoderPlan:
                                 ws["t2i_q"], ws["t2i_y"], B, T_IMG, ws["i2t_t2i_ws"], fold=3 if self.i2t_fold else 0)
                     keys_plain = self.i2t_fold          # the final key state holds plain normalised values
                 y_ready = True
-            elif stream and forked and li + 1 < len(self.layers):
-                # fork: this layer's image->token pass on the side stream, the next layer's token self-attention + norm1 here
-                side_s.wait_stream(main_s)
-                with torch.cuda.stream(side_s):
-                    if li == 0:
-                        hip.i2t_stream(st["src16"], 0, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
-                                       L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Q=st["qi0"], q_bstride=0)
-                    else:
-                        hip.i2t_stream(keys_in, T_IMG * 256, ws["i2t_k"], ws["i2t_v"], L["i2t_o_w"], L["i2t_o_b"],
-                                       L["norm4_g"], L["norm4_b"], 1e-5, keys_out, B, T_IMG, Wq=L["i2t_q_w"],
-                                       qpe=L["i2t_q_peb"])
-                self_attn(li + 1, self.layers[li + 1])
-                sa_done, joined = True, False
             elif stream:
                 if li == 0 and self.i2t_rank and B >= 256:
                     # hoisted-Q layer in its rank-56 form (whole prompts per workgroup: needs >= 256 prompts)
@@ -653,10 +619,6 @@ class DecoderPlan:
                                       residual=iou0.view(B * 4, 1))
 
             iou = None
-            if forked:                                   # fork: the heads need the tokens only; their own scratch (g1b / g2b)
-                side_s.wait_stream(main_s)
-                with torch.cuda.stream(side_s):
-                    iou = iou_heads(ws["g1b"], ws["g2b"])
             # 4 hyper-MLPs: layers 0/1 as two batched MFMA GEMMs over the mask tokens (A stride = one token row)
             hh1, hh2 = ws["hh1"], ws["hh2"]
             hip.gemm_f16_batched(tok16[:, 1], 7 * 256, 256, self.hyper_w0, 256, 256 * 256, hh1, 256, hh1.stride(0),
@@ -694,6 +656,4 @@ class DecoderPlan:
         hip.add_cast(ws["pooled"][:R], out16=ws["pooled16"][:R])
         hip.gemm_f16(ws["pooled16"][:R], self.cls_w16, out=g2[:R], bias=b1, act=hip.ACT_RELU)
         cls = hip.linear_f32(g2[:R], w2, b2, out=ws["cls"][:R])
-        if forked:
-            main_s.wait_stream(side_s)              # join: the heads
         return masks, iou.view(B, 4), cls.view(B, 4, self.n_class)

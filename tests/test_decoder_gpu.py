@@ -174,39 +174,6 @@ def test_decoder_i2t_t2i_fusion_is_bitwise_the_unfused_sweep(cuda):
         assert torch.equal(a, b), (name, (a - b).abs().max().item())
 
 
-@pytest.mark.parametrize("B", [32, 7])
-def test_small_batch_fork_join_graph_is_bit_identical(cuda, B):
-    """Small batches (the shipped EPS configuration: 32 prompts) capture the independent branches of the launch chain on a
-    second stream inside the hipGraph (DecoderPlan.fork; a round-4 experiment, off by default because the forked graph
-    replays slower).  The same kernels on the same operands: masks, IoU and class scores must equal the one-stream graph bit
-    for bit, replay after replay."""
-    from crowdsam_amd import synth
-    from crowdsam_amd.decoder import DecoderPlan
-    sd = synth.make_sam_state_dict("vit_test128")
-    plan = DecoderPlan(sd, cuda, n_class=1, max_batch=64)
-    plan.token_block = False                        # the forked graph is a form of the separate-launch sequence
-    _set_image(plan, cuda)
-    outs = {}
-    for rep, on in enumerate((True, False, True, True)):
-        pts = np.random.RandomState(11 + (rep == 3)).randint(0, 1024, size=(B, 2)).astype(np.float32)
-        coords = torch.from_numpy(pts).to(cuda).contiguous()
-        plan.fork = on
-        if rep < 3:
-            plan.batch_graphs.clear()               # rep 3 replays rep 2's graph on other points
-        m, iou, cls = plan.run_batch(coords)
-        torch.cuda.synchronize()
-        outs[rep] = (m.clone(), iou.clone(), cls.clone())
-    for a, b, name in zip(outs[0], outs[1], ("masks", "iou", "cls")):
-        assert torch.equal(a, b), (name, (a - b).abs().max().item())
-    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[2]))
-    assert not torch.equal(outs[2][0], outs[3][0])          # the replay really computed the new points
-    plan.fork = False
-    plan.batch_graphs.clear()
-    ref = plan.run_batch(coords)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(outs[3], ref))
-
-
 @pytest.mark.parametrize("B", [32, 7, 1])
 def test_token_block_kernels_match_the_launch_sequence_they_replace(cuda, B):
     """csam_token_block_a / _b (round 4): the token side of a decoder block for small batches in two launches.  Same operands,

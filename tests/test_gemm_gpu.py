@@ -157,6 +157,70 @@ def test_gemm_ln_fold_matches_layernorm_then_gemm(cuda, M, D, N2):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("case", ["outlier_channel", "row_offset"])
+def test_gemm_ln_fold_on_massive_activations(cuda, case):
+    """real ViT residual streams carry massive-activation channels and rows whose mean is not small against their
+    spread; the fold multiplies fp16(x) -- the UNCENTRED value -- and subtracts mean * colsum afterwards, so the fp16 rounding of
+    x is relative to |x|, not to |x - mean|.  Two synthetic stand-ins (no real checkpoint exists on any box): one channel at
+    ~500 with unit-scale others (mean / std ~ 0.03: the rounding of the big channel is what the separate LayerNorm kernel's
+    fp16 output pays too), and a common row offset of 5 spreads (the case that costs the fold precision).  Reports the error of
+    both routes against the fp32 LayerNorm + matmul and bounds the fold's."""
+    from crowdsam_amd import hip
+    torch.manual_seed(3)
+    M, D, N2 = 2048, 1024, 3072
+    x = torch.randn(M, D, device=cuda)
+    if case == "outlier_channel":
+        x[:, 77] = 500.0 + 20.0 * torch.randn(M, device=cuda)
+        x[:, 400] = -180.0 + 5.0 * torch.randn(M, device=cuda)
+    else:
+        x += 5.0 * torch.randn(M, 1, device=cuda).sign()
+    # the producer's outputs for this residual stream: fp16 copy + (sum, sum of squares) partials per 128 columns
+    x16 = x.half()
+    part = x.view(M, D // 128, 128)
+    st = torch.stack([part.sum(-1), (part * part).sum(-1)], -1).contiguous()
+    g, be = torch.rand(D, device=cuda) + 0.5, torch.randn(D, device=cuda) * 0.3
+    w2, b2 = torch.randn(N2, D, device=cuda) * 0.05, torch.randn(N2, device=cuda)
+    wf, bf, cs = hip.fold_layernorm(w2, b2, g, be)
+    out = torch.empty(M, N2, dtype=torch.float16, device=cuda)
+    hip.gemm_f16_ln(x16, wf, out, bias=bf, stats_in=st, colsum=cs, eps=1e-6)
+    ref = (torch.nn.functional.layer_norm(x.double(), (D,), g.double(), be.double(), 1e-6) @ w2.double().t() + b2.double()).float()
+    old = hip.gemm_f16(hip.layernorm(x, g, be, 1e-6), w2.half(), bias=b2)
+    e_new, e_old = (out.float() - ref).abs(), (old.float() - ref).abs()
+    mu, sd = x.mean(1).abs().mean().item(), x.std(1).mean().item()
+    print("%s: |row mean| %.2f, row std %.2f | folded max %.3e mean %.3e | LayerNorm kernel + GEMM max %.3e mean %.3e | |ref| mean %.3f"
+          % (case, mu, sd, e_new.max().item(), e_new.mean().item(), e_old.max().item(), e_old.mean().item(), ref.abs().mean().item()))
+    assert torch.isfinite(out).all()
+    assert e_new.mean().item() < (2.5 if case == "outlier_channel" else 8.0) * e_old.mean().item() + 1e-4
+
+
+def test_gelu_polynomial_against_erf(cuda):
+    """The packed polynomial GELU of every fp16-output epilogue (csam_common.h: clamp on the OUTPUT since round 5, by the clamp
+    bit of the last packed FMA) against the exact erf form in float64 (nn.GELU, common.py:25-26 / mask_decoder.py:56-62), through
+    both GEMM kernels (out[m, n] = gelu(x[m]): one non-zero operand column, unit weights): within half an fp16 ulp of the
+    rounded exact value + 8e-5 (the fit: 4.5e-5 on its LP grid, 6.7e-5 at x = -4.35 in fp32 Horner arithmetic), for |x| up to fp16's largest -- beyond +-4.4 the polynomial leaves [0, 1] monotonically
+    (overflowing to +-inf for huge arguments) and the clamp must return exactly x / -0."""
+    from crowdsam_amd import hip
+    xs = torch.cat([torch.linspace(-12, 12, 3841), torch.tensor([4.4, -4.4, 4.5, -4.5, 30.0, -30.0, 250.0, -250.0, 3000.0,
+                                                                    -3000.0, 60000.0, -60000.0, 0.0])]).half()
+    M = 4096
+    x = xs.repeat((M + len(xs) - 1) // len(xs))[:M].contiguous()
+    ref = (x.double() * 0.5 * (1.0 + torch.erf(x.double() / 2 ** 0.5)))
+    for N in (128, 2048):                                   # the 128-column tile kernel / the 256 x 256 ping-pong kernel
+        a = torch.zeros(M, 64, dtype=torch.float16, device=cuda)
+        a[:, 0] = x.to(cuda)
+        w = torch.zeros(N, 64, dtype=torch.float16, device=cuda)
+        w[:, 0] = 1.0
+        out = hip.gemm_f16(a, w, act=hip.ACT_GELU).float().cpu()
+        assert torch.isfinite(out).all()
+        for col in (0, N - 1):
+            got = out[:, col].double()
+            ulp = torch.maximum(ref.abs(), torch.tensor(6.1e-5, dtype=torch.float64)) * 2.0 ** -11
+            bad = (got - ref).abs() > ulp + 8e-5
+            assert not bool(bad.any()), (N, col, x[bad][:5], got[bad][:5], ref[bad][:5])
+        big = x.abs() > 4.5
+        assert torch.equal(out[big, 0], torch.where(x[big] > 0, x[big].float(), torch.zeros(())))
+
+
 @pytest.mark.parametrize("M,N,K,S", [(224, 256, 2048, 8), (128, 256, 5376, 12), (7, 256, 2048, 8), (1785, 256, 2048, 8)])
 def test_gemm_splitk_matches_single_pass(cuda, M, N, K, S):
     """hip.gemm_f16_splitk (K-slices through csam_gemm_f16_batched + csam_splitk_reduce, round 4: the skinny long-K products of

@@ -58,6 +58,38 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, floa
 #define M(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
       REP16(M)
 #undef M
+    } else if (OP == 10) {
+#define M(i) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(a[i]) : "v"(k1));
+      REP16(M)
+#undef M
+    } else if (OP == 11) {
+#define M(i) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(k1));
+      REP16(M)
+#undef M
+    } else if (OP == 12) {
+#define M(i) asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 13) {  // two products + accumulate per lane in one instruction (fp16 inputs, fp32 accumulator)
+#define M(i) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 14) {  // does the transcendental unit run BESIDE the FMA pipe?  8 v_exp_f32 + 8 v_fma_f32, interleaved
+#define M(i) if ((i) & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
+    } else if (OP == 15) {  // ... and beside the packed pipe: 8 v_exp_f32 + 8 v_pk_fma_f32
+#define M(i) if ((i) & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i])); else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(q1), "v"(q2));
+      REP16(M)
+#undef M
+    } else if (OP == 16) {  // v_rcp_f32
+#define M(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+      REP16(M)
+#undef M
+    } else if (OP == 17) {  // fp16 -> fp32 mixed FMA (v_fma_mix_f32: fp16 or fp32 sources, fp32 result)
+#define M(i) asm volatile("v_fma_mix_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(k1), "v"(k2));
+      REP16(M)
+#undef M
     } else if (OP == 7) {   // v_fma_f32 with the constants in SGPRs / literals as the compiler emits Horner steps
 #define M(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 15]), "s"(k2));
       REP16(M)
@@ -69,16 +101,6 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, floa
         csam_gelu_poly2_n<4>(z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) p[g * 4 + q] = z[q] + q1;
-      }
-    } else if (OP == 9) {   // the same polynomial on scalars (csam_gelu_poly1_n<8>), 2 calls per iteration
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        float z[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) z[q] = a[g * 8 + q];
-        csam_gelu_poly1_n<8>(z);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[g * 8 + q] = z[q] + k1;
       }
     }
   }
@@ -129,8 +151,15 @@ int main() {
   run<2>("v_med3_f32", 16, "instruction");
   run<4>("v_cvt_f16_f32", 16, "instruction");
   run<6>("v_pk_fma_f16", 16, "instruction");
+  run<10>("v_pk_mul_f16", 16, "instruction");
+  run<11>("v_pk_max_f16", 16, "instruction");
+  run<12>("v_fma_f16", 16, "instruction");
+  run<13>("v_dot2_f32_f16", 16, "instruction");
+  run<17>("v_fma_mix_f32", 16, "instruction");
   run<5>("v_exp_f32", 16, "instruction");
-  run<8>("csam_gelu_poly2_n<4> (packed; + 1 pk_add)", 16, "PAIR of evaluations");
-  run<9>("csam_gelu_poly1_n<8> (scalar; + 1 add each)", 8, "PAIR of evaluations");
+  run<16>("v_rcp_f32", 16, "instruction");
+  run<14>("8 v_exp_f32 + 8 v_fma_f32 interleaved", 16, "instruction");
+  run<15>("8 v_exp_f32 + 8 v_pk_fma_f32 interleaved", 16, "instruction");
+  run<8>("csam_gelu_poly2_n<4> (r5: output clamp; + 1 pk_add)", 16, "PAIR of evaluations");
   return 0;
 }
