@@ -181,13 +181,15 @@ def stub_run(args, rank, world):
         sys.exit(3)
     if world > 1:
         dist.init_process_group("gloo")
-    rows = []
+    rows = [np.zeros((0, 6), np.float32)]
+    empty = os.environ.get("CSAM_BENCH_STUB_EMPTY_RANK") == str(rank)      # a rank whose images yield no detection at all
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         time.sleep(0.002)
-        rows.append(detections_to_rows(rank * args.steps + i, np.array([[0, 0, 1, 1.0]], np.float32), np.array([0.5], np.float32)))
+        if not empty:
+            rows.append(detections_to_rows(rank * args.steps + i, np.array([[0, 0, 1, 1.0]], np.float32), np.array([0.5], np.float32)))
     my = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
@@ -195,7 +197,8 @@ def stub_run(args, rank, world):
     rates = [args.steps / my]
     if world > 1:
         allrows = gather_rows(np.concatenate(rows))
-        assert len(allrows) == world * args.steps and bool(np.all(np.diff(allrows[:, 0]) >= 0))
+        n_empty = 1 if os.environ.get("CSAM_BENCH_STUB_EMPTY_RANK") in [str(r) for r in range(world)] else 0
+        assert len(allrows) == (world - n_empty) * args.steps and bool(np.all(np.diff(allrows[:, 0]) >= 0))
         t = torch.tensor([elapsed, 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -264,6 +267,10 @@ def main():
         return stub_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # N ranks share one host: every rank keeps its host-side numpy / torch work (frame synthesis, result conversion) inside
+        # its share of the cores instead of N x all of them
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
@@ -351,6 +358,7 @@ def main():
 
     def timed_leg(collect_rows):
         step_trace = [] if os.environ.get("CSAM_BENCH_TRACE") else None
+        step_end = []
         kept = pre = 0
         rws = [np.zeros((0, 6), np.float32)]
         timed = list(range(args.warmup, args.warmup + args.steps))
@@ -365,6 +373,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for k, out in enumerate(frame_stream(timed)):
+            step_end.append(time.perf_counter() - t0)
             if step_trace is not None:
                 step_trace.append(time.perf_counter() - t0)
                 if getattr(model, "timings", None):    # CSAM_TIMING=1: device-synchronised stage times of this step
@@ -381,21 +390,27 @@ def main():
         if step_trace:                                 # developer: CSAM_BENCH_TRACE=1 -> when each generate() returned (ms)
             print("step returns (ms): " + " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip([0.0] + step_trace, step_trace)),
                   file=sys.stderr, flush=True)
-        return time.perf_counter() - t0, mine, kept, pre, rws
+        steps_ms = [1e3 * (b - a) for a, b in zip([0.0] + step_end, step_end)]
+        return time.perf_counter() - t0, mine, kept, pre, rws, steps_ms
 
-    elapsed, my_elapsed, n_kept, n_pre_nms, rows = timed_leg(True)
+    elapsed, my_elapsed, n_kept, n_pre_nms, rows, steps_ms = timed_leg(True)
     rank_rates = [args.steps / my_elapsed]
+    # host-side step times (when generate() returned): median and worst per rank -- a rank stalling on the shared host shows here
+    srt = sorted(steps_ms)
+    rank_steps = [[srt[len(srt) // 2], srt[-1]]]
     if world > 1:
         # the one collective of the design: the variable-length detection gather over RCCL, after
         # the timed region (it is once per RUN, not per image); rank 0 checks that every rank's rows arrived
         rows_np = np.concatenate(rows)
         allrows = gather_rows(rows_np)
-        cnt = torch.tensor([float(len(rows_np)), args.steps / my_elapsed], device=dev, dtype=torch.float64)
+        cnt = torch.tensor([float(len(rows_np)), args.steps / my_elapsed, rank_steps[0][0], rank_steps[0][1]], device=dev,
+                           dtype=torch.float64)
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(cnts, cnt)
         assert len(allrows) == int(sum(c[0].item() for c in cnts)), "detection gather lost rows"
         assert bool(np.all(np.diff(allrows[:, 0]) >= 0)), "gathered rows are not in rank (== image) order"
         rank_rates = [float(c[1].item()) for c in cnts]
+        rank_steps = [[float(c[2].item()), float(c[3].item())] for c in cnts]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -545,7 +560,8 @@ def main():
                        "masks_per_sec": value * n_prompts if args.mode == "dense" else None,
                        "kept_masks_per_image": n_kept / args.steps,
                        "masks_into_nms_per_image": n_pre_nms / args.steps, "parallelism": f"image-sharded x{world}",
-                       "per_rank_images_per_sec": rank_rates, **rccl},
+                       "per_rank_images_per_sec": rank_rates,
+                       "per_rank_step_ms_median_max": rank_steps, **rccl},
         }
         if crowded:
             res["config"]["crowded_frame"] = ("box NMS threshold %.3f, predicted-IoU cut %.4f -- %s (keeps ~%d of the 4096 "

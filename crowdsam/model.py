@@ -97,6 +97,7 @@ class CrowdSAM:
         # list on the host and synchronises after every batch, as the reference does
         self.eps_on_device = os.environ.get("CSAM_EPS_DEVICE", "1") != "0"
         self.eps_trace = None       # set to a list to collect (prompt points, n_valid) of every EPS round (tests, debugging)
+        self.eps_trace_status = []  # with eps_trace set: (score, survivor flag, feeder flag) of every prompt of every round
         self.crop_n_layers = t["crop_n_layers"]
         self.crop_nms_thresh = t["crop_nms_thresh"]
         self.crop_overlap_ratio = t["crop_overlap_ratio"]

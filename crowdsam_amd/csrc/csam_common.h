@@ -125,7 +125,7 @@ __device__ __forceinline__ float2_t csam_gelu_poly2(float2_t x) {
 // v_pk_fma_f32 whose input is the previous instruction's result costs an s_nop on gfx950 (the single-pair form above
 // compiles to fma / s_nop / fma / s_nop ...: 9 wasted issue slots per pair); interleaved chains have none.
 // (Round 5 A/B of a degree-6 fit -- two packed FMAs per pair fewer, |gelu error| 1.9e-4 instead of 4.5e-5: upscaler -4.7 % with it
-// in the second GELU, -6.5 % in both, at 2.7x / 3.7x the error against the fp32 oracle: profiles/r05_upscale_fp16_gelu.txt.  Not
+// in the second GELU, -6.5 % in both, for a 4x coarser polynomial: profiles/r05_upscale_fp16_gelu.txt.  Not
 // taken.  Odd degrees do not work with the output clamp: their leading coefficient is negative, Phi -> -inf for x -> +inf.)
 template <int N>
 __device__ __forceinline__ void csam_gelu_poly2_n(float2_t (&x)[N]) {

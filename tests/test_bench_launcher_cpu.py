@@ -26,6 +26,21 @@ def test_bench_spawns_its_own_ranks():
     assert d["config"]["rccl_world_size"] == 2 and d["config"]["backend"] == "gloo"    # the backend saw both ranks
 
 
+def test_bench_eight_ranks_with_an_empty_rank():
+    """The 8-GPU launch the driver's SCALE run makes, as far as a GPU-less container can rehearse it: eight gloo ranks on one
+    host, rank 5 produces no detection at all (its padded all_gather slot is empty), rows still arrive in rank order."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["CSAM_BENCH_STUB_EMPTY_RANK"] = "5"
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-step", "--gpus", "8", "--steps", "3",
+                         "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and len(d["config"]["per_rank_images_per_sec"]) == 8
+    assert d["config"]["rccl_world_size"] == 8 and d["config"]["backend"] == "gloo"
+
+
 def test_bench_single_rank_needs_no_launcher():
     cp = _run(["--gpus", "1"])
     assert cp.returncode == 0, cp.stderr[-2000:]
