@@ -41,8 +41,8 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
-_WORK_STREAM = os.environ.get("CSAM_WORK_STREAM", "1") != "0"
-_WINDOWED_REGIONS = os.environ.get("CSAM_CC_WINDOWED", "1") != "0"      # small-region clean-up inside the masks' boxes
+_WORK_STREAM = True          # generate() on its own high-priority stream (False: the caller's stream; tests toggle it)
+_WINDOWED_REGIONS = True      # small-region clean-up and RLE inside the masks' boxes (False: whole frames)
 
 
 class CrowdSAM:
@@ -93,9 +93,9 @@ class CrowdSAM:
         self.stability_score_offset = t["stability_score_offset"]
         self.box_nms_thresh = t["box_nms_thresh"]
         self.points_per_batch = t["points_per_batch"]
-        # Efficient Prompt Sampler state on the device (no host round trip per batch); CSAM_EPS_DEVICE=0 keeps the point
-        # list on the host and synchronises after every batch, as the reference does
-        self.eps_on_device = os.environ.get("CSAM_EPS_DEVICE", "1") != "0"
+        # Efficient Prompt Sampler state on the device (no host round trip per batch); False keeps the point list on the host
+        # and synchronises after every batch, as the reference does (parity tests compare the two)
+        self.eps_on_device = True
         self.eps_trace = None       # set to a list to collect (prompt points, n_valid) of every EPS round (tests, debugging)
         self.eps_trace_status = []  # with eps_trace set: (score, survivor flag, feeder flag) of every prompt of every round
         self.crop_n_layers = t["crop_n_layers"]

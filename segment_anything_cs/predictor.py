@@ -6,8 +6,6 @@ reset_image`` and ``model, dino_model, transform, features, dino_feats, original
 is_image_set, device``.  Per image: ONE H2D copy of the uint8 frame; the encoder, DINOv2 and the
 hoisted decoder constants stay resident in HBM until ``reset_image``.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -18,7 +16,7 @@ from crowdsam_amd.dino import DinoV2
 from .utils.transforms import ResizeLongestSide
 
 
-_TWO_STREAMS = os.environ.get("CSAM_TWO_STREAMS", "1") != "0"
+_TWO_STREAMS = True      # DINOv2 on a side stream beside the SAM encoder (bench.py's per-launch timing leg switches it off)
 
 
 class SamPredictor:
@@ -30,6 +28,7 @@ class SamPredictor:
         self._side_stream = None
         self._group_bufs = {}
         self._group_graphs = {}
+        self.group_two_streams = True       # DINOv2 share of a chunk on a second stream (35.9 -> 35.3 ms per frame; False: one stream)
         self.reset_image()
 
     # ------------------------------------------------------------------------------------------
@@ -205,18 +204,34 @@ class SamPredictor:
         if dino is not None:
             lo_d, hi_d = c * dino.depth // n, (c + 1) * dino.depth // n
 
+        def run_dino():
+            if c == 0:
+                dino.embed(g["dino_views"], B)
+            dino.run_blocks(lo_d, hi_d, B)
+            if c == n - 1:
+                dino.final_norm([t[:N_DINO] for t in g["dtok"][:B]], B)
+
         def run():
+            two = dino is not None and self.group_two_streams
+            if two:       # DINOv2's share of the chunk on a second stream (fork / join; inside a capture: two graph branches)
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=g["feat"].device)
+                self._side_stream.wait_stream(main)
+                with torch.cuda.stream(self._side_stream):
+                    run_dino()
             if c == 0:
                 enc.embed(g["sam_views"], B)
-                if dino is not None:
-                    dino.embed(g["dino_views"], B)
             enc.run_blocks(lo_s, hi_s, B)
-            if dino is not None:
-                dino.run_blocks(lo_d, hi_d, B)
             if c == n - 1:
                 enc.neck(g["feat"][:B], B)
+            if two:
+                main.wait_stream(self._side_stream)
+            elif dino is not None:
+                run_dino()
+            if c == n - 1:
                 if dino is not None:
-                    dino.final_norm([t[:N_DINO] for t in g["dtok"][:B]], B)
+                    pass
                 else:   # third-party DINO object: the reference's tensor, one frame at a time (predictor.py:104-106)
                     for b, raw in enumerate(g["dino_views"]):
                         x = hip.bilinear_f32(hip.preprocess_pad(raw), (1022, 1022))
@@ -225,7 +240,7 @@ class SamPredictor:
 
         if dino is None or not hip.GRAPHS_ENABLED or hip.timer_active():
             return run()
-        key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap)
+        key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap, self.group_two_streams)
         ent = self._group_graphs.get(key)
         if ent is None:
             run()                                   # this call's execution (also sets kernel attributes)

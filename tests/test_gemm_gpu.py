@@ -164,7 +164,9 @@ def test_gemm_ln_fold_on_massive_activations(cuda, case):
     x is relative to |x|, not to |x - mean|.  Two synthetic stand-ins (no real checkpoint exists on any box): one channel at
     ~500 with unit-scale others (mean / std ~ 0.03: the rounding of the big channel is what the separate LayerNorm kernel's
     fp16 output pays too), and a common row offset of 5 spreads (the case that costs the fold precision).  Reports the error of
-    both routes against the fp32 LayerNorm + matmul and bounds the fold's."""
+    both routes against the fp32 LayerNorm + matmul and bounds the fold's.  Measured on MI355X: outlier channel 3.3e-4 (folded) vs
+    3.6e-4 (LayerNorm kernel + GEMM) mean error at mean |ref| 1.26; row offset 1.45e-3 vs 5.0e-4 at mean |ref| 1.58 -- the fold
+    pays 2.9x there, 0.09 % of the output magnitude, the order of the path's fp16-operand noise."""
     from crowdsam_amd import hip
     torch.manual_seed(3)
     M, D, N2 = 2048, 1024, 3072
@@ -190,7 +192,7 @@ def test_gemm_ln_fold_on_massive_activations(cuda, case):
     print("%s: |row mean| %.2f, row std %.2f | folded max %.3e mean %.3e | LayerNorm kernel + GEMM max %.3e mean %.3e | |ref| mean %.3f"
           % (case, mu, sd, e_new.max().item(), e_new.mean().item(), e_old.max().item(), e_old.mean().item(), ref.abs().mean().item()))
     assert torch.isfinite(out).all()
-    assert e_new.mean().item() < (2.5 if case == "outlier_channel" else 8.0) * e_old.mean().item() + 1e-4
+    assert e_new.mean().item() < (2.5 if case == "outlier_channel" else 4.0) * e_old.mean().item() + 1e-4
 
 
 def test_gelu_polynomial_against_erf(cuda):
