@@ -246,14 +246,17 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="generate() without any look-ahead (A/B of the pipelined loops)")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=None,
                     help="frames per image-batched encoder pass of the look-ahead (CrowdSAM.generate_stream(batch=B)); 1 = the "
-                         "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  With --encoder-only: images "
-                         "per encoder pass")
+                         "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  Default: 4 from 16 timed steps, "
+                         "2 from 8, else 1 -- the first group of a stream is encoded cold INSIDE the timed region, which a short "
+                         "run cannot amortise.  With --encoder-only: images per encoder pass (default 1)")
     ap.add_argument("--no-cpu-e2e", action="store_true",
                     help="skip the measured end-to-end oracle image (64 prompts, ~1.5 min of host time) of the cpu_baseline leg")
     args = ap.parse_args()
-    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 4 if args.steps >= 16 else 2 if args.steps >= 8 else 1
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way

@@ -93,57 +93,50 @@ __device__ __forceinline__ float csam_gelu_erf(float x) {
   return 0.5f * x * (1.0f + csam_erf_fast(x * 0.70710678118654752440f));
 }
 // Packed-fp32 polynomial GELU for fp16-bound outputs (the fused upscaler, which PMC shows VALU-bound on GELU):
-//   Phi(x) ~ clamp01(0.5 + x * R(x^2)),  R = degree-8 minimax fit on |x| <= 4.4 with Phi(4.4) = 1 (tools/fit_gelu_poly.py),
-// |gelu error| <= 2.5e-5 for |x| < 3 and <= 4.5e-5 overall -- an order below the fp16 rounding of the value it feeds -- in
-// 11 v_pk_*_f32 per PAIR, no transcendental, against ~22 issue slots per element for the erf form above.
-// Round 5: the clamp sits on the OUTPUT and costs nothing -- it is the VOP3P `clamp` bit (result -> [0, 1]) of the last packed
-// FMA.  Rounds 2-4 clamped the ARGUMENT to +-4.4 with two v_med3_f32 per pair, which tools/probe/valu_rate.hip prices at 3.08
-// cycles each, as much as a packed FMA: 6.2 of the pair's 40 issue cycles.  Beyond the fit range the unclamped polynomial is
-// monotone (Phi > 1 for x > 4.4, < 0 for x < -4.4, overflowing to +-inf for |x| >~ 1e4: never NaN, u = x^2 >= 0 keeps the
-// Horner chain at +inf), so the clamped value is exactly 1 / 0 there and gelu(x) = x / -0 as before; inside it the arithmetic is
-// unchanged bit for bit (tests/test_gemm_gpu.py::test_gelu_polynomial_against_erf).  hipcc does not fold min / max / med3 of
-// a packed result into the bit (it emits a v_max_f32 ... clamp per element), hence the one-instruction asm; its operands and
-// result are ordinary registers to the hazard recogniser.
+//   Phi(x) ~ 0.5 + xc * R(xc^2),  xc = clamp(x, +-4.4),  R = degree-8 minimax fit with Phi(4.4) = 1 exactly,
+// |gelu error| <= 2.5e-5 for |x| < 3 and <= 4.5e-5 overall (tools/fit_gelu_poly.py) -- an order below the fp16
+// rounding of the value it feeds -- in 13 instructions per PAIR (v_med3 x2, 11 v_pk_*_f32), no transcendental,
+// against ~22 issue slots per element for the erf form above.
+// (Round 5 tried the clamp on the OUTPUT instead -- the VOP3P `clamp` bit of the last packed FMA, which needs a one-instruction
+// inline asm because hipcc does not fold it: -7 % VALU instructions in the upscaler, -0.7 % time, and the ISA lint
+// (tools/lint_mfma_srcc.py) caught the asm overwriting an MFMA's SrcC quad two instructions behind it with no wait states:
+// the hazard recogniser pads compiler-emitted VALU writes there, not asm ones.  Reverted; profiles/r05_upscale_fp16_gelu.txt.)
 typedef float float2_t __attribute__((ext_vector_type(2)));
-#define CSAM_GELU_K {4.471991608e-11f, -4.528126140e-09f, 2.016253663e-07f, -5.250151905e-06f, 9.008348436e-05f, \
-                     -1.092016766e-03f, 9.773204936e-03f, -6.629599897e-02f, 3.988868129e-01f}
-__device__ __forceinline__ float2_t csam_phi_clamped(float2_t x, float2_t r) {   // clamp01(x * r + 0.5), one v_pk_fma_f32
-  float2_t ph;
-  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(ph) : "v"(x), "v"(r));
-  return ph;
-}
 __device__ __forceinline__ float2_t csam_gelu_poly2(float2_t x) {
-  const float2_t u = x * x;
-  const float k[9] = CSAM_GELU_K;
+  const float c = 4.4f;
+  const float2_t xc = {__builtin_amdgcn_fmed3f(x[0], -c, c), __builtin_amdgcn_fmed3f(x[1], -c, c)};
+  const float2_t u = xc * xc;
+  const float k[9] = {4.471991608e-11f, -4.528126140e-09f, 2.016253663e-07f, -5.250151905e-06f, 9.008348436e-05f,
+                      -1.092016766e-03f, 9.773204936e-03f, -6.629599897e-02f, 3.988868129e-01f};
   float2_t r = {k[0], k[0]};
 #pragma unroll
   for (int i = 1; i < 9; ++i) r = __builtin_elementwise_fma(r, u, (float2_t){k[i], k[i]});
-  return x * csam_phi_clamped(x, r);
+  const float2_t ph = __builtin_elementwise_fma(xc, r, (float2_t){0.5f, 0.5f});
+  return x * ph;
 }
 
 // N independent pairs at once, coefficient-major: consecutive instructions belong to different Horner chains.  A
 // v_pk_fma_f32 whose input is the previous instruction's result costs an s_nop on gfx950 (the single-pair form above
 // compiles to fma / s_nop / fma / s_nop ...: 9 wasted issue slots per pair); interleaved chains have none.
-// (Round 5 A/B of a degree-6 fit -- two packed FMAs per pair fewer, |gelu error| 1.9e-4 instead of 4.5e-5: upscaler -4.7 % with it
-// in the second GELU, -6.5 % in both, for a 4x coarser polynomial: profiles/r05_upscale_fp16_gelu.txt.  Not
-// taken.  Odd degrees do not work with the output clamp: their leading coefficient is negative, Phi -> -inf for x -> +inf.)
 template <int N>
 __device__ __forceinline__ void csam_gelu_poly2_n(float2_t (&x)[N]) {
-  constexpr int DEG = 8;
-  const float k[9] = CSAM_GELU_K;
-  float2_t u[N], r[N], ph[N];
+  const float c = 4.4f;
+  const float k[9] = {4.471991608e-11f, -4.528126140e-09f, 2.016253663e-07f, -5.250151905e-06f, 9.008348436e-05f,
+                      -1.092016766e-03f, 9.773204936e-03f, -6.629599897e-02f, 3.988868129e-01f};
+  float2_t xc[N], u[N], r[N];
 #pragma unroll
-  for (int p = 0; p < N; ++p) u[p] = x[p] * x[p];
+  for (int p = 0; p < N; ++p) {
+    xc[p] = float2_t{__builtin_amdgcn_fmed3f(x[p][0], -c, c), __builtin_amdgcn_fmed3f(x[p][1], -c, c)};
+    u[p] = xc[p] * xc[p];
+  }
 #pragma unroll
   for (int p = 0; p < N; ++p) r[p] = __builtin_elementwise_fma((float2_t){k[0], k[0]}, u[p], (float2_t){k[1], k[1]});
 #pragma unroll
-  for (int i = 2; i <= DEG; ++i)
+  for (int i = 2; i < 9; ++i)
 #pragma unroll
     for (int p = 0; p < N; ++p) r[p] = __builtin_elementwise_fma(r[p], u[p], (float2_t){k[i], k[i]});
 #pragma unroll
-  for (int p = 0; p < N; ++p) ph[p] = csam_phi_clamped(x[p], r[p]);
-#pragma unroll
-  for (int p = 0; p < N; ++p) x[p] = x[p] * ph[p];
+  for (int p = 0; p < N; ++p) x[p] = x[p] * __builtin_elementwise_fma(xc[p], r[p], (float2_t){0.5f, 0.5f});
 }
 
 // exp2 for softmax arguments (<= 0, results in (0, 1]): the bare v_exp_f32.  exp2f() wraps it in a denormal-range

@@ -196,11 +196,10 @@ def test_gemm_ln_fold_on_massive_activations(cuda, case):
 
 
 def test_gelu_polynomial_against_erf(cuda):
-    """The packed polynomial GELU of every fp16-output epilogue (csam_common.h: clamp on the OUTPUT since round 5, by the clamp
-    bit of the last packed FMA) against the exact erf form in float64 (nn.GELU, common.py:25-26 / mask_decoder.py:56-62), through
+    """The packed polynomial GELU of every fp16-output epilogue (csam_common.h) against the exact erf form in float64 (nn.GELU, common.py:25-26 / mask_decoder.py:56-62), through
     both GEMM kernels (out[m, n] = gelu(x[m]): one non-zero operand column, unit weights): within half an fp16 ulp of the
-    rounded exact value + 8e-5 (the fit: 4.5e-5 on its LP grid, 6.7e-5 at x = -4.35 in fp32 Horner arithmetic), for |x| up to fp16's largest -- beyond +-4.4 the polynomial leaves [0, 1] monotonically
-    (overflowing to +-inf for huge arguments) and the clamp must return exactly x / -0."""
+    rounded exact value + 8e-5 (the fit: 4.5e-5 on its LP grid, 6.7e-5 at x = -4.35 in fp32 Horner arithmetic), for |x| up to fp16's largest -- beyond +-4.4 the argument clamp makes Phi exactly 1 / 0: the kernel
+    must return exactly x / -0 there."""
     from crowdsam_amd import hip
     xs = torch.cat([torch.linspace(-12, 12, 3841), torch.tensor([4.4, -4.4, 4.5, -4.5, 30.0, -30.0, 250.0, -250.0, 3000.0,
                                                                     -3000.0, 60000.0, -60000.0, 0.0])]).half()

@@ -24,6 +24,6 @@ e0.record()
 n = 5
 for _ in range(n): plan.run_batch(coords)
 e1.record(); torch.cuda.synchronize(); hip.set_timer(None)
-print(f"B={B}: {e0.elapsed_time(e1)/n:.3f} ms per batch, {e0.elapsed_time(e1)/n/B*1e3:.2f} us/prompt (CSAM_DBG={os.environ.get('CSAM_DBG')})")
+print(f"B={B}: {e0.elapsed_time(e1)/n:.3f} ms per batch, {e0.elapsed_time(e1)/n/B*1e3:.2f} us/prompt")
 for k, v in sorted(t.summary().items(), key=lambda kv: -kv[1]["ms"]):
     print(f"  {k:28s} calls/batch {v['calls']//n:4d}  {v['ms']/n*1e3:9.1f} us/batch")

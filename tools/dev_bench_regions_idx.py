@@ -1,7 +1,6 @@
 """Microbenchmark: csam_small_regions_idx (the compact ring-forest form the driver uses, in place on store slots) on
 person-like masks at 1024 x 1024 (ellipses of a few percent of the frame with holes and specks: the shape real Crowd-SAM
-masks have) and on the noise-like masks random weights produce in bench.py.  CSAM_CC_NO_TRIVIAL=1 disables the
-trivial-tile fast paths for the A/B."""
+masks have) and on the noise-like masks random weights produce in bench.py."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
