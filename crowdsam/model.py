@@ -209,6 +209,12 @@ class CrowdSAM:
         non-CUDA devices: the depth-2 pipeline of generate(image, next_image=...)."""
         B = self.encoder_batch if batch is None else int(batch)
         it = iter(images)
+        # EPS sweeps (pruning, or small prompt batches) are latency chains of ~30 short launches per batch beside which the
+        # look-ahead runs for the WHOLE sweep: the longer launches of a batched pass hold the chain up more than they save
+        # (shipped configuration on MI355X: 19.1 ms per frame at one frame ahead, 20.5 / 20.8 at groups of 2 / 4), so the
+        # groups are for dense sweeps; an explicit ``batch`` argument is honoured either way
+        if batch is None and (math.isfinite(self.filter_thresh) or self.points_per_batch < 256):
+            B = 1
         if B <= 1 or self.crop_n_layers > 0 or self.device.type != "cuda":
             try:
                 cur = next(it)
@@ -371,7 +377,7 @@ class CrowdSAM:
                 if torch.is_tensor(t):
                     t.record_stream(main)           # allocated on the side stream, read on the main one later
 
-    def _lookahead_step(self, look):
+    def _lookahead_step(self, look, early=False):
         """Image-batched look-ahead, called once per frame where _prefetch would be (EPS sweeps: before the sweep is queued;
         dense sweeps: after): on the side stream, (1) at the first frame of a group the NEXT group's frames go up and into the
         encoders' input buffers, (2) chunk j of len(group) of the next group's encoder passes, (3) the decoder constants of the
@@ -391,7 +397,8 @@ class CrowdSAM:
             if states is not None:
                 self._next_group = self._group_upload(nxt, states=states)
             if self._next_group is not None:
-                self.predictor.group_chunk(self._next_group["group"], j, len(cur))
+                # beside an EPS sweep's latency chain one stream of full-chip launches disturbs it less than two (as in _prefetch)
+                self.predictor.group_chunk(self._next_group["group"], j, len(cur), two_streams=not early)
             rec, b = (self._cur_group, j + 1) if j + 1 < len(cur) else (self._next_group, 0)
             if rec is not None:
                 self._prefetched = dict(src=rec["frames"][b], crop_box=None, state=rec["states"][b],
@@ -401,7 +408,7 @@ class CrowdSAM:
 
     def _run_ahead(self, look, early):
         if look is not None:
-            self._lookahead_step(look)
+            self._lookahead_step(look, early=early)
         elif self._next_image is not None:
             self._prefetch(self._next_image, early=early)
         self._next_image = None

@@ -193,7 +193,7 @@ class SamPredictor:
                     feat=bufs["feat"], dtok=bufs["dtok"], bufset=bufset, enc=enc, dino=dino)
 
     @torch.no_grad()
-    def group_chunk(self, g, c, n):
+    def group_chunk(self, g, c, n, two_streams=True):
         """Chunk c of n of the group's encoder passes on the current stream: blocks [c * depth / n, (c + 1) * depth / n) of
         both backbones; chunk 0 starts with the patch embeddings, chunk n - 1 ends with SAM's neck and DINOv2's final norm
         (features into the group's buffers).  One hipGraph per (group shape, c, n).  A chunk continues the residual streams
@@ -212,7 +212,7 @@ class SamPredictor:
                 dino.final_norm([t[:N_DINO] for t in g["dtok"][:B]], B)
 
         def run():
-            two = dino is not None and self.group_two_streams
+            two = dino is not None and self.group_two_streams and two_streams
             if two:       # DINOv2's share of the chunk on a second stream (fork / join; inside a capture: two graph branches)
                 main = torch.cuda.current_stream()
                 if self._side_stream is None:
@@ -240,7 +240,7 @@ class SamPredictor:
 
         if dino is None or not hip.GRAPHS_ENABLED or hip.timer_active():
             return run()
-        key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap, self.group_two_streams)
+        key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap, self.group_two_streams and two_streams)
         ent = self._group_graphs.get(key)
         if ent is None:
             run()                                   # this call's execution (also sets kernel attributes)

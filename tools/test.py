@@ -85,13 +85,22 @@ def run(args, config, logger):
         image_ids = [i for i in range(args.start_idx, end_idx)]
         logger.info(f"total images  to process { len(image_ids)}")
         loaded = (load_img_and_annotation(dataset_path, annots, config["data"]["dataset"], i) for i in image_ids)
-        nxt = next(loaded, None)
-        for id_ in image_ids:
+        # The look-ahead is this build's extension (a model with the reference's plain generate(image) is called as is):
+        # CrowdSAM.generate_stream reads ahead of the frame it returns -- one frame with the shipped EPS configuration, a
+        # group of test.encoder_batch frames (one image-batched encoder pass) with a dense sweep -- so the records of the
+        # frames in flight wait in a queue
+        import collections
+        pending = collections.deque()
+
+        def frames():
+            for rec in loaded:
+                pending.append(rec)
+                yield rec[0]
+
+        results = model.generate_stream(frames()) if hasattr(model, "generate_stream") else (model.generate(f) for f in frames())
+        for id_, result in zip(image_ids, results):
             logger.debug(f"start processing {id_}")
-            (image, gt_boxes, image_id), nxt = nxt, next(loaded, None)     # one image of look-ahead (depth-2 pipeline)
-            # (the look-ahead is this build's extension: a model with the reference's plain generate(image) is called as is)
-            kw = {"next_image": nxt[0]} if nxt is not None and hasattr(model, "generate_stream") else {}
-            result = model.generate(image, **kw)
+            image, gt_boxes, image_id = pending.popleft()
             output_content.append(instance_record(image_id, len(gt_boxes) - 1, result))     # "- 1" as tools/test.py:69
             logger.debug(f"process for image:{id_} is done")
             if args.visualize:
