@@ -38,7 +38,7 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
     needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", "r0%d_pmc_traffic.json" % r) for r in (4, 3, 2)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", "r0%d_pmc_traffic.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     try:
         d = json.load(open(path))
@@ -256,7 +256,8 @@ def main():
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
-        args.batch = 4 if args.steps >= 16 else 2 if args.steps >= 8 else 1
+        # EPS sweeps are latency chains that a batched pass holds up (CrowdSAM.generate_stream): one frame ahead there
+        args.batch = 1 if args.mode == "eps" else 4 if args.steps >= 16 else 2 if args.steps >= 8 else 1
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way

@@ -398,7 +398,7 @@ class CrowdSAM:
                 self._next_group = self._group_upload(nxt, states=states)
             if self._next_group is not None:
                 # beside an EPS sweep's latency chain one stream of full-chip launches disturbs it less than two (as in _prefetch)
-                self.predictor.group_chunk(self._next_group["group"], j, len(cur), two_streams=not early)
+                self.predictor.group_chunk(self._next_group["group"], j, len(cur), two_streams=not early and not self.inline_ahead)
             rec, b = (self._cur_group, j + 1) if j + 1 < len(cur) else (self._next_group, 0)
             if rec is not None:
                 self._prefetched = dict(src=rec["frames"][b], crop_box=None, state=rec["states"][b],
@@ -446,7 +446,7 @@ class CrowdSAM:
             # first frame of a stream: its whole group is encoded now, in one image-batched pass (nothing to overlap it with)
             self._cur_group = self._group_upload(look["cur"])
             if self._cur_group is not None:
-                self.predictor.group_chunk(self._cur_group["group"], 0, 1)
+                self.predictor.group_chunk(self._cur_group["group"], 0, 1, two_streams=not self.inline_ahead)
                 pf = dict(src=image, crop_box=None, state=self._cur_group["states"][0],
                           bundle=self.predictor.group_bundle(self._cur_group["group"], 0))
         if pf is not None and pf["src"] is image and (pf["crop_box"] is None or pf["crop_box"] == list(crop_box)):
