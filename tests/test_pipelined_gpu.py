@@ -119,3 +119,31 @@ def test_pil_look_ahead_is_adopted(cuda):
     assert adopted == [1]
     _same(a, serial[0])
     _same(b, serial[1])
+
+
+def test_multi_crop_through_one_batched_pass_equals_crop_by_crop(cuda):
+    """Multi-crop mode (crowdsam/model.py:151-178: 1 + 4 crops, each resized to max_size and encoded) with the real backbones' plans
+    (SAM vit_test128 + DINOv2 at depth 2): the five crops as ONE image-batched pass of both encoders (CrowdSAM._encode_crops)
+    against the crop-by-crop route -- identical results, field for field."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG
+    from tests.test_pipeline_gpu import ARCH, _config
+    cfg = dict(PIPE_CFG)
+    cfg.update(crop_n_layers=1)
+    m = CrowdSAM(_config(cfg), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_state_dict=synth.make_dino_state_dict(depth=2),
+                 dino_depth=2)
+    img = synth.synthetic_crowd_frame(4, 1366, 90)[:700]
+    calls = []
+    orig = m.predictor.group_chunk
+    m.predictor.group_chunk = lambda g, c, n, **kw: (calls.append(g["B"]), orig(g, c, n, **kw))[1]
+    np.random.seed(9)
+    batched = m.generate(img)
+    assert calls == [5], calls                                  # one pass over the five crops
+    m._encode_crops = lambda image, boxes: None                 # crop by crop: set_image per crop
+    np.random.seed(9)
+    serial = m.generate(img)
+    assert calls == [5]
+    assert len(batched["boxes"]) == len(serial["boxes"])
+    _same(batched, serial)
+    torch.cuda.synchronize()
