@@ -2,7 +2,6 @@
 time, TFLOP/s.  Eager launches with events (graphs and the side streams off), so the times are the kernels' own."""
 import os
 import sys
-os.environ["CSAM_TWO_STREAMS"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import collections
 import numpy as np
@@ -12,6 +11,8 @@ from crowdsam.model import CrowdSAM
 from crowdsam.utils import DEFAULT_TEST_CONFIG
 
 hip.GRAPHS_ENABLED = False
+import segment_anything_cs.predictor as _pred
+_pred._TWO_STREAMS = False
 t = dict(DEFAULT_TEST_CONFIG)
 t.update(grid_size=64, points_per_batch=4096, stability_score_thresh=0.25, pos_sim_thresh=-float("inf"),
          filter_thresh=float("inf"), max_prompts=4096, box_nms_thresh=1.0, crop_nms_thresh=1.0, pred_iou_thresh=0.889)

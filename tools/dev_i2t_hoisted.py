@@ -20,7 +20,7 @@ e0.record()
 for _ in range(5): f()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"ABL={os.environ.get('CSAM_I2T_ABL')} hoisted i2t B={B}: {ms*1e3:.0f} us  write {B*T*512/ms/1e9:.2f} TB/s")
+print(f"hoisted i2t B={B}: {ms*1e3:.0f} us  write {B*T*512/ms/1e9:.2f} TB/s")
 ws = torch.empty(hip.i2t_rank_workspace_bytes(B) // 2, dtype=torch.float16, device=dev)
 f2 = lambda: hip.i2t_rank(X, 0, Q, 0, k, v, Wo, bo, g, be, 1e-5, out, B, T, ws)
 for _ in range(2): f2()
