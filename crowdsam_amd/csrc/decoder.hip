@@ -43,6 +43,21 @@ __global__ __launch_bounds__(256) void point_tokens_kernel(const float* __restri
   t[6 * 256 + ch] = not_a_point[ch];
 }
 
+// box prompts (prompt_encoder.py:95-102, :152-163 with points == None): tokens[b] = [iou_token; mask_tokens(4);
+// PE(x0, y0) + point_embed[2]; PE(x1, y1) + point_embed[3]] -- two corner tokens and NO padding point, i.e. the same seven
+// tokens per prompt the one-point form has, so every decoder kernel downstream serves box prompts unchanged.
+__global__ __launch_bounds__(256) void box_tokens_kernel(const float* __restrict__ boxes, const float* __restrict__ G,
+                                                         const float* __restrict__ out_tokens5,
+                                                         const float* __restrict__ point_embed2,
+                                                         const float* __restrict__ point_embed3, float* __restrict__ tokens) {
+  const int b = blockIdx.x, ch = threadIdx.x;
+  float* t = tokens + (long)b * 7 * 256;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) t[r * 256 + ch] = out_tokens5[r * 256 + ch];
+  t[5 * 256 + ch] = pe_value(boxes[b * 4], boxes[b * 4 + 1], G, ch) + point_embed2[ch];
+  t[6 * 256 + ch] = pe_value(boxes[b * 4 + 2], boxes[b * 4 + 3], G, ch) + point_embed3[ch];
+}
+
 // pure PE rows for arbitrary points: used once per model for the dense 64x64 PE
 // (prompt_encoder.py:64-73,198-209: grid point (i+0.5)/64 == pixel 16*i+7.5 in the 1024 frame)
 __global__ __launch_bounds__(256) void pe_points_kernel(const float* __restrict__ coords,
@@ -644,6 +659,16 @@ extern "C" int csam_point_tokens(void* stream, const float* coords, const float*
   hipLaunchKernelGGL(point_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, coords, gauss, out_tokens5,
                      point_embed1, not_a_point, tokens);
   CSAM_LAUNCH_CHECK("csam_point_tokens");
+  return CSAM_OK;
+}
+
+extern "C" int csam_box_tokens(void* stream, const float* boxes_xyxy, const float* gauss, const float* out_tokens5,
+                               const float* point_embed2, const float* point_embed3, float* tokens, int B) {
+  CSAM_REQUIRE(boxes_xyxy && gauss && out_tokens5 && point_embed2 && point_embed3 && tokens && B > 0,
+               "csam_box_tokens: bad args");
+  hipLaunchKernelGGL(box_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, boxes_xyxy, gauss, out_tokens5,
+                     point_embed2, point_embed3, tokens);
+  CSAM_LAUNCH_CHECK("csam_box_tokens");
   return CSAM_OK;
 }
 

@@ -138,6 +138,8 @@ class DecoderPlan:
         self.gauss = f32(sd[P + "pe_layer.positional_encoding_gaussian_matrix"])
         self.point_embed1 = f32(sd[P + "point_embeddings.1.weight"].reshape(256))
         self.not_a_point = f32(sd[P + "not_a_point_embed.weight"].reshape(256))
+        self.point_embed2 = f32(sd[P + "point_embeddings.2.weight"].reshape(256))      # box corners (prompt_encoder.py:99-100)
+        self.point_embed3 = f32(sd[P + "point_embeddings.3.weight"].reshape(256))
         self.no_mask = f32(sd[P + "no_mask_embed.weight"].reshape(1, 256))
         self.out_tokens5 = f32(torch.cat([sd[M + "iou_token.weight"], sd[M + "mask_tokens.weight"]], 0))
         # dense PE (model constant): grid point (j+0.5)/64 == pixel 16j+7.5
@@ -376,15 +378,24 @@ class DecoderPlan:
         self._tb = dict(layers=layers, final=final, heads=heads)
         return self._tb
 
-    def run_batch(self, coords_f32):
+    def run_batch(self, coords_f32, boxes_f32=None):
         """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C]).
+        ``boxes_f32`` [B,4] XYXY instead of ``coords_f32`` (None): box prompts -- two corner tokens in place of the point and its
+        padding token (prompt_encoder.py:95-102), everything downstream unchanged.
         The ~100 launches of a batch are captured once per batch size into a hipGraph and replayed."""
-        B = coords_f32.shape[0]
+        src = coords_f32 if boxes_f32 is None else boxes_f32
+        B = src.shape[0]
         if B > self.allocB:
             self._alloc(B)
-        c = self.ws["coords"][:B]
-        c.copy_(coords_f32)
-        return self.batch_graphs.run((B, self.slot), lambda: self._run_batch(c))     # the graph holds the slot's pointers
+        if boxes_f32 is None:
+            c = self.ws["coords"][:B]
+        else:
+            if "boxes" not in self.ws or self.ws["boxes"].shape[0] < self.allocB:
+                self.ws["boxes"] = torch.empty(self.allocB, 4, dtype=torch.float32, device=self.device)
+            c = self.ws["boxes"][:B]
+        c.copy_(src)
+        # the graph holds the slot's pointers (and the prompt kind's token kernel)
+        return self.batch_graphs.run((B, self.slot, boxes_f32 is not None), lambda: self._run_batch(c))
 
     def _run_batch(self, coords_f32):
         B = coords_f32.shape[0]
@@ -395,7 +406,10 @@ class DecoderPlan:
         nsplit_i2t = max(1, min(16, 512 // B))
         tokens0, queries = ws["tokens0"][:M7], ws["queries"][:M7]
         q16, qpe16 = ws["q16"][:M7], ws["qpe16"][:M7]
-        hip.point_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed1, self.not_a_point, tokens0)
+        if coords_f32.shape[1] == 4:        # box prompts
+            hip.box_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed2, self.point_embed3, tokens0)
+        else:
+            hip.point_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed1, self.not_a_point, tokens0)
         keys_in, keys_out = None, ws["keysA"]
 
         def ln_queries(g, b):

@@ -40,6 +40,7 @@ SIGNATURES = {
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
     "csam_linear_f32_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _P, _L, _L, _I, _I, _I, _I, _I],
     "csam_point_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
+    "csam_box_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
     "csam_pe_points": [_P, _P, _P, _P, _I],
     "csam_token_self_attn": [_P, _P, _P, _P, _I],
     "csam_attn_t2i": [_P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _P, _L],
@@ -555,6 +556,14 @@ def point_tokens(coords, gauss, out_tokens5, point_embed1, not_a_point, tokens):
     B = coords.shape[0]
     call("csam_point_tokens", _stream(), _ptr(coords), _ptr(gauss), _ptr(out_tokens5), _ptr(point_embed1),
          _ptr(not_a_point), _ptr(tokens), B)
+    return tokens
+
+
+def box_tokens(boxes, gauss, out_tokens5, point_embed2, point_embed3, tokens):
+    """tokens f32 [B,7,256] of B box prompts (boxes f32 [B,4] XYXY in the input frame)."""
+    B = boxes.shape[0]
+    call("csam_box_tokens", _stream(), _ptr(boxes), _ptr(gauss), _ptr(out_tokens5), _ptr(point_embed2), _ptr(point_embed3),
+         _ptr(tokens), B)
     return tokens
 
 

@@ -80,6 +80,31 @@ def golden_decoder():
     print("decoder", low.shape, iou.flatten()[:4], cls.flatten()[:4])
 
 
+def decoder_box_inputs(n=6):
+    """Box prompts for the decoder case above: n seeded XYXY boxes in the 1024 input frame (x0 < x1, y0 < y1)."""
+    rs = np.random.RandomState(21)
+    a = rs.randint(0, 700, size=(n, 2)).astype(np.float64)
+    wh = rs.randint(40, 320, size=(n, 2)).astype(np.float64)
+    return np.concatenate([a, np.minimum(a + wh, 1023.0)], 1)
+
+
+def golden_decoder_box():
+    """Box prompts through the REFERENCE prompt encoder (prompt_encoder.py:95-102: two corner tokens, no padding point) +
+    mask decoder, on the embedding / DINO tokens of decoder_inputs()."""
+    sam, sd, _ = load_ref_sam(TEST_ARCH)
+    emb, dino, _ = decoder_inputs()
+    boxes = torch.as_tensor(decoder_box_inputs())
+    with torch.no_grad():
+        sparse, dense = sam.prompt_encoder(points=None, boxes=boxes, masks=None)
+        pe = sam.prompt_encoder.get_dense_pe()
+        low, iou, cls = sam.mask_decoder(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse,
+                                         dense_prompt_embeddings=dense, multimask_output=True, dino_feats=dino)
+    np.savez_compressed(os.path.join(OUT, "decoder_box_test128.npz"), sparse=sparse.numpy(),
+                        low_sample=low[:, :, ::8, ::8].numpy(), low_sum=low.double().sum((2, 3)).numpy(),
+                        iou=iou.numpy(), cls=cls.numpy())
+    print("decoder_box", sparse.shape, low.shape, iou.flatten()[:4], cls.flatten()[:4])
+
+
 def decoder_big_inputs(n=320):
     """Production-batch decoder case: the embedding / DINO tokens of decoder_inputs() and n seeded prompts (>= 256 so the
     persistent stream kernels -- t2i_stream / upscale_stream / i2t_rank -- are the ones that run on the GPU)."""

@@ -168,6 +168,18 @@ def embed_points(sd, coords, labels, img_size=1024):
     return emb
 
 
+def embed_boxes(sd, boxes, img_size=1024):
+    """prompt_encoder.py:95-102 _embed_boxes + :211-218 forward_with_coords: boxes [B,4] XYXY in the 1024 frame -> the two
+    corner embeddings [B,2,256] (with points == None the sparse prompt is exactly these: no padding point, :152-163)."""
+    c = (boxes + 0.5).reshape(-1, 2, 2).clone()
+    c[:, :, 0] = c[:, :, 0] / img_size
+    c[:, :, 1] = c[:, :, 1] / img_size
+    emb = _pe_encoding(sd, c.to(torch.float))
+    emb[:, 0, :] += sd["prompt_encoder.point_embeddings.2.weight"][0]
+    emb[:, 1, :] += sd["prompt_encoder.point_embeddings.3.weight"][0]
+    return emb
+
+
 # ------------------------------------------------------------------------------------------------
 # two-way transformer + mask decoder (transformer.py, mask_decoder.py)
 # ------------------------------------------------------------------------------------------------

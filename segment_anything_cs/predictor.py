@@ -296,15 +296,18 @@ class SamPredictor:
                 return_logits=False, attn_sim=None, target_embedding=None):
         """Numpy front-end of predict_torch (predictor.py:133-212)."""
         self._require_image()
-        coords_t = labels_t = None
+        coords_t = labels_t = box_t = None
         if point_coords is not None:
             assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
             pc = self.transform.apply_coords(point_coords, self.original_size)
             coords_t = torch.as_tensor(pc, dtype=torch.float, device=self.device)[None, :, :]
             labels_t = torch.as_tensor(point_labels, dtype=torch.int, device=self.device)[None, :]
-        if box is not None or mask_input is not None:
-            raise NotImplementedError("box / mask prompts are not on Crowd-SAM's inference path")
-        masks, iou, cls, low = self.predict_torch(coords_t, labels_t, None, None, multimask_output,
+        if box is not None:                                     # predictor.py:176-179
+            bx = self.transform.apply_boxes(np.asarray(box, dtype=np.float64), self.original_size)
+            box_t = torch.as_tensor(bx, dtype=torch.float, device=self.device).reshape(-1, 4)[:1]
+        if mask_input is not None:
+            raise NotImplementedError("mask prompts are not on Crowd-SAM's inference path")
+        masks, iou, cls, low = self.predict_torch(coords_t, labels_t, box_t, None, multimask_output,
                                                   return_logits=return_logits)
         return masks[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy(), masks[0]
 
@@ -324,13 +327,20 @@ class SamPredictor:
     @torch.no_grad()
     def decode_points(self, point_coords, point_labels, boxes=None, mask_input=None, attn_sim=None,
                       target_embedding=None):
-        """Prompt encoder + mask decoder for one-point prompts: coords [B,1,2] in the input frame.
+        """Prompt encoder + mask decoder for one-point prompts (coords [B,1,2] in the input frame) or box prompts (boxes [B,4]).
         Returns views into the plan's workspace (valid until the next decode)."""
         self._require_image()
-        if boxes is not None or mask_input is not None or attn_sim is not None or target_embedding is not None:
-            raise NotImplementedError("only point prompts are on Crowd-SAM's inference path")
+        if mask_input is not None or attn_sim is not None or target_embedding is not None:
+            raise NotImplementedError("mask prompts / attention priors are not on Crowd-SAM's inference path")
+        if boxes is not None:
+            # box prompts (predictor.py:214-292 `boxes`, prompt_encoder.py:95-102): two corner tokens and no padding point -- the
+            # same seven tokens per prompt as one point, so the fused decoder serves them; a point AND a box would be eight
+            if point_coords is not None:
+                raise NotImplementedError("a box prompt combined with points makes 8 tokens per prompt: not supported")
+            bx = torch.as_tensor(boxes).reshape(-1, 4).to(device=self.device, dtype=torch.float32).contiguous()
+            return self._plan.run_batch(None, boxes_f32=bx)
         if point_coords is None or point_coords.dim() != 3 or point_coords.shape[1] != 1:
-            raise NotImplementedError("the HIP decoder takes exactly one positive point per prompt")
+            raise NotImplementedError("the HIP decoder takes exactly one positive point (or one box) per prompt")
         if point_labels is not None and not bool((torch.as_tensor(point_labels) == 1).all()):
             raise NotImplementedError("only foreground (label 1) point prompts are supported")
         # trap 6: the frame scaling was done by the caller in float64; (x+0.5)/1024 is exact in fp32

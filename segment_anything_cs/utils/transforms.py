@@ -37,3 +37,17 @@ class ResizeLongestSide:
 
     def apply_boxes(self, boxes, original_size):
         return self.apply_coords(boxes.reshape(-1, 2, 2), original_size).reshape(-1, 4)
+
+    def apply_coords_torch(self, coords, original_size):
+        """Tensor form of apply_coords (transforms.py:68-81): fp32 on the tensor's device."""
+        import torch
+        old_h, old_w = original_size
+        new_h, new_w = self.get_preprocess_shape(old_h, old_w, self.target_length)
+        out = coords.clone().to(torch.float)
+        out[..., 0] = out[..., 0] * (new_w / old_w)
+        out[..., 1] = out[..., 1] * (new_h / old_h)
+        return out
+
+    def apply_boxes_torch(self, boxes, original_size):
+        """Bx4 XYXY tensor -> input frame (transforms.py:83-91)."""
+        return self.apply_coords_torch(boxes.reshape(-1, 2, 2), original_size).reshape(-1, 4)

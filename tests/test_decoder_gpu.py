@@ -59,6 +59,39 @@ def test_decoder_vs_reference_golden(plan, cuda):
     np.testing.assert_allclose(tok, g["sparse"], rtol=0, atol=2e-5)
 
 
+def _boxes():
+    rs = np.random.RandomState(21)
+    a = rs.randint(0, 700, size=(6, 2)).astype(np.float64)
+    wh = rs.randint(40, 320, size=(6, 2)).astype(np.float64)
+    return np.concatenate([a, np.minimum(a + wh, 1023.0)], 1)
+
+
+def test_box_prompts_vs_reference_golden(plan, cuda):
+    """Box prompts (predictor.py:214-292 `boxes`; prompt_encoder.py:95-102: corner tokens PE + point_embeddings[2 / 3], no
+    padding point -- seven tokens per prompt like the one-point form) through the same fused decoder, against the REFERENCE's
+    prompt encoder + mask decoder on six seeded boxes (tests/golden/decoder_box_test128.npz, oracle/make_goldens.py)."""
+    g = np.load(os.path.join(G, "decoder_box_test128.npz"))
+    _set_image(plan, cuda)
+    boxes = torch.from_numpy(_boxes().astype(np.float32)).to(cuda).contiguous()
+    masks, iou, cls = plan.run_batch(None, boxes_f32=boxes)
+    torch.cuda.synchronize()
+    tok = plan.ws["tokens0"][:42].view(6, 7, 256)[:, 5:7].cpu().numpy()
+    np.testing.assert_allclose(tok, g["sparse"], rtol=0, atol=2e-5)               # the two corner tokens (fp32 kernel)
+    low = masks.cpu().numpy()
+    ref = g["low_sample"]
+    err = np.abs(low[:, :, ::8, ::8] - ref)
+    scale = np.abs(ref).mean()
+    print("box prompts, low-res logits: mean|ref|=%.3f max err=%.4f mean err=%.5f" % (scale, err.max(), err.mean()))
+    assert err.mean() < 0.005 * scale and err.max() < 0.05 * scale
+    np.testing.assert_allclose(low.astype(np.float64).sum((2, 3)), g["low_sum"], rtol=0, atol=0.005 * scale * 65536)
+    assert np.abs(iou.cpu().numpy() - g["iou"]).max() < 5e-3 and np.abs(cls.cpu().numpy() - g["cls"]).max() < 5e-3
+    # a point batch after a box batch of the same size replays ITS graph (the graph key carries the prompt kind)
+    coords = torch.from_numpy(np.random.RandomState(3).randint(0, 1024, size=(6, 2)).astype(np.float32)).to(cuda)
+    m_pt = plan.run_batch(coords)[0].clone()
+    m_bx = plan.run_batch(None, boxes_f32=boxes)[0].clone()
+    assert torch.equal(m_bx, masks) and not torch.equal(m_pt, m_bx)
+
+
 def test_fg_prior_vs_reference_golden(plan, cuda):
     g = np.load(os.path.join(G, "decoder_test128.npz"))
     _set_image(plan, cuda)

@@ -72,6 +72,20 @@ def test_prompt_encoder_and_decoder_match_reference(sd):
     np.testing.assert_allclose(fg[:, :, ::8, ::8].numpy(), g["fg_sample"], rtol=1e-4, atol=1e-5)
 
 
+def test_box_prompts_match_reference(sd):
+    """oracle box prompts (prompt_encoder.py:95-102) + decoder against the reference's own run on six seeded boxes."""
+    from oracle.make_goldens import decoder_box_inputs
+    g = _load("decoder_box_test128.npz")
+    emb, dino, _ = _decoder_inputs()
+    with torch.no_grad():
+        sparse = so.embed_boxes(sd, torch.as_tensor(decoder_box_inputs()))
+        low, iou, cls = so.mask_decoder(sd, emb, so.dense_pe(sd), sparse, dino)
+    np.testing.assert_allclose(sparse.numpy(), g["sparse"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(low[:, :, ::8, ::8].numpy(), g["low_sample"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(iou.numpy(), g["iou"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cls.numpy(), g["cls"], rtol=1e-4, atol=1e-5)
+
+
 def test_encoder_matches_reference(sd):
     g = _load("encoder_test128.npz")
     D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]

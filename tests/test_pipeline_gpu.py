@@ -338,3 +338,26 @@ def test_generate_max_size_1536_matches_oracle(cuda):
     assert all(r["size"] == [1152, 1536] for r in out["rles"])
     min_iou, max_xor = mask_agreement(out["rles"], ref["rles"], "max_size 1536")
     assert min_iou >= MASK_BOUNDS["max_size"][0] and max_xor <= MASK_BOUNDS["max_size"][1]
+
+
+def test_predictor_box_prompt_api(cuda):
+    """SamPredictor.predict(box=...) / predict_torch(None, None, boxes) (predictor.py:133-292): the numpy front-end scales the box
+    into the input frame (ResizeLongestSide.apply_boxes) and returns the reference's four values; a box together with points is
+    refused (eight tokens per prompt), mask prompts stay refused."""
+    from crowdsam.model import CrowdSAM
+    from crowdsam_amd import synth
+    from oracle.make_goldens import PIPE_CFG
+    m = CrowdSAM(_config(dict(PIPE_CFG)), sam_state_dict=synth.make_sam_state_dict(ARCH), dino_model=GpuStandInDino(cuda))
+    img = synth.synthetic_crowd_frame(2, 1024, 60)[:768]
+    p = m.predictor
+    p.set_image(img)
+    masks, iou, low, masks_t = p.predict(box=np.array([100, 80, 400, 500]), multimask_output=True)
+    assert masks.shape == (4, 768, 1024) and masks.dtype == bool and iou.shape == (4,) and low.shape == (4, 256, 256)
+    bt = torch.tensor([[100.0, 80.0, 400.0, 500.0], [10.0, 20.0, 300.0, 200.0]], device=cuda)
+    mk, io, cl, lw = p.predict_torch(None, None, p.transform.apply_boxes_torch(bt, p.original_size), return_logits=True)
+    assert mk.shape == (2, 4, 768, 1024) and io.shape == (2, 4) and cl.shape[:2] == (2, 4) and lw.shape == (2, 4, 256, 256)
+    np.testing.assert_allclose(lw[0].cpu().numpy(), low, rtol=0, atol=1e-4)      # same box, either entry point
+    with pytest.raises(NotImplementedError):
+        p.predict_torch(torch.zeros(1, 1, 2, device=cuda), torch.ones(1, 1, device=cuda), bt[:1])
+    with pytest.raises(NotImplementedError):
+        p.predict(box=np.array([1, 2, 30, 40]), mask_input=np.zeros((1, 256, 256), np.float32))
