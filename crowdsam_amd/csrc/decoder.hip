@@ -43,6 +43,26 @@ __global__ __launch_bounds__(256) void point_tokens_kernel(const float* __restri
   t[6 * 256 + ch] = not_a_point[ch];
 }
 
+// one point per prompt with an explicit label (prompt_encoder.py:88-92): 1 = foreground (point_embeddings[1]), 0 = background
+// (point_embeddings[0]), -1 = "not a point" (the PE is zeroed and not_a_point_embed added); the padding token as above
+__global__ __launch_bounds__(256) void point_tokens_labeled_kernel(const float* __restrict__ coords, const int* __restrict__ labels,
+                                                                   const float* __restrict__ G,
+                                                                   const float* __restrict__ out_tokens5,
+                                                                   const float* __restrict__ point_embed0,
+                                                                   const float* __restrict__ point_embed1,
+                                                                   const float* __restrict__ not_a_point,
+                                                                   float* __restrict__ tokens) {
+  const int b = blockIdx.x, ch = threadIdx.x;
+  float* t = tokens + (long)b * 7 * 256;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) t[r * 256 + ch] = out_tokens5[r * 256 + ch];
+  const int lb = labels[b];
+  float v = lb == -1 ? 0.f : pe_value(coords[b * 2], coords[b * 2 + 1], G, ch);
+  v += lb == -1 ? not_a_point[ch] : lb == 0 ? point_embed0[ch] : lb == 1 ? point_embed1[ch] : 0.f;
+  t[5 * 256 + ch] = v;
+  t[6 * 256 + ch] = not_a_point[ch];
+}
+
 // box prompts (prompt_encoder.py:95-102, :152-163 with points == None): tokens[b] = [iou_token; mask_tokens(4);
 // PE(x0, y0) + point_embed[2]; PE(x1, y1) + point_embed[3]] -- two corner tokens and NO padding point, i.e. the same seven
 // tokens per prompt the one-point form has, so every decoder kernel downstream serves box prompts unchanged.
@@ -659,6 +679,17 @@ extern "C" int csam_point_tokens(void* stream, const float* coords, const float*
   hipLaunchKernelGGL(point_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, coords, gauss, out_tokens5,
                      point_embed1, not_a_point, tokens);
   CSAM_LAUNCH_CHECK("csam_point_tokens");
+  return CSAM_OK;
+}
+
+extern "C" int csam_point_tokens_labeled(void* stream, const float* coords, const int* labels, const float* gauss,
+                                         const float* out_tokens5, const float* point_embed0, const float* point_embed1,
+                                         const float* not_a_point, float* tokens, int B) {
+  CSAM_REQUIRE(coords && labels && gauss && out_tokens5 && point_embed0 && point_embed1 && not_a_point && tokens && B > 0,
+               "csam_point_tokens_labeled: bad args");
+  hipLaunchKernelGGL(point_tokens_labeled_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, coords, labels, gauss,
+                     out_tokens5, point_embed0, point_embed1, not_a_point, tokens);
+  CSAM_LAUNCH_CHECK("csam_point_tokens_labeled");
   return CSAM_OK;
 }
 

@@ -138,6 +138,7 @@ class DecoderPlan:
         self.gauss = f32(sd[P + "pe_layer.positional_encoding_gaussian_matrix"])
         self.point_embed1 = f32(sd[P + "point_embeddings.1.weight"].reshape(256))
         self.not_a_point = f32(sd[P + "not_a_point_embed.weight"].reshape(256))
+        self.point_embed0 = f32(sd[P + "point_embeddings.0.weight"].reshape(256))      # background points (label 0)
         self.point_embed2 = f32(sd[P + "point_embeddings.2.weight"].reshape(256))      # box corners (prompt_encoder.py:99-100)
         self.point_embed3 = f32(sd[P + "point_embeddings.3.weight"].reshape(256))
         self.no_mask = f32(sd[P + "no_mask_embed.weight"].reshape(1, 256))
@@ -378,10 +379,11 @@ class DecoderPlan:
         self._tb = dict(layers=layers, final=final, heads=heads)
         return self._tb
 
-    def run_batch(self, coords_f32, boxes_f32=None):
+    def run_batch(self, coords_f32, boxes_f32=None, labels_i32=None):
         """coords f32 [B,2] (x,y) in the 1024 input frame -> (masks f32 [B,4,256,256], iou [B,4], cls [B,4,C]).
         ``boxes_f32`` [B,4] XYXY instead of ``coords_f32`` (None): box prompts -- two corner tokens in place of the point and its
-        padding token (prompt_encoder.py:95-102), everything downstream unchanged.
+        padding token (prompt_encoder.py:95-102), everything downstream unchanged.  ``labels_i32`` [B] with point prompts: 1 / 0 /
+        -1 per prompt (prompt_encoder.py:88-92); None = all foreground.
         The ~100 launches of a batch are captured once per batch size into a hipGraph and replayed."""
         src = coords_f32 if boxes_f32 is None else boxes_f32
         B = src.shape[0]
@@ -394,10 +396,17 @@ class DecoderPlan:
                 self.ws["boxes"] = torch.empty(self.allocB, 4, dtype=torch.float32, device=self.device)
             c = self.ws["boxes"][:B]
         c.copy_(src)
+        lab = None
+        if labels_i32 is not None and boxes_f32 is None:
+            if "labels" not in self.ws or self.ws["labels"].shape[0] < self.allocB:
+                self.ws["labels"] = torch.empty(self.allocB, dtype=torch.int32, device=self.device)
+            lab = self.ws["labels"][:B]
+            lab.copy_(labels_i32.reshape(-1))
         # the graph holds the slot's pointers (and the prompt kind's token kernel)
-        return self.batch_graphs.run((B, self.slot, boxes_f32 is not None), lambda: self._run_batch(c))
+        kind = 1 if boxes_f32 is not None else 2 if lab is not None else 0
+        return self.batch_graphs.run((B, self.slot, kind), lambda: self._run_batch(c, lab))
 
-    def _run_batch(self, coords_f32):
+    def _run_batch(self, coords_f32, labels=None):
         B = coords_f32.shape[0]
         ws, st = self.ws, self.state
         M7 = B * 7
@@ -408,6 +417,9 @@ class DecoderPlan:
         q16, qpe16 = ws["q16"][:M7], ws["qpe16"][:M7]
         if coords_f32.shape[1] == 4:        # box prompts
             hip.box_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed2, self.point_embed3, tokens0)
+        elif labels is not None:
+            hip.point_tokens_labeled(coords_f32, labels, self.gauss, self.out_tokens5, self.point_embed0, self.point_embed1,
+                                     self.not_a_point, tokens0)
         else:
             hip.point_tokens(coords_f32, self.gauss, self.out_tokens5, self.point_embed1, self.not_a_point, tokens0)
         keys_in, keys_out = None, ws["keysA"]

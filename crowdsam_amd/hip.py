@@ -40,6 +40,7 @@ SIGNATURES = {
     "csam_linear_f32": [_P, _P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _I, _I],
     "csam_linear_f32_batched": [_P, _P, _L, _L, _P, _L, _L, _P, _L, _P, _L, _L, _I, _I, _I, _I, _I],
     "csam_point_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
+    "csam_point_tokens_labeled": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I],
     "csam_box_tokens": [_P, _P, _P, _P, _P, _P, _P, _I],
     "csam_pe_points": [_P, _P, _P, _P, _I],
     "csam_token_self_attn": [_P, _P, _P, _P, _I],
@@ -556,6 +557,14 @@ def point_tokens(coords, gauss, out_tokens5, point_embed1, not_a_point, tokens):
     B = coords.shape[0]
     call("csam_point_tokens", _stream(), _ptr(coords), _ptr(gauss), _ptr(out_tokens5), _ptr(point_embed1),
          _ptr(not_a_point), _ptr(tokens), B)
+    return tokens
+
+
+def point_tokens_labeled(coords, labels, gauss, out_tokens5, point_embed0, point_embed1, not_a_point, tokens):
+    """point_tokens with an int32 label per prompt (1 foreground / 0 background / -1 not a point)."""
+    B = coords.shape[0]
+    call("csam_point_tokens_labeled", _stream(), _ptr(coords), _ptr(labels), _ptr(gauss), _ptr(out_tokens5), _ptr(point_embed0),
+         _ptr(point_embed1), _ptr(not_a_point), _ptr(tokens), B)
     return tokens
 
 

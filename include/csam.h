@@ -171,6 +171,10 @@ int csam_flash_attn80(void* stream, const void* qkv_f16, long ld, int q_off, int
  * [iou; mask0..3; PE(point)+point_embed[1]; not_a_point]; coords f32 [B,2] in the 1024 frame. */
 int csam_point_tokens(void* stream, const float* coords, const float* gauss_2x128, const float* out_tokens5,
                       const float* point_embed1, const float* not_a_point, float* tokens, int B);
+/* the same with a label per prompt (prompt_encoder.py:88-92): 1 foreground, 0 background (point_embed[0]), -1 not-a-point */
+int csam_point_tokens_labeled(void* stream, const float* coords, const int* labels, const float* gauss_2x128,
+                              const float* out_tokens5, const float* point_embed0, const float* point_embed1,
+                              const float* not_a_point, float* tokens, int B);
 /* box prompts (prompt_encoder.py:95-102,152-163 with points == None; predictor.py:214-292 `boxes`): tokens f32 [B,7,256] =
  * [iou; mask0..3; PE(x0,y0)+point_embed[2]; PE(x1,y1)+point_embed[3]] -- two corner tokens, no padding point: the same seven
  * tokens per prompt, so the decoder entries below serve box prompts unchanged.  boxes f32 [B,4] XYXY in the 1024 frame. */

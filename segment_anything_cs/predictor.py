@@ -341,11 +341,16 @@ class SamPredictor:
             return self._plan.run_batch(None, boxes_f32=bx)
         if point_coords is None or point_coords.dim() != 3 or point_coords.shape[1] != 1:
             raise NotImplementedError("the HIP decoder takes exactly one positive point (or one box) per prompt")
-        if point_labels is not None and not bool((torch.as_tensor(point_labels) == 1).all()):
-            raise NotImplementedError("only foreground (label 1) point prompts are supported")
         # trap 6: the frame scaling was done by the caller in float64; (x+0.5)/1024 is exact in fp32
         c = torch.as_tensor(point_coords)[:, 0, :].to(device=self.device, dtype=torch.float32).contiguous()
-        return self._plan.run_batch(c)
+        lab = None
+        if point_labels is not None:
+            pl = torch.as_tensor(point_labels).reshape(-1).to(torch.int32)
+            if not bool((pl == 1).all()):           # background (0) / not-a-point (-1) prompts: prompt_encoder.py:88-92
+                if not bool(((pl >= -1) & (pl <= 1)).all()):
+                    raise NotImplementedError("point labels must be 1, 0 or -1")
+                lab = pl.to(self.device)
+        return self._plan.run_batch(c, labels_i32=lab)
 
     @torch.no_grad()
     def decode_coords_device(self, coords_f32):

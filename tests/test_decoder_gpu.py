@@ -92,6 +92,24 @@ def test_box_prompts_vs_reference_golden(plan, cuda):
     assert torch.equal(m_bx, masks) and not torch.equal(m_pt, m_bx)
 
 
+def test_labelled_point_tokens_vs_oracle(plan, cuda):
+    """Point prompts with labels 1 / 0 / -1 (prompt_encoder.py:88-92: foreground, background, not-a-point): the token kernel
+    against the oracle's embed_points (pinned to the reference by test_oracle_vs_golden), and a background prompt decodes to
+    something else than the foreground prompt at the same pixel."""
+    from crowdsam_amd import synth
+    from oracle import sam_oracle as so
+    sd = synth.make_sam_state_dict("vit_test128")
+    coords = _set_image(plan, cuda)
+    labels = torch.tensor([1, 0, -1, 0, 1], dtype=torch.int32)
+    m_lab = plan.run_batch(coords, labels_i32=labels.to(cuda))[0].clone()
+    tok = plan.ws["tokens0"][:35].view(5, 7, 256)[:, 5:7].cpu().numpy()
+    ref = so.embed_points(sd, coords.cpu().double()[:, None, :], labels[:, None]).numpy()
+    np.testing.assert_allclose(tok, ref, rtol=0, atol=2e-5)
+    m_fg = plan.run_batch(coords)[0].clone()
+    assert torch.equal(m_lab[0], m_fg[0]) and torch.equal(m_lab[4], m_fg[4])          # label-1 prompts: the same decode
+    assert not torch.equal(m_lab[1], m_fg[1])
+
+
 def test_fg_prior_vs_reference_golden(plan, cuda):
     g = np.load(os.path.join(G, "decoder_test128.npz"))
     _set_image(plan, cuda)
