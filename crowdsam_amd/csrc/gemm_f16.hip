@@ -320,17 +320,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 // nothing else is resident to hide a workgroup's barrier / LDS-latency bubbles.  Group 1 (waves 4-7, rows
 // 128..255) runs one barrier behind group 0, so while one group issues its ds_reads + global_load_lds the other
 // owns the matrix pipe:
-//     tick 2s   : G0 reads the 12 fragments of stage s, issues stage s+4   | G1 32 MFMAs of stage s-1
-//     tick 2s+1 : G0 32 MFMAs of stage s                                  | G1 reads stage s, issues its share of s+4
-// K step 32 per stage (64-B LDS rows, swizzle slot ^= 3*((row>>2)&1)), FIVE-slot ring of 32 KB stages (all of the LDS):
-// three stages in flight, retired by ONE counted vmcnt per stage two barriers before anybody reads them.  Per wave
-// 128 x 64 outputs = 32 accumulator tiles.  (Round 5: the earlier form had two 16-MFMA phases per stage and a four-slot
-// ring with two stages in flight; the k-loop alone is within 3 % of it, inside the encoders -- where the operands miss in
-// L2 more often -- the deeper ring is worth 6 %: profiles/r05_gemm_five_slot_ring.txt.)
+//     tick 4s   : G0 loads {A rows 0-63 of its half, B}  of stage s     | G1 MFMAs of its previous phase
+//     tick 4s+1 : G0 16 MFMAs                                           | G1 loads ...
+// K step 32 per stage (64-B LDS rows, swizzle slot ^= 3*((row>>2)&1)), 4-slot ring of 32 KB stages, stage s+2 is
+// issued ahead of its use (never into a slot the lagging group may still be reading) and retired by ONE counted
+// vmcnt per stage a full phase before anybody reads it.  Per wave 128 x 64 outputs = 32 accumulator tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int G2_STAGE = 2 * 256 * 64;                  // A 256 rows + W 256 rows, 64 B each
-constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB: the 256x256 fp16 output tile
-constexpr int G2_SMEM_ALL = 5 * G2_STAGE;               // five-slot ring = all 160 KB; the [256][2] LayerNorm table sits behind the output tile
+constexpr int G2_SMEM = 4 * G2_STAGE;                   // 128 KB ring; the 256x256 fp16 output tile reuses it
+constexpr int G2_SMEM_ALL = G2_SMEM + 2048;             // + the [256][2] LayerNorm table of csam_gemm_f16_ln
 
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,50 +395,63 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   const int w_base = 16384 + (wc * 64 + fr) * 64 + coff;          // + j * 1024
 
   const int nst = p.K / 32;
-  // One load tick + one 32-MFMA tick per stage and group.  Five-slot ring: stage s+4 is issued in the load tick of stage s
-  // (its slot held stage s-1, whose reads both groups completed before the previous barrier), stage s+2 is retired there by
-  // ONE counted wait -- two barriers before the leading group reads it.
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i < nst) { stage_a(i, i * 32); stage_w(i, i * 32); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Prefetch: A(s+3) is issued in phase b of stage s, W(s+3) in phase a of stage s+1 -- two barriers after the last
+  // read of the slot they overwrite (stage s-1, lagging group's phase b).  The one counted wait per stage sits in
+  // phase a and retires stage s+1 while stage s+2 stays in flight.
+  stage_a(0, 0); stage_w(0, 0);
+  stage_a(1, 32); stage_w(1, 32);
+  if (nst > 2) stage_a(2, 64);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // prologue: everything issued so far has landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (wr == 1) {
+  if (wr == 1) {                                                  // group 1 runs one barrier behind
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
   int slot = 0;
   for (int s = 0; s < nst; ++s) {
     const char* base = smem + slot * G2_STAGE;
-    half8_t af[8], wf[4];
+    half8_t af[4], wf[4];
+    // ---- phase a: rows 0..63 of the wave's half x all its 64 columns
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[j] = *(const half8_t*)(base + w_base + j * 1024);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
-    const int nslot = slot == 0 ? 4 : slot - 1;
-    if (s + 4 < nst) {
-      stage_a(nslot, (s + 4) * 32);
-      stage_w(nslot, (s + 4) * 32);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (s + 3 < nst) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + i * 1024);
+    if (s + 2 < nst) stage_w((slot + 2) & 3, (s + 2) * 32);
+    // retire stage s+1 HERE, a full phase (two barriers) before either group reads it: a counted wait followed by
+    // a read in the same phase is not safe for the other waves' LDS-DMA data.  A(s+2) and W(s+2) may stay in flight.
+    if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    slot = slot == 4 ? 0 : slot + 1;
+    // ---- phase b: rows 64..127, same W fragments
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *(const half8_t*)(base + a_base + (4 + i) * 1024);
+    if (s + 3 < nst) stage_a((slot + 3) & 3, (s + 3) * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot = (slot + 1) & 3;
   }
   if (wr == 0) {                                                  // rejoin
     __builtin_amdgcn_s_barrier();
