@@ -349,8 +349,8 @@ def main():
         loop = "depth-2 pipeline: generate(frame_i, next_image=frame_i+1), batch-of-one encoders beside the previous tail"
     else:
         loop = ("image-batched look-ahead: generate_stream(frames, batch=%d) -- SAM encoder + DINOv2 of the NEXT group of %d frames "
-                "as one pass each, a quarter-pass queued beside each frame's tail; the first group is encoded cold inside "
-                "the timed region" % (B_AHEAD, B_AHEAD))
+                "as one pass each, a share of the pass queued beside each frame's tail; the stream starts with groups of 1, 2, .. "
+                "frames, the first frame is encoded cold inside the timed region" % (B_AHEAD, B_AHEAD))
 
     def frame_stream(idx):
         """The per-image loop under test over frames[idx]: every frame of the timed region is encoded, decoded and

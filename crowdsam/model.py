@@ -122,6 +122,7 @@ class CrowdSAM:
         self.last_candidates = 0
         self._next_image = None      # depth-2 pipeline (generate(next_image=...)): see _prefetch
         self._prefetched = None
+        self.group_ramp = True       # generate_stream starts with groups of 1, 2, 4, .. frames up to encoder_batch
         self.inline_ahead = False    # look-ahead work on the frame's own stream instead of the side stream (no overlap)
         self._look = None            # image-batched look-ahead (generate_stream(batch=B)): see _lookahead_step
         self._cur_group = None
@@ -205,8 +206,9 @@ class CrowdSAM:
         launch-shaped batch-of-one regime), and that pass is cut into len(group) chunks, one queued beside the tail of each
         frame of the group before it.  Every frame's features are bit-identical to a pass of its own
         (tests/test_encoder_batch_gpu.py), no random number is drawn before sample_prompts, so results equal serial
-        generate() calls (tests/test_pipelined_gpu.py).  The first group is encoded cold.  batch <= 1, multi-crop configs and
-        non-CUDA devices: the depth-2 pipeline of generate(image, next_image=...)."""
+        generate() calls (tests/test_pipelined_gpu.py).  The first group is encoded cold; it is ONE frame and the groups double
+        up to B (``group_ramp``), so the first result is not held back by B frames' encoders.  batch <= 1, multi-crop configs
+        and non-CUDA devices: the depth-2 pipeline of generate(image, next_image=...)."""
         B = self.encoder_batch if batch is None else int(batch)
         it = iter(images)
         # EPS sweeps (pruning, or small prompt batches) are latency chains of ~30 short launches per batch beside which the
@@ -226,13 +228,17 @@ class CrowdSAM:
             yield self.generate(cur)
             return
         import itertools
-        cur = list(itertools.islice(it, B))
+        # The stream STARTS with groups of 1, 2, 4, .. frames (group_ramp): the first result waits for one frame's encoders
+        # instead of B frames', and the pipeline fills while it already delivers.  Results do not depend on the grouping.
+        size = 1 if self.group_ramp else B
+        cur = list(itertools.islice(it, size))
         first = True
         self._cur_group = self._next_group = None
         self._group_parity = 0        # the groups' buffer sets alternate from the same start: same hipGraph keys every stream
         try:
             while cur:
-                nxt = list(itertools.islice(it, B))
+                size = min(2 * size, B)
+                nxt = list(itertools.islice(it, size))
                 for j, img in enumerate(cur):
                     self._look = dict(cur=cur, j=j, nxt=nxt, cold=first and j == 0)
                     try:

@@ -28,12 +28,16 @@ def test_pipelined_generate_equals_serial_small_model(cuda):
              [synth.synthetic_crowd_frame(8, 1366, 80)[:700]]
     np.random.seed(11)
     serial = [m.generate(f) for f in frames]
-    for batch in (1, 2, 4):        # depth-2 pipeline; image-batched look-ahead in groups of 2 / 4 (mixed frame shapes in a group)
+    # depth-2 pipeline; image-batched look-ahead in groups of 2 / 4 (mixed frame shapes in a group), the stream starting with
+    # groups of 1, 2, 4 frames (group_ramp, the default) or with a full group
+    for batch, ramp in ((1, True), (2, True), (4, True), (4, False)):
         np.random.seed(11)
+        m.group_ramp = ramp
         piped = list(m.generate_stream(frames, batch=batch))
         assert len(piped) == len(serial) and any(len(o["boxes"]) for o in serial)
         for a, b in zip(serial, piped):
             _same(a, b)
+    m.group_ramp = True
     # a look-ahead that does not come true: the prefetched state must be dropped, not used
     np.random.seed(11)
     a = m.generate(frames[0], next_image=frames[3])
