@@ -251,6 +251,8 @@ def main():
                          "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  Default: 4 from 16 timed steps, "
                          "2 from 8, else 1 -- the first group of a stream is encoded cold INSIDE the timed region, which a short "
                          "run cannot amortise.  With --encoder-only: images per encoder pass (default 1)")
+    ap.add_argument("--no-ramp", action="store_true",
+                    help="developer A/B: the stream starts with a full group of --batch frames instead of groups of 1, 2, 4, ..")
     ap.add_argument("--no-cpu-e2e", action="store_true",
                     help="skip the measured end-to-end oracle image (64 prompts, ~1.5 min of host time) of the cpu_baseline leg")
     args = ap.parse_args()
@@ -343,6 +345,8 @@ def main():
             crowd_how = "calibrated on rank 0's warm-up frame, broadcast to all ranks"
 
     B_AHEAD = max(1, args.batch)
+    if args.no_ramp:
+        model.group_ramp = False
     if args.serial:
         loop = "serial: generate(frame_i), no look-ahead"
     elif B_AHEAD == 1:

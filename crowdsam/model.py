@@ -231,6 +231,7 @@ class CrowdSAM:
         # The stream STARTS with groups of 1, 2, 4, .. frames (group_ramp): the first result waits for one frame's encoders
         # instead of B frames', and the pipeline fills while it already delivers.  Results do not depend on the grouping.
         size = 1 if self.group_ramp else B
+        self.predictor.group_reserve(B)
         cur = list(itertools.islice(it, size))
         first = True
         self._cur_group = self._next_group = None

@@ -170,6 +170,15 @@ class SamPredictor:
     # through SAM's encoder and DINOv2 as ONE pass each (EncoderPlan / DinoPlan: [B * tokens, D] token matrices), cut into
     # chunks at block boundaries so that crowdsam.model can queue one chunk beside each frame's tail.
     @torch.no_grad()
+    def group_reserve(self, B):
+        """Size the encoder plans' workspaces for passes of up to B frames NOW (crowdsam.model.generate_stream calls this before
+        its first group): a stream whose groups grow 1, 2, 4 would otherwise re-allocate them -- and re-capture every chunk
+        graph, whose key carries the capacity -- twice on the way."""
+        self.model.image_encoder.plan()._alloc(B)
+        if isinstance(self.dino_model, DinoV2):
+            self.dino_model.plan()._alloc(B)
+
+    @torch.no_grad()
     def group_begin(self, images, bufset=0):
         """images: device frames as for prefetch_image.  Copies them into the encoders' static input buffers and returns the
         group record, or None when a frame needs the general route.  A third-party DINO object (anything but
@@ -185,9 +194,14 @@ class SamPredictor:
         key = (bufset, str(dev))
         bufs = self._group_bufs.get(key)
         if bufs is None or bufs["feat"].shape[0] < B:
-            bufs = dict(feat=torch.empty(B, 4096, 256, dtype=torch.float32, device=dev),
-                        dtok=[torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=dev) for _ in range(B)])
+            # sized for the encoder plans' capacity from the start: groups of every size (a stream's first groups, its
+            # remainder) share ONE allocation per buffer set, and the chunk graphs captured on it stay valid.  Should it
+            # still have to grow, the graphs that hold the old addresses go with it.
+            cap = max(B, enc.cap)
+            bufs = dict(feat=torch.empty(cap, 4096, 256, dtype=torch.float32, device=dev),
+                        dtok=[torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=dev) for _ in range(cap)])
             self._group_bufs[key] = bufs
+            self._group_graphs = {k: v for k, v in self._group_graphs.items() if k[4] != bufset}
         return dict(B=B, sizes=[hw for _, hw in inputs], input_sizes=[tuple(f.shape[-2:]) for f in raws],
                     sam_views=enc.load_images(raws), dino_views=dino.load_images(raws) if dino is not None else raws,
                     feat=bufs["feat"], dtok=bufs["dtok"], bufset=bufset, enc=enc, dino=dino)

@@ -92,8 +92,11 @@ def test_pipelined_generate_equals_serial_full_model(cuda):
     np.random.seed(3)
     serial = [m.generate(f) for f in frames]
     assert sum(len(o["boxes"]) for o in serial) > 200
-    for batch in (1, 2, 3, 4):
+    # the second (4, True) stream REPLAYS the chunk graphs the first one captured (groups of 1, 2, 4 frames on two buffer sets
+    # that must not move between streams); (4, False) starts with a full group
+    for batch, ramp in ((1, True), (2, True), (3, True), (4, True), (4, True), (4, False), (2, True)):
         np.random.seed(3)
+        m.group_ramp = ramp
         piped = list(m.generate_stream(frames, batch=batch))
         assert len(piped) == len(serial)
         for a, b in zip(serial, piped):

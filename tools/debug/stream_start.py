@@ -21,8 +21,10 @@ for f in frames[:2]:
     m.generate(f)
 
 
-def stream(batch, ramp):
+def stream(batch, ramp, serial_before=0):
     m.group_ramp = ramp
+    for f in frames[:serial_before]:
+        m.generate(f)                  # bench.py's warm-up frames: serial calls between the rehearsal and the timed stream
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ends = []
@@ -32,10 +34,17 @@ def stream(batch, ramp):
     return steps
 
 
+fresh = os.environ.get("FRESH")          # bench.py's order: the rehearsal runs on ONE frame repeated, the timed frames are new arrays
+if fresh:
+    keep = frames
 for name, batch, ramp in (("batch 1", 1, False), ("groups of 4", 4, False), ("ramp 1 2 4", 4, True)):
+    if fresh:
+        frames = [keep[0]] * n
     stream(batch, ramp)
-    for rep in range(2):
-        s = stream(batch, ramp)
+    if fresh:
+        frames = [f.copy() for f in keep]
+    for rep in range(3):
+        s = stream(batch, ramp, serial_before=2 if rep == 2 else 0)
         print("%-12s total %.1f ms, first result %.1f | " % (name, s.sum(), s[0]) + " ".join("%.1f" % v for v in s), flush=True)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
