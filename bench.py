@@ -248,9 +248,9 @@ def main():
                     help="generate() without any look-ahead (A/B of the pipelined loops)")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per image-batched encoder pass of the look-ahead (CrowdSAM.generate_stream(batch=B)); 1 = the "
-                         "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  Default: 4 from 16 timed steps, "
-                         "2 from 8, else 1 -- the first group of a stream is encoded cold INSIDE the timed region, which a short "
-                         "run cannot amortise.  With --encoder-only: images per encoder pass (default 1)")
+                         "depth-2 pipeline of round 4 (one frame ahead, batch-of-one encoders).  Default: 4 (the stream starts with "
+                         "groups of 1 and 2 frames, so short runs do not pay for a cold four-frame pass); EPS mode: 1.  With "
+                         "--encoder-only: images per encoder pass (default 1)")
     ap.add_argument("--no-ramp", action="store_true",
                     help="developer A/B: the stream starts with a full group of --batch frames instead of groups of 1, 2, 4, ..")
     ap.add_argument("--no-cpu-e2e", action="store_true",
@@ -259,7 +259,7 @@ def main():
     args.batch_given = args.batch is not None
     if args.batch is None:
         # EPS sweeps are latency chains that a batched pass holds up (CrowdSAM.generate_stream): one frame ahead there
-        args.batch = 1 if args.mode == "eps" else 4 if args.steps >= 16 else 2 if args.steps >= 8 else 1
+        args.batch = 1 if args.mode == "eps" else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way
