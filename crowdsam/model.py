@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 import crowdsam.utils as utils
-from crowdsam_amd import hip
+from crowdsam_amd import hip, trace
 from crowdsam_amd.dino import DinoV2
 from segment_anything_cs.utils.amg import (MaskData, coco_encode_rle, coco_encode_rles, generate_crop_boxes,
                                            mask_to_coco_rles, mask_to_rle_arrays)
@@ -41,6 +41,19 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 
 
 _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
+_STAGES = ("set_image", "sample_prompts", "eps_sweep", "gather", "nms", "small_regions", "rle")   # _process_crop, in order
+
+
+def profile(on=True, ranges=True):
+    """tools/test.py --profile: per-stage times into CrowdSAM.timings (device-synchronised, so the stages no longer overlap)
+    and roctx ranges for rocprofv3 --marker-trace (the reference has neither).  ``ranges`` alone
+    (on=False) keeps the loop asynchronous."""
+    global _TIMING
+    _TIMING = bool(on)
+    if ranges:
+        trace.enable()
+    else:
+        trace.disable()
 _WORK_STREAM = True          # generate() on its own high-priority stream (False: the caller's stream; tests toggle it)
 _WINDOWED_REGIONS = True      # small-region clean-up and RLE inside the masks' boxes (False: whole frames)
 
@@ -49,10 +62,19 @@ class CrowdSAM:
     vis_img_id = 0
 
     def _tick(self, name, t0):
-        """Per-stage wall time (ms) into self.timings when CSAM_TIMING=1 (adds device syncs: diagnostics only)."""
+        """End of stage ``name``.  Per-stage wall time (ms) into self.timings when CSAM_TIMING=1 / profile(True) (adds device
+        syncs: diagnostics only); with roctx ranges on (crowdsam_amd.trace) the stage's range closes and the next one opens."""
         if _TIMING:
             torch.cuda.synchronize()
             self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        if trace.enabled:
+            if name in _STAGES:
+                trace.pop()
+                k = _STAGES.index(name) + 1
+                if k < len(_STAGES):
+                    trace.push(_STAGES[k])
+            else:
+                trace.mark(name)
         return time.perf_counter()
 
     def __init__(self, config, logger=None, sam_state_dict=None, dino_state_dict=None, dino_depth=24,
@@ -178,6 +200,8 @@ class CrowdSAM:
         packing.  No random number is drawn before sample_prompts, so results are bit-identical to serial calls
         (tests/test_pipelined_gpu.py).  Ignored with crop_n_layers > 0 (the crops of one frame share the buffers)."""
         self._next_image = next_image if self.crop_n_layers == 0 else None
+        d0 = trace.depth
+        trace.push("generate")
         try:
             if not _WORK_STREAM or self.device.type != "cuda":
                 return self._generate_masks(image)
@@ -196,6 +220,7 @@ class CrowdSAM:
             return out
         finally:
             self._next_image = None
+            trace.unwind(d0)
 
     def generate_stream(self, images, batch=None):
         """Iterator over generate(image) for an iterable of frames, pipelined (build extension; the per-image loop of
@@ -414,10 +439,11 @@ class CrowdSAM:
             self._cur_group, self._next_group = self._next_group, None
 
     def _run_ahead(self, look, early):
-        if look is not None:
-            self._lookahead_step(look, early=early)
-        elif self._next_image is not None:
-            self._prefetch(self._next_image, early=early)
+        with trace.range("lookahead"):
+            if look is not None:
+                self._lookahead_step(look, early=early)
+            elif self._next_image is not None:
+                self._prefetch(self._next_image, early=early)
         self._next_image = None
 
     def _prefetch(self, image, early):
@@ -444,7 +470,15 @@ class CrowdSAM:
         self._prefetched = None if bundle is None else dict(src=image, crop_box=None, state=state, bundle=bundle)
 
     def _process_crop(self, image, crop_box):
+        d0 = trace.depth
+        try:
+            return self._process_crop_stages(image, crop_box)
+        finally:
+            trace.unwind(d0)             # an early return (no prompts, no candidates) leaves its stage's range open
+
+    def _process_crop_stages(self, image, crop_box):
         t0 = time.perf_counter()
+        trace.push(_STAGES[0])
         pf, self._prefetched = self._prefetched, None
         if self._pf_stream is not None:
             torch.cuda.current_stream().wait_stream(self._pf_stream)     # a prefetch (used or not) owns the shared buffers
@@ -539,8 +573,9 @@ class CrowdSAM:
                     hip.eps_select(all_pts_dev, alive_dev, B, new_w / old_w, new_h / old_h, pts_b, coords_b, counts)
                     if self.eps_trace is not None:          # debugging / parity aid: the prompts of every round (async copies)
                         self.eps_trace.append((pts_b.clone(), counts[:1].clone()))
-                    bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
-                                             device_batch=(pts_b, coords_b, counts[:1]))
+                    with trace.range("decoder_batch"):
+                        bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
+                                                 device_batch=(pts_b, coords_b, counts[:1]))
                     if prune:
                         hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
                     count += B
@@ -560,7 +595,8 @@ class CrowdSAM:
                     tb = time.perf_counter()
                     if self.eps_trace is not None:
                         self.eps_trace.append((points[sel_idx].copy(), len(sel_idx)))
-                    bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
+                    with trace.range("decoder_batch"):
+                        bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
                     tb = self._tick("eps.batch", tb)
                     if prune and len(alive) > 0:
                         if all_pts_dev is None:

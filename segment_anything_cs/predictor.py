@@ -9,7 +9,7 @@ hoisted decoder constants stay resident in HBM until ``reset_image``.
 import numpy as np
 import torch
 
-from crowdsam_amd import hip
+from crowdsam_amd import hip, trace
 from crowdsam_amd.decoder import N_DINO, N_DINO_PAD
 from crowdsam_amd.dino import DinoV2
 
@@ -93,8 +93,10 @@ class SamPredictor:
         if self._dtok16 is None or self._dtok16.device != raw.device:
             self._dtok16 = torch.zeros(N_DINO_PAD, 1024, dtype=torch.float16, device=raw.device)
         if isinstance(self.dino_model, DinoV2) and not (_TWO_STREAMS and two_streams):
-            feat = self.model.image_encoder.forward_tokens(raw)
-            self.dino_model.patch_tokens16(raw, self._dtok16)
+            with trace.range("sam_encoder"):
+                feat = self.model.image_encoder.forward_tokens(raw)
+            with trace.range("dinov2"):
+                self.dino_model.patch_tokens16(raw, self._dtok16)
         elif isinstance(self.dino_model, DinoV2):
             # the two backbones are independent until the decoder: DINOv2 runs on a side stream next to the SAM
             # encoder, so one's under-filled launches (N = 1024 GEMMs, LayerNorms, the 2.6-workgroups-per-CU
@@ -104,9 +106,10 @@ class SamPredictor:
                 self._side_stream = torch.cuda.Stream(device=raw.device)
             side = self._side_stream
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), trace.range("dinov2"):
                 self.dino_model.patch_tokens16(raw, self._dtok16)
-            feat = self.model.image_encoder.forward_tokens(raw)
+            with trace.range("sam_encoder"):
+                feat = self.model.image_encoder.forward_tokens(raw)
             main.wait_stream(side)
         else:   # third-party DINO object: feed it the reference's tensor (predictor.py:104-106)
             feat = self.model.image_encoder.forward_tokens(raw)
@@ -115,7 +118,8 @@ class SamPredictor:
             self._dtok16[:N_DINO].copy_(tok.reshape(N_DINO, -1))
         plan = self.model.decoder_plan()
         slot = (1 - plan.slot) if prefetch else plan.slot
-        plan.set_image(feat, self._dtok16, slot=slot, activate=not prefetch)      # copies both into the slot's own buffers
+        with trace.range("decoder_constants"):
+            plan.set_image(feat, self._dtok16, slot=slot, activate=not prefetch)  # copies both into the slot's own buffers
         # the API views (features / dino_feats) are served from the slot's OWN copies: the encoders' output buffers are
         # overwritten by the next look-ahead frame while this one is still the current image
         return dict(original_size=tuple(original_image_size), input_size=tuple(transformed_image.shape[-2:]),
@@ -252,6 +256,11 @@ class SamPredictor:
                         tok = self.dino_model.forward_features(x.unsqueeze(0))["x_norm_patchtokens"]
                         g["dtok"][b][:N_DINO].copy_(tok.reshape(N_DINO, -1))
 
+        with trace.range("encoder_chunk %d/%d x%d" % (c + 1, n, B)):
+            self._chunk_run_or_replay(g, c, n, run, two_streams)
+
+    def _chunk_run_or_replay(self, g, c, n, run, two_streams):
+        enc, dino, B = g["enc"], g["dino"], g["B"]
         if dino is None or not hip.GRAPHS_ENABLED or hip.timer_active():
             return run()
         key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap, self.group_two_streams and two_streams)

@@ -3,6 +3,7 @@ arithmetic) against the reference-generated goldens and the oracle."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import crowdsam.utils as cu
@@ -178,3 +179,28 @@ def test_batched_coco_strings_equal_per_mask_strings():
     for r, b in zip(rles, batch):
         assert b == amg.coco_encode_rle(r)
         assert b["counts"] == po.coco_rle_string([int(c) for c in r["counts"]])
+
+
+def test_roctx_ranges_are_balanced_and_off_by_default():
+    """crowdsam_amd.trace (the reference has no tracing): a no-op until enable(); ranges nest, unwind()
+    closes what an early return left open; the roctx library of the ROCm install loads without a profiler attached."""
+    from crowdsam_amd import trace
+    assert not trace.enabled and trace.depth == 0
+    trace.push("x"); trace.pop(); trace.mark("m")
+    assert trace.depth == 0
+    if not trace.enable():
+        pytest.skip("no roctx library in this image")
+    try:
+        with trace.range("generate"):
+            trace.push("set_image")
+            trace.push("sam_encoder")
+            assert trace.depth == 3
+            trace.unwind(1)
+            assert trace.depth == 1
+            trace.mark("eps.batch")
+        assert trace.depth == 0
+        trace.pop()                         # an unmatched pop is ignored
+        assert trace.depth == 0
+    finally:
+        trace.disable()
+    assert not trace.enabled

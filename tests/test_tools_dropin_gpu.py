@@ -54,3 +54,15 @@ def test_tools_test_py_from_checkpoint_files(tmp_path, cuda):
         assert (b >= 0).all() and (b[:, [0, 2]] <= im["width"]).all() and (b[:, [1, 3]] <= im["height"]).all()
     assert sum(len(x["boxes"]) for x in res) > 0
     assert os.path.exists(tmp_path / "out" / "0.jpg")            # -v: visualisation written per image
+
+    # --profile (build extension): same detections, plus the per-rank timings record and roctx ranges
+    # (no profiler attached here: the calls go to the roctx library and nowhere else)
+    out2 = tmp_path / "res_profile.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "test.py"), "-c", str(tmp_path / "cfg.yaml"), "-s", str(out2),
+                        "--profile", "test.grid_size", "6"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert json.load(open(out2)) == res
+    t = json.load(open(tmp_path / "out" / "timings_rank0.json"))
+    assert t["rank"] == 0 and t["images"] == 3 and t["kept_masks"] == sum(len(x["boxes"]) for x in res)
+    for stage in ("set_image", "sample_prompts", "eps_sweep"):
+        assert t["stage_ms_total"][stage] > 0 and t["stage_ms_per_image"][stage] == pytest.approx(t["stage_ms_total"][stage] / 3)

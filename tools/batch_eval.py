@@ -21,6 +21,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import torch
@@ -73,6 +74,8 @@ def parse(argv=None):
     parser.add_argument("-n", "--num_nodes", type=int, default=8, help="Number of nodes (GPUs / processes) to use")
     parser.add_argument("-c", "--config_file", default="./configs/crowdhuman.yaml")
     parser.add_argument("--synthetic", type=int, default=0)
+    parser.add_argument("--profile", action="store_true",
+                        help="per-stage times (device-synchronised) into <output_dir>/timings_rank<r>.json + roctx ranges")
     parser.add_argument("-o", "--output", default="test.json")
     parser.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     parser.add_argument("--keep_json", action="store_true")
@@ -127,9 +130,18 @@ def worker(args):
             model = CrowdSAM(config, logger)
             d = config["data"]
             load = lambda i: utils.load_img_and_annotation(d["dataset_root"], gt_js, d["dataset"], i)[0]
-        for i in range(start, end):
-            out = model.generate(load(i))
+        if args.profile:
+            import crowdsam.model as cm
+            cm.profile(True)
+        t_run, kept = time.perf_counter(), 0
+        # the rank's shard as ONE stream (CrowdSAM.generate_stream: the next frames' encoders run beside this frame's tail)
+        for i, out in zip(range(start, end), model.generate_stream(load(i) for i in range(start, end))):
             rows.append(detections_to_rows(i, out["boxes"], out["scores"]))
+            kept += len(out["boxes"])
+        if args.profile:
+            from crowdsam_amd import trace
+            trace.write_timings(os.path.join(config["environ"]["output_dir"], "timings_rank%d.json" % rank), rank, model,
+                                end - start, kept, time.perf_counter() - t_run)
     else:   # --backend gloo: launch / shard / gather plumbing only (one deterministic fake detection per image)
         for i in range(start, end):
             rows.append(detections_to_rows(i, [[i, i, i + 10, i + 20]], [1.0 / (1 + i)]))

@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -36,6 +37,10 @@ def envrion_init(argv=None):
     parser.add_argument("-s", "--save_path", help="the path to dump json result", type=str, default="")
     parser.add_argument("-r", "--local_rank", type=int, default=0)
     parser.add_argument("--synthetic", type=int, default=0, help="(build extension) N synthetic frames, seeded weights")
+    parser.add_argument("--profile", action="store_true",
+                        help="(build extension; the reference has no tracing, SURVEY.md section 5) per-stage times -- "
+                             "device-synchronised, so the stages do not overlap -- into <output_dir>/timings_rank<r>.json, and "
+                             "roctx ranges for `rocprofv3 --marker-trace --kernel-trace -- python tools/test.py --profile ...`")
     parser.add_argument("options", nargs=argparse.REMAINDER)
     args = parser.parse_args(argv)
     configs = modify_config(load_config(args.config_file), args.options)
@@ -68,6 +73,10 @@ def run(args, config, logger):
         print(f"set device cuda:{args.local_rank}")
         config["environ"]["device"] = f"cuda:{args.local_rank}"
     output_content = []
+    if getattr(args, "profile", False):
+        import crowdsam.model as _cm
+        _cm.profile(True)
+    t_run = time.perf_counter()
     if args.synthetic:
         from crowdsam_amd import synth
         model = CrowdSAM(config, logger, sam_state_dict=synth.make_sam_state_dict(config["model"]["sam_model"]),
@@ -110,6 +119,11 @@ def run(args, config, logger):
                 visualize_result(image, result, class_names, save_path, conf_thresh=config["vis"]["vis_thresh"],
                                  FP_ind=FP_list, FN_ind=FN_list, vis_masks=args.mode == "seg")
             del result
+    if getattr(args, "profile", False):
+        from crowdsam_amd import trace
+        trace.write_timings(os.path.join(config["environ"]["output_dir"], "timings_rank%d.json" % args.local_rank), args.local_rank,
+                            model, len(output_content), sum(len(r.get("boxes", [])) for r in output_content),
+                            time.perf_counter() - t_run)
     if args.save_path == "":
         file_path = os.path.join(config["environ"]["output_dir"], "result.json")
         print(f"dump json file to {file_path}")
