@@ -32,8 +32,8 @@ for i in 1 2 3; do python bench.py --no-cpu-baseline --no-kernel-timer 2>/dev/nu
 python tools/dev_bench_gemm_batch.py > gpurun_out/${TAG}_gemm_shapes_batched.txt 2>&1
 python tools/dev_bench_gemm_k.py > gpurun_out/${TAG}_gemm_fixed_cost.txt 2>&1
 python tools/dev_bench_encoder_batch.py > gpurun_out/${TAG}_encoder_batch.txt 2>&1
-bash tools/prof_bench.sh ${TAG}_bench_serial --steps 10 --warmup 3 --no-cpu-e2e --serial     # per-kernel averages: the serial trace
-bash tools/prof_bench.sh ${TAG}_bench --steps 20 --warmup 3 --no-cpu-e2e                      # the headline loop (--batch 4)
+bash tools/prof_bench.sh ${TAG}_bench --steps 10 --warmup 3 --no-cpu-e2e --serial               # <tag>_bench_kernel_stats.txt: per-kernel averages, the SERIAL trace
+bash tools/prof_bench.sh ${TAG}_bench_pipelined --steps 20 --warmup 3 --no-cpu-e2e            # <tag>_bench_pipelined_kernel_stats.txt: the headline loop (--batch 4)
 bash tools/prof_bench.sh ${TAG}_encoder_only --encoder-only --steps 20 --warmup 3
 bash tools/prof_bench.sh ${TAG}_encoder_only_batch4 --encoder-only --batch 4 --steps 10 --warmup 3
 bash tools/prof_bench.sh ${TAG}_eps_mode --mode eps --grid 192 --points-per-batch 32 --stability-thresh 0.25 --steps 6 --warmup 3 --crowd-keep 0
