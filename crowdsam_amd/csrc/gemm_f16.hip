@@ -198,7 +198,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
-  float* stab = (float*)(smem + TBM * 512);            // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
+  // tiles taller than 128 rows go out in passes of 128 rows (PR): the staged fp32 slab stays at 64 KB, two workgroups per CU
+  constexpr int NPASS = TBM > 128 ? TBM / 128 : 1, PR = TBM / NPASS;
+  float* stab = (float*)(smem + PR * 512);             // [TBM][2] mean, rstd (LayerNorm-consumer launches only)
   if (p.st_in) {
     for (int r = tid; r < TBM; r += NT) {
       const int m = min(bm0 + r, p.M - 1);
@@ -215,16 +217,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   // as whole coalesced rows, 16 B per lane.
   const bool res_late = p.R && p.c_dt == CSAM_DT_F32 && p.r_dt == CSAM_DT_F32;   // residual added at copy-out
 #pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+  if (NPASS == 1 || (wm * MI * 16) / PR == pass) {
+#pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int row = wm * MI * 16 + mi * 16 + fr;     // row inside the workgroup tile
-    const int m = bm0 + row;
+    const int trow = wm * MI * 16 + mi * 16 + fr;    // row inside the workgroup tile
+    const int row = trow - pass * PR;                // row inside this pass's slab
+    const int m = bm0 + trow;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int col = wn * NI * 16 + ni * 16 + fg * 4;    // column inside the 128-col tile
       const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
       if (p.st_in) {                                      // folded LayerNorm: rstd * (acc - mean * colsum)
-        const float mean = stab[2 * row], rstd = stab[2 * row + 1];
+        const float mean = stab[2 * trow], rstd = stab[2 * trow + 1];
         const floatx4 cs = *(const floatx4*)(p.colsum + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = rstd * (v[j] - mean * cs[j]);
@@ -262,13 +268,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       }
     }
   }
+  }
   __syncthreads();
   if (p.c_dt == CSAM_DT_F32) {
 #pragma unroll
-    for (int it = 0; it < TBM * 32 / NT; ++it) {
-      const int c = tid + it * NT;                     // TBM*32 16-B pieces: row c>>5, LDS slot c&31
+    for (int it = 0; it < PR * 32 / NT; ++it) {
+      const int c = tid + it * NT;                     // PR*32 16-B pieces: row c>>5, LDS slot c&31
       const int row = c >> 5, sl = c & 31;
-      const int m = bm0 + row;
+      const int m = bm0 + pass * PR + row;
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < p.M) {
         const int n = bn0 + ((sl ^ (row & 31)) << 2);
@@ -302,15 +309,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     }
   } else {
 #pragma unroll
-    for (int it = 0; it < TBM * 16 / NT; ++it) {
-      const int c = tid + it * NT;                     // TBM*16 16-B pieces: row c>>4, LDS slot c&15
+    for (int it = 0; it < PR * 16 / NT; ++it) {
+      const int c = tid + it * NT;                     // PR*16 16-B pieces: row c>>4, LDS slot c&15
       const int row = c >> 4, sl = c & 15;
-      const int m = bm0 + row;
+      const int m = bm0 + pass * PR + row;
       if (m < p.M) {
         const int n = bn0 + ((sl ^ (row & 15)) << 3);
         GEMM_ST((half8_t*)((half_t*)p.C + (long)m * p.ldc + n), *(const half8_t*)(smem + c * 16));
       }
     }
+  }
+  if (pass + 1 < NPASS) __syncthreads();               // the slab is free for the next pass
   }
 }
 
@@ -574,7 +583,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
 #define CSAM_GEMM_LAUNCH(MI_, NI_, WM_, WN_, NS_, KB_)                                                         \
   {                                                                                                            \
     constexpr int SM_RING = NS_ * (WM_ * MI_ * 16 + BN) * KB_ * 2;                                             \
-    constexpr int SM_OUT = WM_ * MI_ * 16 * 512;                                                               \
+    constexpr int SM_OUT = (WM_ * MI_ * 16 > 128 ? 128 : WM_ * MI_ * 16) * 512;                                \
     constexpr int SM = (SM_RING > SM_OUT + 2048 ? SM_RING : SM_OUT + 2048);  /* + [TBM][2] LayerNorm table */  \
     static csam_once_t set;                                                                                    \
     auto kern = gemm_f16_kernel<MI_, NI_, WM_, WN_, NS_, KB_>;                                                 \
@@ -582,7 +591,15 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SM);                  \
     hipLaunchKernelGGL(kern, grid, dim3(WM_ * WN_ * 64), SM, (hipStream_t)stream, p);                          \
   }
-  if (mid) CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
+  // 256-row tiles (8 waves, 3 x 24 KB ring, the fp32 slab staged in two passes of 128 rows: still two workgroups per CU) when they
+  // fill whole rounds of the 512 resident workgroups: a quarter fewer operand bytes per flop and half the tile prologues.  SAM at
+  // four images per pass (M = 16384, N = 1024: 512 tiles): proj 75.5 -> 68.1 us, fc2 171 -> 163; DINOv2's M = 21320 (672 tiles = 1.3
+  // rounds) loses 8-17 % to the part-filled round and stays on 128 rows (profiles/r05_gemm_tall_tile.txt)
+  const long t256r = (long)(N / BN) * csam_cdiv(M, 256);
+  const bool tall = !small && !mid && batch == 1 && t256r >= 512 && 100 * t256r >= 90 * 512 * csam_cdiv(t256r, 512);
+  if (tall) grid = dim3((N / BN) * csam_cdiv(M, 256), 1, batch);
+  if (tall) CSAM_GEMM_LAUNCH(4, 4, 4, 2, 3, 32)
+  else if (mid) CSAM_GEMM_LAUNCH(3, 4, 2, 2, 2, 64)
   else if (small) CSAM_GEMM_LAUNCH(2, 4, 2, 2, 3, 64)
   else CSAM_GEMM_LAUNCH(4, 4, 2, 2, 2, 64)
   CSAM_LAUNCH_CHECK("csam_gemm_f16");
