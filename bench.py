@@ -281,7 +281,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
-    from crowdsam.model import CrowdSAM
+    from crowdsam.model import CrowdSAM, settle_host
     from crowdsam_amd import hip, synth
     from crowdsam.utils import DEFAULT_TEST_CONFIG as DEFAULT_TEST_CFG
 
@@ -378,6 +378,12 @@ def main():
                 pass
         for i in range(args.warmup):
             model.generate(frames[i])            # no look-ahead: nothing of a timed frame may run outside the timed region
+        # Host hygiene of a serving loop: everything alive now (modules, plans, graphs, the frames) is long-lived -- moved out
+        # of the garbage collector's generations, so that the full collection CPython starts every few thousand container
+        # allocations does not walk it inside a frame (measured: ONE 100 ms step per ~92 frames, profiles/r05_gc_stall.txt)
+        n_frozen = settle_host()
+        if step_trace is not None:
+            print("settle_host(): %d long-lived objects out of the collector's generations" % n_frozen, file=sys.stderr, flush=True)
         barrier()
         t0 = time.perf_counter()
         for k, out in enumerate(frame_stream(timed)):

@@ -44,6 +44,18 @@ _TIMING = os.environ.get("CSAM_TIMING", "0") == "1"
 _STAGES = ("set_image", "sample_prompts", "eps_sweep", "gather", "nms", "small_regions", "rle")   # _process_crop, in order
 
 
+def settle_host():
+    """Host hygiene for a per-image loop (tools/test.py, tools/batch_eval.py, bench.py call it once the model is built and
+    warm): everything alive at this point -- modules, weights, plans, captured graphs -- is long-lived, so it is moved out of
+    the garbage collector's generations (gc.freeze).  CPython otherwise walks all of it in the full collection it starts
+    every few thousand container allocations: one 100 ms frame in ~90 on the bench's loop (profiles/r05_gc_stall.txt).
+    Returns the number of objects frozen."""
+    import gc
+    gc.collect()
+    gc.freeze()
+    return gc.get_freeze_count()
+
+
 def profile(on=True, ranges=True):
     """tools/test.py --profile: per-stage times into CrowdSAM.timings (device-synchronised, so the stages no longer overlap)
     and roctx ranges for rocprofv3 --marker-trace (the reference has neither).  ``ranges`` alone

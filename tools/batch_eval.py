@@ -130,9 +130,10 @@ def worker(args):
             model = CrowdSAM(config, logger)
             d = config["data"]
             load = lambda i: utils.load_img_and_annotation(d["dataset_root"], gt_js, d["dataset"], i)[0]
+        import crowdsam.model as cm
         if args.profile:
-            import crowdsam.model as cm
             cm.profile(True)
+        cm.settle_host()                 # long-lived objects out of the garbage collector's way (crowdsam.model.settle_host)
         t_run, kept = time.perf_counter(), 0
         # the rank's shard as ONE stream (CrowdSAM.generate_stream: the next frames' encoders run beside this frame's tail)
         for i, out in zip(range(start, end), model.generate_stream(load(i) for i in range(start, end))):

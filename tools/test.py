@@ -73,14 +73,15 @@ def run(args, config, logger):
         print(f"set device cuda:{args.local_rank}")
         config["environ"]["device"] = f"cuda:{args.local_rank}"
     output_content = []
+    import crowdsam.model as _cm
     if getattr(args, "profile", False):
-        import crowdsam.model as _cm
         _cm.profile(True)
     t_run = time.perf_counter()
     if args.synthetic:
         from crowdsam_amd import synth
         model = CrowdSAM(config, logger, sam_state_dict=synth.make_sam_state_dict(config["model"]["sam_model"]),
                          dino_state_dict=synth.make_dino_state_dict())
+        _cm.settle_host()
         end_idx = args.synthetic if args.end_idx == -1 else min(args.end_idx, args.synthetic)
         ids = list(range(args.start_idx, end_idx))
         # one frame of look-ahead (CrowdSAM.generate_stream): frame i+1's encoders run beside frame i's tail
@@ -88,6 +89,7 @@ def run(args, config, logger):
             output_content.append(instance_record(f"synthetic_{id_}.jpg", 0, result))
     else:
         model = CrowdSAM(config, logger)
+        _cm.settle_host()                # long-lived objects out of the garbage collector's way (one 100 ms frame in ~90 otherwise)
         logger.info("load images and annotations from crowdhuman dataset..")
         annots = json.load(open(config["data"]["json_file"]))
         end_idx = len(annots["images"]) if args.end_idx == -1 else min(args.end_idx, len(annots["images"]))
