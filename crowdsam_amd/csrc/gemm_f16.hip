@@ -527,6 +527,147 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile on FOUR waves, one per SIMD, 128 x 128 outputs per wave in a[0:255] -- the main loop is generated,
+// hand-scheduled assembly (tools/gen/gen_gemm4w_asm.py -> gemm4w_asm.inc: one barrier per 64-wide K tile, LDS reads and LDS-DMA
+// threaded one per MFMA gap).  16 ds_read_b128 per 64 MFMAs where the ping-pong kernel's 128 x 64 wave tile needs 12 per 32.
+// LDS: two stages of [A: 256 rows x 128 B][W: 256 rows x 128 B], slot ^= row & 7; the fp16 output tile reuses them.
+// Same operands, same ascending chain of 32-wide MFMA steps per output element as the other kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int G4_STAGE = 65536;
+constexpr int G4_SMEM = 2 * G4_STAGE + 2048;            // + the [256][2] LayerNorm table
+
+#include "gemm4w_asm.inc"
+
+template <int I, int J>
+__device__ __forceinline__ void gemm4w_store_tile(char* smem, const GemmArgs& p, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
+                                                  const float* stab, int wm, int wn, int fr, int fg) {
+  const int row = wm * 128 + I * 16 + fr;
+  const int col = wn * 128 + J * 16 + fg * 4;
+  floatx4 v = gemm4w_acc<I * 8 + J>();
+  if (p.st_in) {
+    const float mean = stab[2 * row], rstd = stab[2 * row + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * cz[J][e]);
+  }
+  v += bz[J];
+  if (p.act == CSAM_ACT_GELU) {
+    const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
+    v = floatx4{g0[0], g0[1], g1[0], g1[1]};
+  } else if (p.act == CSAM_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+  }
+  half4_t h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+  const int sl = (col >> 3) ^ (row & 31);
+  *(half4_t*)(smem + row * 512 + sl * 16 + ((col >> 2) & 1) * 8) = h;
+}
+
+template <int I, int... Js>
+__device__ __forceinline__ void gemm4w_store_row(char* smem, const GemmArgs& p, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
+                                                 const float* stab, int wm, int wn, int fr, int fg) {
+  (gemm4w_store_tile<I, Js>(smem, p, bz, cz, stab, wm, wn, fr, fg), ...);
+}
+
+__global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int gx = p.N / 256;
+  int t = blockIdx.x;
+  if (p.xcd) {
+    const int ntiles = gridDim.x, b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int bn0 = (t % gx) * 256, bm0 = (t / gx) * 256;
+
+  // LDS-DMA pieces: 1 KB = 8 rows x 128 B; wave w issues pieces w*8 .. w*8+7 of the activation tile and of the weight tile.
+  // Lane l of a piece lands in LDS row l >> 3, slot l & 7, and fetches global chunk (l & 7) ^ (row & 7) (the bank swizzle).
+  unsigned oa[8], ow[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (wave * 8 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const int gm = min(bm0 + row, p.M - 1) - bm0;      // rows past M are loaded (clamped) but never stored
+    oa[i] = (unsigned)(gm * (int)p.lda * 2 + chunk * 16);
+    ow[i] = (unsigned)(row * (int)p.ldw * 2 + chunk * 16);
+  }
+  const half_t* pa = p.A + (long)bm0 * p.lda;
+  const half_t* pw = p.W + (long)bn0 * p.ldw;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+  unsigned ra[2][2], rw[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned sl = (unsigned)(((ks * 4 + fg) ^ (fr & 7)) << 4);
+      ra[s][ks] = lds0 + s * G4_STAGE + (wm * 128 + fr) * 128 + sl;
+      rw[s][ks] = lds0 + s * G4_STAGE + 32768 + (wn * 128 + fr) * 128 + sl;
+    }
+  // epilogue operands, fetched under the main loop: the lane's 8 x 4 bias values / column sums, tile row tid's LayerNorm partials
+  floatx4 bz[8], cz[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = bn0 + wn * 128 + j * 16 + fg * 4;
+    bz[j] = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+    cz[j] = p.st_in ? *(const floatx4*)(p.colsum + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  floatx4 pr[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) pr[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (p.st_in) {
+    const floatx4* s4 = (const floatx4*)(p.st_in + (long)min(bm0 + tid, p.M - 1) * p.st_np * 2);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (2 * i < p.st_np) pr[i] = s4[i];
+  }
+
+  gemm4w_mainloop(pa, pw, ldsw, oa, ow, ra, rw, (p.K / 64 - 2) / 2);
+
+  __syncthreads();                                     // every wave is done with the operand stages: the output tile goes there
+  float* stab = (float*)(smem + 2 * G4_STAGE);         // [256][2] mean, rstd
+  if (p.st_in) {                                       // same summation order as ln_row_stats
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      sm += pr[i][0];
+      sq += pr[i][1];
+      sm += pr[i][2];
+      sq += pr[i][3];
+    }
+    const float inv = 1.0f / (float)(p.st_np * 128);
+    const float mean = sm * inv;
+    stab[2 * tid] = mean;
+    stab[2 * tid + 1] = rsqrtf(fmaxf(sq * inv - mean * mean, 0.f) + p.eps);
+    __syncthreads();
+  }
+  // fp16 tile staged in LDS [256 rows][512 B], 32 slots of 16 B, slot ^= row & 31, then written as whole coalesced rows
+  gemm4w_store_row<0, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<1, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<2, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<3, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<4, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<5, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<6, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  gemm4w_store_row<7, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
+  __syncthreads();
+#pragma unroll 8
+  for (int it = 0; it < 32; ++it) {
+    const int c = tid + it * 256;                      // 256 rows x 32 slots
+    const int row = c >> 5, sl = c & 31;
+    const int m = bm0 + row;
+    if (m < p.M) {
+      const int n = bn0 + ((sl ^ (row & 31)) << 3);
+      GEMM_ST((half8_t*)((half_t*)p.C + (long)m * p.ldc + n), *(const half8_t*)(smem + c * 16));
+    }
+  }
+}
+
 }  // namespace
 
 static int gemm_launch(void* stream, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
@@ -575,7 +716,14 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
   if (batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 && fills && K >= 64 &&
       (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
     dim3 g256((unsigned)t256);
-    hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM_ALL, (hipStream_t)stream, p);
+    if (K % 128 == 0 && K >= 256) {                    // the hand-scheduled four-wave kernel (two K tiles per loop trip)
+      static csam_once_t set4w;
+      if (csam_first_call(set4w))
+        hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
+      hipLaunchKernelGGL(gemm4w_kernel, g256, dim3(256), G4_SMEM, (hipStream_t)stream, p);
+    } else {
+      hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM_ALL, (hipStream_t)stream, p);
+    }
     CSAM_LAUNCH_CHECK("csam_gemm_f16");
     return CSAM_OK;
   }

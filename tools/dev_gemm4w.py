@@ -1,0 +1,56 @@
+"""Developer harness for the hand-scheduled four-wave GEMM (gemm4w_kernel): error against an fp32 reference, an output hash (run
+it under two builds with CSAM_LIB=... to check bit-identity), time beside the vendor library on the image-batched encoder shapes.
+    python tools/dev_gemm4w.py [--quick]"""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from crowdsam_amd import hip
+
+dev = torch.device("cuda")
+
+
+def tm(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+shapes = [(300, 2048, 128), (256, 2048, 256), (1000, 2304, 4096), (4096, 3072, 1024), (4096, 4096, 1024), (5330, 3072, 1024),
+          (16384, 3072, 1024), (16384, 4096, 1024), (21320, 3072, 1024), (21320, 4096, 1024), (4096, 4096, 4096), (16384, 4096, 4096)]
+if "--quick" in sys.argv:
+    shapes = shapes[:4]
+print("lib:", hip.LIB_PATH)
+for M, N, K in shapes:
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).half()
+    bias = torch.randn(N, generator=g).to(dev)
+    out = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    hip.gemm_f16(a, w, out=out, bias=bias)
+    torch.cuda.synchronize()
+    h = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]
+    rows = torch.randint(0, M, (64,), generator=g).to(dev)
+    ref = a[rows].float() @ w.float().t() + bias
+    err = (out[rows].float() - ref).abs().max().item()
+    # repeated launches must agree bitwise (an LDS-DMA race would show as flicker)
+    flick = 0
+    for _ in range(6):
+        o2 = torch.empty_like(out)
+        hip.gemm_f16(a, w, out=o2, bias=bias)
+        flick += int(not torch.equal(o2, out))
+    t_own = tm(lambda: hip.gemm_f16(a, w, out=out, bias=bias))
+    o16 = torch.empty_like(out)
+    t_lib = tm(lambda: torch.mm(a, w.t(), out=o16))
+    fl = 2.0 * M * N * K / 1e6
+    print(f"M={M:6d} N={N:5d} K={K:5d}: own {t_own:7.1f} us {fl / t_own:7.1f} TF/s | vendor {t_lib:7.1f} us {fl / t_lib:7.1f} TF/s | "
+          f"ratio {t_lib / t_own:.2f} | err {err:.2e} finite {bool(torch.isfinite(out).all())} flicker {flick} hash {h}", flush=True)
