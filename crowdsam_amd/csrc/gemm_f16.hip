@@ -60,6 +60,12 @@ __device__ __forceinline__ float2_t ln_row_stats(const float* st, int np, float 
   return float2_t{mean, rsqrtf(var + eps)};
 }
 
+// The folded LayerNorm + bias of one accumulator value, with the two FMAs spelled out: every tile shape must round the same way
+// (an image's features are bit-identical whichever kernel its batch size selects), so the contraction is not left to the compiler.
+__device__ __forceinline__ float ln_fold1(float acc, float mean, float rstd, float cs, float b) {
+  return __builtin_fmaf(rstd, __builtin_fmaf(-mean, cs, acc), b);
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -229,13 +235,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       const int col = wn * NI * 16 + ni * 16 + fg * 4;    // column inside the 128-col tile
       const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
-      if (p.st_in) {                                      // folded LayerNorm: rstd * (acc - mean * colsum)
+      const floatx4 bb = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+      if (p.st_in) {                                      // folded LayerNorm: rstd * (acc - mean * colsum) + bias
         const float mean = stab[2 * trow], rstd = stab[2 * trow + 1];
         const floatx4 cs = *(const floatx4*)(p.colsum + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rstd * (v[j] - mean * cs[j]);
+        for (int j = 0; j < 4; ++j) v[j] = ln_fold1(v[j], mean, rstd, cs[j], bb[j]);
+      } else {
+        v += bb;
       }
-      if (p.bias) v += *(const floatx4*)(p.bias + n);
       if (p.act == CSAM_ACT_GELU && p.c_dt == CSAM_DT_F16) {
         // fp16-bound output: packed polynomial GELU (13 instructions per pair).  With the erf form the activation
         // was ~40 % of the fc1 GEMM's cycles at K = 1024 (64 GELUs per lane against 512 MFMA cycles per K step).
@@ -497,9 +505,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
       floatx4 v = acc[i][j];
       if (p.st_in) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * cz[j][e]);
+        for (int e = 0; e < 4; ++e) v[e] = ln_fold1(v[e], mean, rstd, cz[j][e], bz[j][e]);
+      } else {
+        v += bz[j];
       }
-      v += bz[j];
       if (p.act == CSAM_ACT_GELU) {
         const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
         v = floatx4{g0[0], g0[1], g1[0], g1[1]};
@@ -537,40 +546,64 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 constexpr int G4_STAGE = 65536;
 constexpr int G4_SMEM = 2 * G4_STAGE + 2048;            // + the [256][2] LayerNorm table
 
-#include "gemm4w_asm.inc"
+#ifndef G4_ASM_INC          // developer A/B: tools/debug/gemm4w_variants.sh builds ablated / re-placed main loops
+#define G4_ASM_INC "gemm4w_asm.inc"
+#endif
+#include G4_ASM_INC
 
-template <int I, int J>
-__device__ __forceinline__ void gemm4w_store_tile(char* smem, const GemmArgs& p, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
-                                                  const float* stab, int wm, int wn, int fr, int fg) {
-  const int row = wm * 128 + I * 16 + fr;
-  const int col = wn * 128 + J * 16 + fg * 4;
-  floatx4 v = gemm4w_acc<I * 8 + J>();
-  if (p.st_in) {
-    const float mean = stab[2 * row], rstd = stab[2 * row + 1];
+// Epilogue of one PAIR of accumulator tiles (I, 2 JP) and (I, 2 JP + 1), straight from the registers: after the LayerNorm fold /
+// bias / activation each lane holds 4 consecutive columns (8 B of fp16) of row fr in both tiles; v_permlane16_swap exchanges the
+// odd 16-lane rows of the first tile's registers with the even rows of the second's, after which lanes fg = 0, 2 hold 8 consecutive
+// columns (16 B) of tile 2 JP and lanes fg = 1, 3 of tile 2 JP + 1: ONE 16-byte store per lane and pair, 64-B segments per row,
+// no LDS round trip and no barrier (cdna_hip_programming.md T21, the 16-lane form).
+template <bool LN, int ACT, int I, int JP>
+__device__ __forceinline__ void gemm4w_store_pair(half_t* crow, bool ok, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
+                                                  float mean, float rstd) {
+  floatx4 v[2] = {gemm4w_acc<I * 8 + 2 * JP>(), gemm4w_acc<I * 8 + 2 * JP + 1>()};
+  unsigned h[2][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * cz[J][e]);
+  for (int t = 0; t < 2; ++t) {
+    if (LN) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[t][e] = ln_fold1(v[t][e], mean, rstd, cz[2 * JP + t][e], bz[2 * JP + t][e]);
+    } else {
+      v[t] += bz[2 * JP + t];
+    }
   }
-  v += bz[J];
-  if (p.act == CSAM_ACT_GELU) {
-    const float2_t g0 = csam_gelu_poly2((float2_t){v[0], v[1]}), g1 = csam_gelu_poly2((float2_t){v[2], v[3]});
-    v = floatx4{g0[0], g0[1], g1[0], g1[1]};
-  } else if (p.act == CSAM_ACT_RELU) {
+  if (ACT == CSAM_ACT_GELU) {
+    float2_t g[4] = {{v[0][0], v[0][1]}, {v[0][2], v[0][3]}, {v[1][0], v[1][1]}, {v[1][2], v[1][3]}};
+    csam_gelu_poly2_n<4>(g);
+    v[0] = floatx4{g[0][0], g[0][1], g[1][0], g[1][1]};
+    v[1] = floatx4{g[2][0], g[2][1], g[3][0], g[3][1]};
+  } else if (ACT == CSAM_ACT_RELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[t][e] = v[t][e] > 0.f ? v[t][e] : 0.f;
   }
-  half4_t h;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-  const int sl = (col >> 3) ^ (row & 31);
-  *(half4_t*)(smem + row * 512 + sl * 16 + ((col >> 2) & 1) * 8) = h;
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const half2_t hh = {(half_t)v[t][2 * q], (half_t)v[t][2 * q + 1]};
+      h[t][q] = __builtin_bit_cast(unsigned, hh);
+    }
+  const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  if (ok) *(uintx4*)(crow + JP * 32) = uintx4{s0[0], s1[0], s0[1], s1[1]};
 }
 
-template <int I, int... Js>
-__device__ __forceinline__ void gemm4w_store_row(char* smem, const GemmArgs& p, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
-                                                 const float* stab, int wm, int wn, int fr, int fg) {
-  (gemm4w_store_tile<I, Js>(smem, p, bz, cz, stab, wm, wn, fr, fg), ...);
+template <bool LN, int ACT, int I>
+__device__ __forceinline__ void gemm4w_store_row(half_t* crow, bool ok, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
+                                                 float mean, float rstd) {
+  gemm4w_store_pair<LN, ACT, I, 0>(crow, ok, bz, cz, mean, rstd);
+  gemm4w_store_pair<LN, ACT, I, 1>(crow, ok, bz, cz, mean, rstd);
+  gemm4w_store_pair<LN, ACT, I, 2>(crow, ok, bz, cz, mean, rstd);
+  gemm4w_store_pair<LN, ACT, I, 3>(crow, ok, bz, cz, mean, rstd);
 }
 
+template <bool LN, int ACT>
 __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -615,12 +648,12 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
   for (int j = 0; j < 8; ++j) {
     const int n = bn0 + wn * 128 + j * 16 + fg * 4;
     bz[j] = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-    cz[j] = p.st_in ? *(const floatx4*)(p.colsum + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+    cz[j] = LN ? *(const floatx4*)(p.colsum + n) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
   floatx4 pr[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) pr[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-  if (p.st_in) {
+  if (LN) {
     const floatx4* s4 = (const floatx4*)(p.st_in + (long)min(bm0 + tid, p.M - 1) * p.st_np * 2);
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -629,9 +662,14 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
 
   gemm4w_mainloop(pa, pw, ldsw, oa, ow, ra, rw, (p.K / 64 - 2) / 2);
 
-  __syncthreads();                                     // every wave is done with the operand stages: the output tile goes there
-  float* stab = (float*)(smem + 2 * G4_STAGE);         // [256][2] mean, rstd
-  if (p.st_in) {                                       // same summation order as ln_row_stats
+#ifdef G4_SKIP_EPILOGUE                                 // developer timing ablation (tools/debug/gemm4w_variants.sh)
+  if (p.M > 0) return;
+#endif
+  float2_t ms[8];                                      // (mean, rstd) of the lane's row in each of its 8 row tiles
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ms[i] = float2_t{0.f, 1.f};
+  if (LN) {                                            // [256][2] table behind the operand stages; same summation order as ln_row_stats
+    float* stab = (float*)(smem + 2 * G4_STAGE);
     float sm = 0.f, sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -645,27 +683,21 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
     stab[2 * tid] = mean;
     stab[2 * tid + 1] = rsqrtf(fmaxf(sq * inv - mean * mean, 0.f) + p.eps);
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ms[i] = *(const float2_t*)(stab + 2 * (wm * 128 + i * 16 + fr));
   }
-  // fp16 tile staged in LDS [256 rows][512 B], 32 slots of 16 B, slot ^= row & 31, then written as whole coalesced rows
-  gemm4w_store_row<0, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<1, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<2, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<3, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<4, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<5, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<6, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  gemm4w_store_row<7, 0, 1, 2, 3, 4, 5, 6, 7>(smem, p, bz, cz, stab, wm, wn, fr, fg);
-  __syncthreads();
-#pragma unroll 8
-  for (int it = 0; it < 32; ++it) {
-    const int c = tid + it * 256;                      // 256 rows x 32 slots
-    const int row = c >> 5, sl = c & 31;
-    const int m = bm0 + row;
-    if (m < p.M) {
-      const int n = bn0 + ((sl ^ (row & 31)) << 3);
-      GEMM_ST((half8_t*)((half_t*)p.C + (long)m * p.ldc + n), *(const half8_t*)(smem + c * 16));
-    }
-  }
+  // lane (fr, fg) stores 16 B of row fr of each row tile at column pair-base + (fg & 1) * 16 + (fg >> 1) * 8 (see gemm4w_store_pair)
+  const int m0 = bm0 + wm * 128 + fr;
+  half_t* c0 = (half_t*)p.C + (long)m0 * p.ldc + bn0 + wn * 128 + (fg & 1) * 16 + (fg >> 1) * 8;
+  const long rs = 16 * p.ldc;
+  gemm4w_store_row<LN, ACT, 0>(c0, m0 < p.M, bz, cz, ms[0][0], ms[0][1]);
+  gemm4w_store_row<LN, ACT, 1>(c0 + rs, m0 + 16 < p.M, bz, cz, ms[1][0], ms[1][1]);
+  gemm4w_store_row<LN, ACT, 2>(c0 + 2 * rs, m0 + 32 < p.M, bz, cz, ms[2][0], ms[2][1]);
+  gemm4w_store_row<LN, ACT, 3>(c0 + 3 * rs, m0 + 48 < p.M, bz, cz, ms[3][0], ms[3][1]);
+  gemm4w_store_row<LN, ACT, 4>(c0 + 4 * rs, m0 + 64 < p.M, bz, cz, ms[4][0], ms[4][1]);
+  gemm4w_store_row<LN, ACT, 5>(c0 + 5 * rs, m0 + 80 < p.M, bz, cz, ms[5][0], ms[5][1]);
+  gemm4w_store_row<LN, ACT, 6>(c0 + 6 * rs, m0 + 96 < p.M, bz, cz, ms[6][0], ms[6][1]);
+  gemm4w_store_row<LN, ACT, 7>(c0 + 7 * rs, m0 + 112 < p.M, bz, cz, ms[7][0], ms[7][1]);
 }
 
 }  // namespace
@@ -717,10 +749,22 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
       (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
     dim3 g256((unsigned)t256);
     if (K % 128 == 0 && K >= 256) {                    // the hand-scheduled four-wave kernel (two K tiles per loop trip)
-      static csam_once_t set4w;
-      if (csam_first_call(set4w))
-        hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
-      hipLaunchKernelGGL(gemm4w_kernel, g256, dim3(256), G4_SMEM, (hipStream_t)stream, p);
+#define CSAM_GEMM4W(LN_, ACT_)                                                                                   \
+  {                                                                                                              \
+    static csam_once_t set4w;                                                                                    \
+    auto k4 = gemm4w_kernel<LN_, ACT_>;                                                                          \
+    if (csam_first_call(set4w)) hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM); \
+    hipLaunchKernelGGL(k4, g256, dim3(256), G4_SMEM, (hipStream_t)stream, p);                                    \
+  }
+      if (st_in) {
+        if (act == CSAM_ACT_GELU) CSAM_GEMM4W(true, CSAM_ACT_GELU)
+        else if (act == CSAM_ACT_RELU) CSAM_GEMM4W(true, CSAM_ACT_RELU)
+        else CSAM_GEMM4W(true, CSAM_ACT_NONE)
+      } else {
+        if (act == CSAM_ACT_GELU) CSAM_GEMM4W(false, CSAM_ACT_GELU)
+        else if (act == CSAM_ACT_RELU) CSAM_GEMM4W(false, CSAM_ACT_RELU)
+        else CSAM_GEMM4W(false, CSAM_ACT_NONE)
+      }
     } else {
       hipLaunchKernelGGL(gemm256_kernel, g256, dim3(512), G2_SMEM_ALL, (hipStream_t)stream, p);
     }

@@ -29,6 +29,9 @@ shapes = [(300, 2048, 128), (256, 2048, 256), (1000, 2304, 4096), (4096, 3072, 1
           (16384, 3072, 1024), (16384, 4096, 1024), (21320, 3072, 1024), (21320, 4096, 1024), (4096, 4096, 4096), (16384, 4096, 4096)]
 if "--quick" in sys.argv:
     shapes = shapes[:4]
+AB = "--ab" in sys.argv          # timing only, three shapes: for tools/debug/gemm4w_variants.sh builds
+if AB:
+    shapes = [(16384, 3072, 1024), (16384, 4096, 1024), (16384, 4096, 4096)]
 print("lib:", hip.LIB_PATH)
 for M, N, K in shapes:
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -44,13 +47,29 @@ for M, N, K in shapes:
     err = (out[rows].float() - ref).abs().max().item()
     # repeated launches must agree bitwise (an LDS-DMA race would show as flicker)
     flick = 0
-    for _ in range(6):
+    for _ in range(0 if AB else 6):
         o2 = torch.empty_like(out)
         hip.gemm_f16(a, w, out=o2, bias=bias)
         flick += int(not torch.equal(o2, out))
+    # the LayerNorm-consumer + GELU epilogue (csam_gemm_f16_ln): hash for the two-build bit-identity check, error vs fp32 LN -> GEMM -> GELU
+    h2, err2, t_ln = "-", float("nan"), float("nan")
+    if K // 128 <= 10 and (K // 128) % 2 == 0:
+        af = a.float().view(M, K // 128, 128)
+        stats = torch.stack([af.sum(-1), (af * af).sum(-1)], -1).contiguous()
+        colsum = w.float().sum(1).contiguous()
+        o3 = torch.empty_like(out)
+        hip.gemm_f16_ln(a, w, o3, bias=bias, act=hip.ACT_GELU, stats_in=stats, colsum=colsum, eps=1e-6)
+        torch.cuda.synchronize()
+        h2 = hashlib.sha1(o3.cpu().numpy().tobytes()).hexdigest()[:12]
+        x = a[rows].float()
+        xn = (x - x.mean(1, keepdim=True)) * torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+        ref2 = torch.nn.functional.gelu(xn @ w.float().t() + bias)
+        err2 = (o3[rows].float() - ref2).abs().max().item()
+        t_ln = tm(lambda: hip.gemm_f16_ln(a, w, o3, bias=bias, act=hip.ACT_GELU, stats_in=stats, colsum=colsum, eps=1e-6))
     t_own = tm(lambda: hip.gemm_f16(a, w, out=out, bias=bias))
     o16 = torch.empty_like(out)
-    t_lib = tm(lambda: torch.mm(a, w.t(), out=o16))
+    t_lib = t_own if AB else tm(lambda: torch.mm(a, w.t(), out=o16))
     fl = 2.0 * M * N * K / 1e6
     print(f"M={M:6d} N={N:5d} K={K:5d}: own {t_own:7.1f} us {fl / t_own:7.1f} TF/s | vendor {t_lib:7.1f} us {fl / t_lib:7.1f} TF/s | "
-          f"ratio {t_lib / t_own:.2f} | err {err:.2e} finite {bool(torch.isfinite(out).all())} flicker {flick} hash {h}", flush=True)
+          f"ratio {t_lib / t_own:.2f} | err {err:.2e} finite {bool(torch.isfinite(out).all())} flicker {flick} hash {h} | "
+          f"LN+GELU {t_ln:7.1f} us err {err2:.2e} hash {h2}", flush=True)

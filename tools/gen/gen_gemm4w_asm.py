@@ -62,17 +62,23 @@ def frag_reads(ks, stage):
     return out
 
 
+BUF = "bufglds" in ABLATE       # LDS-DMA through buffer descriptors s[44:47] / s[48:51] + the K offset in s52
+
+
 def glds_pairs(stage):
     """16 (m0 write, LDS-DMA) pairs: this wave's 8 activation pieces and 8 weight pieces of a stage."""
     out = []
+    lda = "buffer_load_dwordx4 %%[oa%d], s[44:47], s52 offen lds" if BUF else "global_load_lds_dwordx4 %%[oa%d], s[40:41]"
+    ldw = "buffer_load_dwordx4 %%[ow%d], s[48:51], s52 offen lds" if BUF else "global_load_lds_dwordx4 %%[ow%d], s[42:43]"
     for i in range(8):
-        out.append(("s_add_u32 m0, %%[ldsw], %d" % (stage * STAGE + i * 1024), "global_load_lds_dwordx4 %%[oa%d], s[40:41]" % i))
+        out.append(("s_add_u32 m0, %%[ldsw], %d" % (stage * STAGE + i * 1024), lda % i))
     for i in range(8):
-        out.append(("s_add_u32 m0, %%[ldsw], %d" % (stage * STAGE + W_OFF + i * 1024), "global_load_lds_dwordx4 %%[ow%d], s[42:43]" % i))
+        out.append(("s_add_u32 m0, %%[ldsw], %d" % (stage * STAGE + W_OFF + i * 1024), ldw % i))
     return out
 
 
-ADVANCE = ["s_add_u32 s40, s40, 128", "s_addc_u32 s41, s41, 0", "s_add_u32 s42, s42, 128", "s_addc_u32 s43, s43, 0"]
+ADVANCE = (["s_add_u32 s52, s52, 128"] if BUF else
+           ["s_add_u32 s40, s40, 128", "s_addc_u32 s41, s41, 0", "s_add_u32 s42, s42, 128", "s_addc_u32 s43, s43, 0"])
 
 
 def weave(mfmas, side):
@@ -116,6 +122,10 @@ def tile(stage, with_glds, with_next):
 
 def program():
     L = ["s_mov_b32 %[keep], m0", "s_mov_b64 s[40:41], %[pa]", "s_mov_b64 s[42:43], %[pw]"]
+    if BUF:
+        L += ["s_mov_b64 s[44:45], %[pa]", "s_and_b32 s45, s45, 0xffff", "s_mov_b32 s46, 0x80000000", "s_mov_b32 s47, 0x00020000",
+              "s_mov_b64 s[48:49], %[pw]", "s_and_b32 s49, s49, 0xffff", "s_mov_b32 s50, 0x80000000", "s_mov_b32 s51, 0x00020000",
+              "s_mov_b32 s52, 0", "s_nop 4"]
     # prologue: tiles 0 and 1 into stages 0 and 1
     for stage in range(2):
         for m0, ld in glds_pairs(stage):
@@ -147,7 +157,7 @@ def emit():
         for ks in range(2):
             ins.append('[ra%d%d] "v"(ra[%d][%d])' % (s, ks, s, ks))
             ins.append('[rw%d%d] "v"(rw[%d][%d])' % (s, ks, s, ks))
-    clob = ['"memory"', '"scc"', '"s40"', '"s41"', '"s42"', '"s43"'] + ['"v%d"' % n for n in range(128, 256)] + ['"a%d"' % n for n in range(256)]
+    clob = ['"memory"', '"scc"'] + ['"s%d"' % n for n in range(40, 53 if BUF else 44)] + ['"v%d"' % n for n in range(128, 256)] + ['"a%d"' % n for n in range(256)]
 
     def wrap(items, ind):
         out, cur = [], ind
