@@ -543,6 +543,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // LDS: two stages of [A: 256 rows x 128 B][W: 256 rows x 128 B], slot ^= row & 7; the fp16 output tile reuses them.
 // Same operands, same ascending chain of 32-wide MFMA steps per output element as the other kernels: bit-identical results.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef G4_GROUP_M
+#define G4_GROUP_M 4
+#endif
 constexpr int G4_STAGE = 65536;
 constexpr int G4_SMEM = 2 * G4_STAGE + 2048;            // + the [256][2] LayerNorm table
 
@@ -616,7 +619,11 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
     const int ntiles = gridDim.x, b = blockIdx.x, xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int bn0 = (t % gx) * 256, bm0 = (t / gx) * 256;
+  // ... and inside an XCD's run, tile rows are taken G4_GROUP_M at a time, column-major inside the group: the 32 tiles an XCD has
+  // in flight then cover about 4 x 8 tiles (12 operand panels per K step through its L2) instead of 2 x 16 (18)
+  const int gy = (p.M + 255) / 256;
+  const int tpg = G4_GROUP_M * gx, grp = t / tpg, row0 = grp * G4_GROUP_M, gsz = min(G4_GROUP_M, gy - row0);
+  const int bn0 = ((t % tpg) / gsz) * 256, bm0 = (row0 + (t % tpg) % gsz) * 256;
 
   // LDS-DMA pieces: 1 KB = 8 rows x 128 B; wave w issues pieces w*8 .. w*8+7 of the activation tile and of the weight tile.
   // Lane l of a piece lands in LDS row l >> 3, slot l & 7, and fetches global chunk (l & 7) ^ (row & 7) (the bank swizzle).

@@ -28,9 +28,17 @@ ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))
 MF = "v_mfma_f32_16x16x32_f16"
 STAGE = 65536
 W_OFF = 32768
-# placement knobs (MFMA slot after which the r-th side instruction goes)
-RD0_FIRST, RD0_STEP = 3, 3          # phase 0: the 16 F1 reads
-G_FIRST, G_STEP = 1, 3              # phase 1: m0 at G_FIRST + 3 g, glds one slot later, the F0 read one slot after that
+# placement knobs (MFMA slot after which the r-th side instruction goes): "first:step" per stream, overridable for A/B builds with
+# G4_PLACE="r0=0:2,g=0:3,r1=2:3,wait=counted"
+PLACE = {"r0": (3, 3),      # phase 0: the 16 reads of fragment set F1
+         "g": (1, 3),       # phase 1: m0 write at first + step * g, the LDS-DMA one slot later
+         "r1": (3, 3),      # phase 1: the 16 reads of the next tile's set F0
+         "wait": "phase"}   # "phase": lgkmcnt(0) at both phase ends; "counted": F0 reads stay in flight into phase 0 (counted waits)
+#        "y": (slot,)       # optional: vmcnt wait + a second barrier at this phase-1 slot instead of vmcnt(0) at the phase-0 barrier
+for kv in filter(None, os.environ.get("G4_PLACE", "").split(",")):
+    k, v = kv.split("=")
+    PLACE[k] = v if k == "wait" else tuple(int(x) for x in (v + ":1").split(":")[:2])
+COUNTED = PLACE["wait"] == "counted"
 
 
 def wreg(ks, j):
@@ -53,13 +61,11 @@ def mfma_list(ks):
 
 
 def frag_reads(ks, stage):
-    """16 ds_read_b128 of fragment set ks from LDS stage `stage`: W fragments first (the first MFMA row needs all of them)."""
-    out = []
-    for j in range(8):
-        out.append("ds_read_b128 %s, %%[rw%d%d] offset:%d" % (wreg(ks, j), stage, ks, j * 2048))
-    for i in range(8):
-        out.append("ds_read_b128 %s, %%[ra%d%d] offset:%d" % (areg(ks, i), stage, ks, i * 2048))
-    return out
+    """16 ds_read_b128 of fragment set ks from LDS stage `stage`, in the order the MFMA stream (i outer, j inner) first touches them:
+    W0, A0, W1 .. W7, A1 .. A7.  Returns (register name, instruction)."""
+    rw = lambda j: (("W", j), "ds_read_b128 %s, %%[rw%d%d] offset:%d" % (wreg(ks, j), stage, ks, j * 2048))
+    ra = lambda i: (("A", i), "ds_read_b128 %s, %%[ra%d%d] offset:%d" % (areg(ks, i), stage, ks, i * 2048))
+    return [rw(0), ra(0)] + [rw(j) for j in range(1, 8)] + [ra(i) for i in range(1, 8)]
 
 
 BUF = "bufglds" in ABLATE       # LDS-DMA through buffer descriptors s[44:47] / s[48:51] + the K offset in s52
@@ -90,32 +96,69 @@ def weave(mfmas, side):
     return out
 
 
+def place(side, first_step, items):
+    for r, ins in enumerate(items):
+        side.setdefault(first_step[0] + first_step[1] * r, []).append(ins)
+
+
+def phase0(stage, pending):
+    """MFMAs on F0 with the F1 reads threaded in.  pending: F0 reads still in flight at entry (counted mode), oldest first, as register
+    names; LDS operations return in order, so `s_waitcnt lgkmcnt(n)` before the first MFMA that touches a register, n = LDS operations
+    issued after that register's read."""
+    reads = [] if "noreads" in ABLATE else frag_reads(1, stage)
+    side = {}
+    place(side, PLACE["r0"], [ins for _, ins in reads])
+    mf = mfma_list(0)
+    if not pending:
+        return weave(mf, side)
+    out, queue, done = [], list(pending), set()     # queue: outstanding LDS ops in issue order (names; None for F1 reads)
+    for k, m in enumerate(mf):
+        i, j = divmod(k, 8)
+        need = [len(queue) - 1 - queue.index(r) for r in (("W", j), ("A", i)) if r in queue]
+        if need:
+            c = min(min(need), 15)                      # the counter saturates at 15
+            out.append("s_waitcnt lgkmcnt(%d)" % c)
+            del queue[:len(queue) - c]
+        out.append(m)
+        for ins in side.get(k, []):
+            out.append(ins)
+            queue.append(None)
+    return out
+
+
 def tile(stage, with_glds, with_next):
     L = []
     if "noglds" in ABLATE:
         with_glds = False
+    nxt = frag_reads(0, 1 - stage) if with_next and "noreads" not in ABLATE else []
+    cur = frag_reads(0, stage) if "noreads" not in ABLATE else []
     # ---- phase 0
-    side = {}
-    for r, ins in enumerate([] if "noreads" in ABLATE else frag_reads(1, stage)):
-        side.setdefault(RD0_FIRST + RD0_STEP * r, []).append(ins)
-    L += weave(mfma_list(0), side)
-    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ([] if "nobarrier" in ABLATE else ["s_barrier"])
+    L += phase0(stage, [name for name, _ in cur] if COUNTED else [])
+    bar = [] if "nobarrier" in ABLATE else ["s_barrier"]
+    LATE = "y" in PLACE                                  # second barrier: "the next tile has landed" moved into phase 1
+    L += ["s_waitcnt lgkmcnt(0)" if LATE else "s_waitcnt vmcnt(0) lgkmcnt(0)"] + bar
     # ---- phase 1
     side = {}
-    nxt = frag_reads(0, 1 - stage) if with_next and "noreads" not in ABLATE else []
+    g_slots = []
     if with_glds:
-        for g, (m0, ld) in enumerate(glds_pairs(stage)):
-            side.setdefault(G_FIRST + G_STEP * g, []).append(m0)
-            side.setdefault(G_FIRST + G_STEP * g + 1, []).append(ld)
-        for g in range(len(nxt)):
-            side.setdefault(G_FIRST + G_STEP * g + 2, []).append(nxt[g])
-        for q, ins in enumerate(ADVANCE):
-            side.setdefault(G_FIRST + G_STEP * 16 + 1 + q, []).append(ins)
-    else:
-        for r, ins in enumerate(nxt):
-            side.setdefault(RD0_FIRST + RD0_STEP * r, []).append(ins)
+        pairs = glds_pairs(stage)
+        g_slots = [PLACE["g"][0] + 1 + PLACE["g"][1] * g for g in range(16)]
+        assert g_slots[-1] + 4 <= 63, "LDS-DMA placement runs past the phase"
+        place(side, PLACE["g"], [m0 for m0, _ in pairs])
+        place(side, (PLACE["g"][0] + 1, PLACE["g"][1]), [ld for _, ld in pairs])
+        place(side, (g_slots[-1] + 1, 1), ADVANCE)
+    if LATE and with_next:
+        ys = PLACE["y"][0]
+        newer = sum(1 for q in g_slots if q < ys or (q == ys and False))   # pieces of tile t+2 issued before the wait
+        # the wait + barrier go FIRST in their slot, ahead of any LDS-DMA placed in the same slot
+        side.setdefault(ys, []).insert(0, "s_waitcnt vmcnt(%d)" % newer)
+        for bi in bar:
+            side[ys].insert(1, bi)
+        assert PLACE["r1"][0] > ys, "the F0 reads must follow the second barrier"
+    place(side, PLACE["r1"], [ins for _, ins in nxt])
+    assert not nxt or PLACE["r1"][0] + PLACE["r1"][1] * 15 <= 63, "read placement runs past the phase"
     L += weave(mfma_list(1), side)
-    if with_next:
+    if with_next and not COUNTED:
         L += ["s_waitcnt lgkmcnt(0)"]
     return L
 
@@ -134,8 +177,8 @@ def program():
     for n in range(256):
         L.append("v_accvgpr_write_b32 a%d, 0" % n)
     L += ["s_waitcnt vmcnt(16)", "s_barrier"]
-    L += frag_reads(0, 0)
-    L += ["s_waitcnt lgkmcnt(0)", "s_cmp_eq_u32 %[niter], 0", "s_cbranch_scc1 L_g4_tail_%="]
+    L += [ins for _, ins in frag_reads(0, 0)]
+    L += ([] if COUNTED else ["s_waitcnt lgkmcnt(0)"]) + ["s_cmp_eq_u32 %[niter], 0", "s_cbranch_scc1 L_g4_tail_%="]
     L += ["L_g4_loop_%=:"]
     L += tile(0, True, True)
     L += tile(1, True, True)
