@@ -66,6 +66,14 @@ __device__ __forceinline__ float ln_fold1(float acc, float mean, float rstd, flo
   return __builtin_fmaf(rstd, __builtin_fmaf(-mean, cs, acc), b);
 }
 
+// (sum, sum of squares) of one 4-column piece of a LayerNorm-producer row, operation by operation (same reason as ln_fold1: the
+// 128-column kernel and gemm4w must round alike); the 32 pieces of a 128-column tile are then summed as a butterfly over the
+// piece index with strides 16, 8, 4, 2, 1.
+__device__ __forceinline__ void ln_piece_stats(const floatx4 v, float& sm, float& sq) {
+  sm = __fadd_rn(__fadd_rn(v[0], v[1]), __fadd_rn(v[2], v[3]));
+  sq = __fadd_rn(__builtin_fmaf(v[0], v[0], __fmul_rn(v[1], v[1])), __builtin_fmaf(v[2], v[2], __fmul_rn(v[3], v[3])));
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -301,8 +309,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
         }
       }
       if (p.st_out) {                                  // 32 consecutive lanes hold one row's 128 columns
-        float sm = (v[0] + v[1]) + (v[2] + v[3]);
-        float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        float sm, sq;
+        ln_piece_stats(v, sm, sq);
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
           sm += __shfl_xor(sm, o, 64);
@@ -546,6 +554,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #ifndef G4_GROUP_M
 #define G4_GROUP_M 4
 #endif
+#ifndef G4_F32_MIN_TILES       // smallest 256 x 256 grid the fp32-epilogue form of gemm4w takes over from the 128-column kernel
+#define G4_F32_MIN_TILES 192
+#endif
 constexpr int G4_STAGE = 65536;
 constexpr int G4_SMEM = 2 * G4_STAGE + 2048;            // + the [256][2] LayerNorm table
 
@@ -606,7 +617,78 @@ __device__ __forceinline__ void gemm4w_store_row(half_t* crow, bool ok, const fl
   gemm4w_store_pair<LN, ACT, I, 3>(crow, ok, bz, cz, mean, rstd);
 }
 
-template <bool LN, int ACT>
+// fp32-output epilogue of one 16-row tile row (the residual projections: image_encoder.py:238 proj, common.py:26 lin2):
+// C = (acc + bias) [* colscale] [+ residual], its fp16 copy and the LayerNorm partials of the next block's folded norm
+// (csam_gemm_f16_ln producer), all straight from the registers: per lane 8 x 16-byte residual loads (issued one tile row
+// ahead), 8 x 16-byte fp32 stores, 4 x 16-byte fp16 stores (permlane16-widened), and the 128-column statistics as the same
+// butterfly the 128-column kernel runs over lanes -- strides 16, 8, 4 are register pairs here, 2 and 1 are lane ^ 32, lane ^ 16.
+template <int I>
+__device__ __forceinline__ void gemm4w_f32_row(const GemmArgs& p, int m, int n0, int fg, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
+                                               floatx4 (&rc)[8], floatx4 (&rn)[8]) {
+  const bool ok = m < p.M, okn = m + 16 < p.M;
+  if (I < 7 && p.R) {                                  // residual of the NEXT tile row (in-place C == R is fine: other rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rn[j] = okn ? *(const floatx4*)((const float*)p.R + (long)(m + 16) * p.ldr + n0 + j * 16) : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  floatx4 v[8] = {gemm4w_acc<I * 8 + 0>(), gemm4w_acc<I * 8 + 1>(), gemm4w_acc<I * 8 + 2>(), gemm4w_acc<I * 8 + 3>(),
+                  gemm4w_acc<I * 8 + 4>(), gemm4w_acc<I * 8 + 5>(), gemm4w_acc<I * 8 + 6>(), gemm4w_acc<I * 8 + 7>()};
+  float sm[8], sq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] += bz[j];
+    if (p.colscale) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = __fmul_rn(v[j][e], cz[j][e]);
+    }
+    if (p.R) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = __fadd_rn(v[j][e], rc[j][e]);
+    }
+    if (ok) *(floatx4*)((float*)p.C + (long)m * p.ldc + n0 + j * 16) = v[j];
+    ln_piece_stats(v[j], sm[j], sq[j]);
+  }
+  if (p.C16) {
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    half_t* crow = p.C16 + (long)m * p.ldc16 + (n0 - fg * 4) + (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      unsigned h[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const half2_t hh = {(half_t)v[2 * jp + t][2 * q], (half_t)v[2 * jp + t][2 * q + 1]};
+          h[t][q] = __builtin_bit_cast(unsigned, hh);
+        }
+      const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+      if (ok) *(uintx4*)(crow + jp * 32) = uintx4{s0[0], s1[0], s0[1], s1[1]};
+    }
+  }
+  if (p.st_out) {                                      // piece index of (tile j, lane group fg) = 4 j + fg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sm[j] = __fadd_rn(sm[j], sm[j + 4]);
+      sq[j] = __fadd_rn(sq[j], sq[j + 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sm[j] = __fadd_rn(sm[j], sm[j + 2]);
+      sq[j] = __fadd_rn(sq[j], sq[j + 2]);
+    }
+    float a = __fadd_rn(sm[0], sm[1]), b = __fadd_rn(sq[0], sq[1]);
+    a = __fadd_rn(a, __shfl_xor(a, 32, 64));
+    b = __fadd_rn(b, __shfl_xor(b, 32, 64));
+    a = __fadd_rn(a, __shfl_xor(a, 16, 64));
+    b = __fadd_rn(b, __shfl_xor(b, 16, 64));
+    if (fg == 0 && ok) *(float2_t*)(p.st_out + ((long)m * (p.N / BN) + (n0 >> 7)) * 2) = float2_t{a, b};
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rc[j] = rn[j];
+}
+
+template <bool LN, int ACT, bool F32>
 __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -655,7 +737,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
   for (int j = 0; j < 8; ++j) {
     const int n = bn0 + wn * 128 + j * 16 + fg * 4;
     bz[j] = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-    cz[j] = LN ? *(const floatx4*)(p.colsum + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+    cz[j] = LN ? *(const floatx4*)(p.colsum + n) : (F32 && p.colscale) ? *(const floatx4*)(p.colscale + n) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
   floatx4 pr[5];
 #pragma unroll
@@ -672,6 +754,24 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
 #ifdef G4_SKIP_EPILOGUE                                 // developer timing ablation (tools/debug/gemm4w_variants.sh)
   if (p.M > 0) return;
 #endif
+  if (F32) {
+    const int m0 = bm0 + wm * 128 + fr, n0 = bn0 + wn * 128 + fg * 4;
+    floatx4 rc[8], rn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      rc[j] = (p.R && m0 < p.M) ? *(const floatx4*)((const float*)p.R + (long)m0 * p.ldr + n0 + j * 16) : floatx4{0.f, 0.f, 0.f, 0.f};
+      rn[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    gemm4w_f32_row<0>(p, m0, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<1>(p, m0 + 16, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<2>(p, m0 + 32, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<3>(p, m0 + 48, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<4>(p, m0 + 64, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<5>(p, m0 + 80, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<6>(p, m0 + 96, n0, fg, bz, cz, rc, rn);
+    gemm4w_f32_row<7>(p, m0 + 112, n0, fg, bz, cz, rc, rn);
+    return;
+  }
   float2_t ms[8];                                      // (mean, rstd) of the lane's row in each of its 8 row tiles
 #pragma unroll
   for (int i = 0; i < 8; ++i) ms[i] = float2_t{0.f, 1.f};
@@ -752,6 +852,18 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
     hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_ALL);
   const long t256 = (long)(N / 256) * csam_cdiv(M, 256);
   const bool fills = t256 <= 256 || 100 * t256 >= 85 * 256 * csam_cdiv(t256, 256);
+  // The residual projections (fp32 stream out, fp32 residual in, optionally the fp16 copy + LayerNorm partials): the four-wave kernel
+  // with the fp32 epilogue when its grid is about one round of the chip or more
+  if (batch == 1 && c_dtype == CSAM_DT_F32 && (!residual || r_dtype == CSAM_DT_F32) && res_mod == 0 && act == CSAM_ACT_NONE && !st_in &&
+      N % 256 == 0 && K % 128 == 0 && K >= 256 && ldc % 4 == 0 && (!residual || ldr % 4 == 0) && t256 >= G4_F32_MIN_TILES) {
+    static csam_once_t set4f;
+    auto k4 = gemm4w_kernel<false, CSAM_ACT_NONE, true>;
+    if (csam_first_call(set4f)) hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
+    p.xcd = 1;
+    hipLaunchKernelGGL(k4, dim3((unsigned)t256), dim3(256), G4_SMEM, (hipStream_t)stream, p);
+    CSAM_LAUNCH_CHECK("csam_gemm_f16");
+    return CSAM_OK;
+  }
   if (batch == 1 && c_dtype == CSAM_DT_F16 && !residual && !colscale && N % 256 == 0 && N >= 2048 && fills && K >= 64 &&
       (!st_in || (st_np % 2 == 0 && st_np <= 10))) {
     dim3 g256((unsigned)t256);
@@ -759,7 +871,7 @@ static int gemm_launch(void* stream, const void* A, long lda, const void* W, lon
 #define CSAM_GEMM4W(LN_, ACT_)                                                                                   \
   {                                                                                                              \
     static csam_once_t set4w;                                                                                    \
-    auto k4 = gemm4w_kernel<LN_, ACT_>;                                                                          \
+    auto k4 = gemm4w_kernel<LN_, ACT_, false>;                                                                          \
     if (csam_first_call(set4w)) hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM); \
     hipLaunchKernelGGL(k4, g256, dim3(256), G4_SMEM, (hipStream_t)stream, p);                                    \
   }

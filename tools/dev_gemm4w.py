@@ -73,3 +73,40 @@ for M, N, K in shapes:
     print(f"M={M:6d} N={N:5d} K={K:5d}: own {t_own:7.1f} us {fl / t_own:7.1f} TF/s | vendor {t_lib:7.1f} us {fl / t_lib:7.1f} TF/s | "
           f"ratio {t_lib / t_own:.2f} | err {err:.2e} finite {bool(torch.isfinite(out).all())} flicker {flick} hash {h} | "
           f"LN+GELU {t_ln:7.1f} us err {err2:.2e} hash {h2}", flush=True)
+
+# ---- the residual projections: fp32 out + fp32 residual (+ LayerScale) + fp16 copy + LayerNorm partials (csam_gemm_f16_ln producer)
+if "--f32" in sys.argv or not AB:
+    for M, N, K, cs in [(16384, 1024, 1024, 0), (16384, 1024, 4096, 0), (21320, 1024, 1024, 1), (21320, 1024, 4096, 1), (12288, 1024, 1024, 0),
+                        (20000, 1024, 4096, 1), (4096, 1024, 1024, 0)]:
+        g = torch.Generator(device="cpu").manual_seed(M + N + K)
+        a = (torch.randn(M, K, generator=g) * 0.5).to(dev).half()
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dev).half()
+        bias = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev)
+        colscale = (torch.rand(N, generator=g) + 0.5).to(dev) if cs else None
+        out = torch.full((M, N), float("nan"), device=dev)
+        out16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        stats = torch.full((M, N // 128, 2), float("nan"), device=dev)
+        run = lambda: hip.gemm_f16_ln(a, w, out, bias=bias, residual=res, colscale=colscale, out16=out16, stats_out=stats)
+        run()
+        torch.cuda.synchronize()
+        hs = [hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()[:10] for t in (out, out16, stats)]
+        rows = torch.randint(0, M, (64,), generator=g).to(dev)
+        ref = a[rows].float() @ w.float().t() + bias
+        if cs:
+            ref = ref * colscale
+        ref = ref + res[rows]
+        err = (out[rows] - ref).abs().max().item()
+        o4 = out.view(M, N // 128, 128)
+        serr = max((stats[..., 0] - o4.sum(-1)).abs().max().item(), ((stats[..., 1] - (o4 * o4).sum(-1)).abs() / (o4 * o4).sum(-1)).max().item())
+        ok16 = torch.equal(out16, out.half())
+        # in place (C == residual), as the encoders call it
+        res2 = res.clone()
+        hip.gemm_f16_ln(a, w, res2, bias=bias, residual=res2, colscale=colscale, out16=out16, stats_out=stats)
+        inpl = torch.equal(res2, out)
+        t_own = tm(run)
+        o16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+        t_lib = t_own if AB else tm(lambda: torch.mm(a, w.t(), out=o16))
+        fl = 2.0 * M * N * K / 1e6
+        print(f"f32 M={M:6d} N={N:5d} K={K:5d} cs={cs}: own {t_own:7.1f} us {fl / t_own:7.1f} TF/s | vendor (fp16, no epilogue) {t_lib:7.1f} us | ratio {t_lib / t_own:.2f} | "
+              f"err {err:.2e} stats err {serr:.2e} fp16 copy ok {ok16} in-place ok {inpl} finite {bool(torch.isfinite(out).all() and torch.isfinite(stats).all())} hash {' '.join(hs)}", flush=True)
