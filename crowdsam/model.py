@@ -154,6 +154,7 @@ class CrowdSAM:
         self.encoder_batch = int(t.get("encoder_batch", 4))
         self.timings = {}
         self.last_candidates = 0
+        self.last_prompts = 0
         self._next_image = None      # depth-2 pipeline (generate(next_image=...)): see _prefetch
         self._prefetched = None
         self.group_ramp = True       # generate_stream starts with groups of 1, 2, 4, .. frames up to encoder_batch
@@ -588,6 +589,8 @@ class CrowdSAM:
                     with trace.range("decoder_batch"):
                         bd = self._process_batch(None, self.predictor.original_size, crop_box, store,
                                                  device_batch=(pts_b, coords_b, counts[:1]))
+                    if self.eps_trace is not None:          # ... and (fused score, survivor flag, feeder flag) of its prompts
+                        self.eps_trace_status.append((bd["score"].clone(), bd["keep"].clone(), bd["occ"].clone()))
                     if prune:
                         hip.occupancy_prune(all_pts_dev, store["masks"], bd["occ"], B, H, W, alive_dev, slot=bd["slot"])
                     count += B
@@ -609,6 +612,8 @@ class CrowdSAM:
                         self.eps_trace.append((points[sel_idx].copy(), len(sel_idx)))
                     with trace.range("decoder_batch"):
                         bd = self._process_batch(points[sel_idx], self.predictor.original_size, crop_box, store)
+                    if self.eps_trace is not None:
+                        self.eps_trace_status.append((bd["score"].clone(), bd["keep"].clone(), bd["occ"].clone()))
                     tb = self._tick("eps.batch", tb)
                     if prune and len(alive) > 0:
                         if all_pts_dev is None:
@@ -634,6 +639,7 @@ class CrowdSAM:
             # this frame's tail
             self._run_ahead(look, early=False)
         t0 = self._tick("eps_sweep", t0)
+        self.last_prompts = count                    # prompt slots decoded for this crop (rounds x batch width; bench.py reports it)
         if n_batches == 0:
             return None
         n = int(store["counter"].item())             # the one sync of a dense sweep

@@ -132,6 +132,7 @@ def test_shipped_chain_free_running_vs_reference_golden(cuda):
     fb, fp, fm = g["fragile_batch"], g["fragile_point"], g["fragile_margin"]
     nb = len(g["batch_points"])
     assert len(trace) == nb, (len(trace), nb)
+    assert len(status) == len(trace), (len(status), len(trace))       # one status record per traced round
     first = None
     for bi in range(nb):
         pts, nv = trace[bi]

@@ -16,14 +16,44 @@ constexpr int ITER = 512;
 
 #define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
+// Round 6: the GELU off the VALU pipe -- Phi(x) from a piecewise-linear table in LDS, 1024 intervals of
+// (value, slope) fp16 pairs on [-4.4, 4.4]: index + fraction = 1 FMA (clamp modifier) + 1 mul + 1 fract + 1 cvt + 1 shift, one
+// ds_read_b32, 1 mixed-precision FMA + 1 mul.  OP 9: every lane its own argument (N(0,1)-like spread: the bank conflicts a
+// real activation tile would see); OP 18: all lanes the same argument (LDS broadcast: the VALU side alone).
+constexpr int TBL_N = 1024;
+__device__ __forceinline__ float gelu_tbl(float x, const unsigned* tbl) {
+  float t;
+  asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(t) : "v"(x), "v"(1.0f / 8.8f));       // (x + 4.4) / 8.8 clamped to [0, 1]
+  const float u = t * (float)TBL_N;
+  const unsigned i = (unsigned)u;                                                       // v_cvt_u32_f32 (truncation = floor here)
+  const float f = __builtin_amdgcn_fractf(u);
+  const unsigned e = tbl[i];
+  float ph;
+  asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(ph) : "v"(f), "v"(e));   // f * slope(hi) + value(lo)
+  return x * ph;
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, float seed) {
   float a[16];
   f2 p[16];
+  __shared__ unsigned tbl[TBL_N + 1];
+  if (OP == 9 || OP == 18) {
+    for (int i = threadIdx.x; i <= TBL_N; i += 256) {
+      const float x0 = -4.4f + 8.8f * i / TBL_N, x1 = x0 + 8.8f / TBL_N;
+      const float v0 = 0.5f * (1.f + erff(x0 * 0.70710678f)), v1 = 0.5f * (1.f + erff(x1 * 0.70710678f));
+      const _Float16 hv = (_Float16)v0, hs = (_Float16)(v1 - v0);
+      tbl[i] = (unsigned)__builtin_bit_cast(unsigned short, hv) | ((unsigned)__builtin_bit_cast(unsigned short, hs) << 16);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     a[i] = seed + i + threadIdx.x;
     p[i] = f2{seed + i, seed - i};
+    if (OP == 9) {                                  // per-lane arguments, spread like unit-variance activations
+      const unsigned h = (threadIdx.x * 2654435761u + i * 40503u) >> 8;
+      p[i] = f2{((h & 0xfff) / 4096.f - 0.5f) * 5.f, (((h >> 12) & 0xfff) / 4096.f - 0.5f) * 5.f};
+    }
   }
   float k1 = 1.0001f + seed, k2 = 0.25f + seed;
   f2 q1 = {k1, k1}, q2 = {k2, k2};
@@ -94,6 +124,12 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, floa
 #define M(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 15]), "s"(k2));
       REP16(M)
 #undef M
+    } else if (OP == 9 || OP == 18) {   // LDS-table GELU, 16 pairs per iteration; the feedback keeps the arguments spread
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const f2 z = {gelu_tbl(p[g][0], tbl), gelu_tbl(p[g][1], tbl)};
+        p[g] = z * q2 + p[(g + 1) & 15] * q1;
+      }
     } else if (OP == 8) {   // the upscaler's GELU, 4 pairs per call (13 instructions per pair), 4 calls per iteration
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -160,6 +196,8 @@ int main() {
   run<16>("v_rcp_f32", 16, "instruction");
   run<14>("8 v_exp_f32 + 8 v_fma_f32 interleaved", 16, "instruction");
   run<15>("8 v_exp_f32 + 8 v_pk_fma_f32 interleaved", 16, "instruction");
-  run<8>("csam_gelu_poly2_n<4> (r5: output clamp; + 1 pk_add)", 16, "PAIR of evaluations");
+  run<8>("csam_gelu_poly2_n<4> (packed; + 1 pk_add)", 16, "PAIR of evaluations");
+  run<9>("LDS-table GELU, per-lane arguments (+ 1 pk_fma + 1 pk_mul)", 16, "PAIR of evaluations");
+  run<18>("LDS-table GELU, one argument for all lanes", 16, "PAIR of evaluations");
   return 0;
 }
