@@ -253,6 +253,9 @@ def main():
                          "--encoder-only: images per encoder pass (default 1)")
     ap.add_argument("--no-ramp", action="store_true",
                     help="developer A/B: the stream starts with a full group of --batch frames instead of groups of 1, 2, 4, ..")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the encoder-only and shipped-EPS legs of the default line (profiling runs: their kernels would mix "
+                         "into the trace of the timed loop)")
     ap.add_argument("--no-cpu-e2e", action="store_true",
                     help="skip the measured end-to-end oracle image (64 prompts, ~1.5 min of host time) of the cpu_baseline leg")
     args = ap.parse_args()
@@ -532,7 +535,7 @@ def main():
     # normalised tensors, one image per pass and four images per pass, 10 passes each, HIP events; fraction of the dense fp16 MFMA
     # peak on the reference module's FLOP count, as `python bench.py --encoder-only [--batch 4]` reports it
     roofline_encoder = None
-    if rank == 0 and args.mode == "dense" and not args.serial:
+    if rank == 0 and args.mode == "dense" and not args.serial and not args.no_extra_legs:
         REF_GFLOP = {"vit_b": 972.1, "vit_l": 2985.7, "vit_h": 5961.1}
         sam = model.predictor.model
         enc = sam.image_encoder
@@ -561,7 +564,7 @@ def main():
     # on the same synthetic frames, one frame of look-ahead -- a data-dependent prompt count, reported.  stability_score_thresh
     # stays at this run's value (random-weight masks never reach the shipped 0.8; see --stability-thresh).
     eps_leg = None
-    if rank == 0 and args.mode == "dense" and not args.serial and args.frame == 1024:
+    if rank == 0 and args.mode == "dense" and not args.serial and args.frame == 1024 and not args.no_extra_legs:
         ecfg = dict(DEFAULT_TEST_CFG)
         ecfg.update(stability_score_thresh=args.stability_thresh)
         emodel = CrowdSAM({"environ": {"device": f"cuda:{local_rank}"},

@@ -114,6 +114,15 @@ class CrowdSAM:
         self.predictor = self.load_sam_model(m["sam_model"], m.get("sam_arch", "crowdsam"), m.get("sam_checkpoint"),
                                              m.get("sam_adapter_checkpoint"), dino_model, m["n_class"],
                                              sam_state_dict)
+        # model.ln_fold (build extension, default true): the encoders' LayerNorms are folded into the projections around them
+        # (csam_gemm_f16_ln: the projection multiplies the fp16 copy of the UNNORMALISED residual stream and applies mean /
+        # rstd in its epilogue).  false = separate LayerNorm launches whose fp16 output feeds a plain GEMM: ~4 % slower
+        # encoders, and the operand rounding is relative to |x - mean| instead of |x| -- the conservative choice for a
+        # checkpoint whose residual rows sit far from zero (tests/test_encoder_gpu.py::test_ln_fold_on_vit_l_outlier_profile)
+        ln_fold = bool(m.get("ln_fold", True))
+        self.predictor.model.image_encoder.ln_fold = ln_fold
+        if hasattr(dino_model, "plan"):
+            dino_model.ln_fold = ln_fold
         t = config["test"]
         self.mask_selection = t["mask_selection"]
         self.apply_box_offsets = t["apply_box_offsets"]

@@ -9,7 +9,12 @@ CSRC = os.path.join(HERE, "csrc")
 # CSAM_DEFS_<source stem> = extra hipcc flags for one source, e.g. CSAM_DEFS_decoder_fused="-DFOO -fno-slp-vectorize"
 TAG = os.environ.get("CSAM_BUILD_TAG", "")
 LIB = os.path.join(HERE, "libcsam_hip%s.so" % ("_" + TAG if TAG else ""))
-ARCH = "gfx950"
+ARCH = os.environ.get("CSAM_ARCH", "gfx950")     # developer: "gfx950:xnack+" for the sanitizer build (tools/asan_smoke.sh)
+# CSAM_EXTRA_FLAGS: extra hipcc flags for EVERY source and the link (e.g. "-fsanitize=address -shared-libsan -g")
+GLOBAL_FLAGS = os.environ.get("CSAM_EXTRA_FLAGS", "").split()
+# ... except the sources named here (comma list of stems): the hand-scheduled inline-asm kernels do not survive instrumentation
+# ("s" operands stop being provably uniform, 512-register kernels have no room for shadow checks)
+GLOBAL_SKIP = set(filter(None, os.environ.get("CSAM_EXTRA_FLAGS_SKIP", "").split(",")))
 
 
 # -amdgpu-mfma-vgpr-form (MFMA accumulators in the unified VGPR file instead of AGPRs: no v_accvgpr_read/write around a
@@ -55,7 +60,8 @@ def build(force=False, verbose=True):
                         for h in os.listdir(CSRC) if h.endswith((".h", ".inc")))):
             continue
         cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-               "-Wno-unused-result", "-Wno-unused-value"] + EXTRA_FLAGS.get(os.path.basename(src), []) + \
+               "-Wno-unused-result", "-Wno-unused-value"] + \
+              ([] if os.path.basename(src).split(".")[0] in GLOBAL_SKIP else GLOBAL_FLAGS) + EXTRA_FLAGS.get(os.path.basename(src), []) + \
               os.environ.get("CSAM_DEFS_" + os.path.basename(src).split(".")[0], "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -67,7 +73,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}")
         elif verbose and out.strip():
             print(out.decode())
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + GLOBAL_FLAGS + ["-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -221,11 +221,12 @@ class DinoV2(torch.nn.Module):
         return super()._apply(fn, *a, **k)
 
     def plan(self):
-        if self._plan is None:
+        if self._plan is None or self._plan.ln_fold != bool(getattr(self, "ln_fold", True)):
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("crowdsam_amd runs on MI355X only: move DinoV2 to 'cuda' first")
-            self._plan = DinoPlan(self.state_dict(), dev, self.depth, self.num_heads, self.pos_offset)
+            self._plan = DinoPlan(self.state_dict(), dev, self.depth, self.num_heads, self.pos_offset,
+                                  ln_fold=getattr(self, "ln_fold", True))
         return self._plan
 
     @torch.no_grad()

@@ -77,12 +77,13 @@ class ImageEncoderViT(_Planned):
         self.img_size = img_size
         self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
         self.global_attn_indexes = tuple(global_attn_indexes)
+        self.ln_fold = True      # config model.ln_fold (crowdsam/model.py): LayerNorms folded into the projections around them
 
     def plan(self):
-        if self._plan is None:
+        if self._plan is None or self._plan.ln_fold != bool(self.ln_fold):
             self._require_gpu()
             self._plan = EncoderPlan(self.state_dict(), "", self.embed_dim, self.depth, self.num_heads,
-                                     self.global_attn_indexes, self.device)
+                                     self.global_attn_indexes, self.device, ln_fold=self.ln_fold)
         return self._plan
 
     def forward_tokens(self, raw_chw_f32):

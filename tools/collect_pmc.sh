@@ -11,7 +11,7 @@ cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   timeout 900 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer "$@" > /tmp/pmc_$C.log 2>&1
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-legs "$@" > /tmp/pmc_$C.log 2>&1
   DB=$(find /tmp/pmc_$C -name "*.db" | head -1)
   python $R/tools/pmc_summary.py $DB $C > $R/gpurun_out/pmc_$(echo $C | cut -d_ -f1 | tr A-Z a-z).json
 done

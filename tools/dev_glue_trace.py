@@ -37,8 +37,10 @@ for ev in prof.events():
         continue                     # count the outermost aten op only
     where = "?"
     for fr in ev.stack or []:
-        if ROOT in fr and "tools/dev_glue" not in fr:
-            where = fr.replace(ROOT + "/", "")
+        if any(k in fr for k in ("crowdsam/", "crowdsam_amd/", "segment_anything_cs/")) and "tools/dev_glue" not in fr:
+            where = fr[max(fr.find("crowdsam"), fr.find("segment_anything_cs")) if "crowdsam" in fr or "segment_anything_cs" in fr else 0:]
+            i = min([x for x in (fr.find("crowdsam/"), fr.find("crowdsam_amd/"), fr.find("segment_anything_cs/")) if x >= 0])
+            where = fr[i:]
             break
     nk = len(ev.kernels)
     if nk == 0:

@@ -7,7 +7,7 @@ export PYTHONPATH=$R TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 cd /tmp
 rm -rf /tmp/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o p -- python $R/bench.py --no-cpu-baseline --no-kernel-timer "$@" > $R/gpurun_out/${TAG}_bench.out 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o p -- python $R/bench.py --no-cpu-baseline --no-kernel-timer --no-extra-legs "$@" > $R/gpurun_out/${TAG}_bench.out 2>&1
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $R/gpurun_out/${TAG}_kernel_stats.txt > /dev/null
 grep '"metric"' $R/gpurun_out/${TAG}_bench.out > $R/gpurun_out/${TAG}_bench_line.json
