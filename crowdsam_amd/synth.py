@@ -214,3 +214,113 @@ def synthetic_crowd_frame(index, size=1024, n_ellipses=150):
         sub = ((xx[y0:y1, x0:x1] - cx) / ax) ** 2 + ((yy[y0:y1, x0:x1] - cy) / ay) ** 2 <= 1.0
         img[y0:y1, x0:x1][sub] = col
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def blob_heads(sd, sel_gain=0.5, key_gain=1.5, point_const=8.0, level=(3.4, 3.0, 2.6, 2.2), steep=25.0, pe_scale=2.0, noise=0.1, iou_shift=-0.6):
+    """Synthetic decoder weights whose masks are BLOBS AROUND THE PROMPT POINT instead of the noise-like fields random
+    weights give -- same architecture, same kernels, same FLOPs; only the values move, IN PLACE:
+
+      * layer 0's image->token attention (transformer.py:186-190) scores every key against the point token on 64 of the
+        128 random-Fourier frequencies of the positional encoding (prompt_encoder.py:189-196): q / k projections select the
+        matching sin / cos channels, so the logit is sum cos(2 pi g . (x - p)) over the 64 highest frequencies -- a kernel peaked at the prompt -- and the
+        other tokens score 0 (their embeddings and the queries' LayerNorm are zero on those channels);
+      * its value projection reads ONE channel that only the point token carries (point_embeddings.1), its output
+        projection writes the attention mass into ONE key channel that the neck leaves empty: keys[x, 254] grows
+        with the kernel;
+      * the upscaler's first transposed convolution copies that key channel into channel 0, the second one thresholds it
+        (bias -1) beside a constant channel 1, and the hyper-networks' last layers put a positive weight on channel 0 and a
+        negative one on channel 1: mask m = a (blob) - b_m, four nested blobs per prompt;
+      * the token-side paths (token->image attention, MLP, layer-1 attentions) keep their random weights at a tenth of
+        their scale: they still perturb, they no longer drown the construction.
+    Prompts 16 px apart give heavily overlapping blobs, so the shipped box NMS (0.65) thins them the way it thins
+    detections of a crowd, and stability scores sit in 0.85-0.99: the shipped thresholds are live decision boundaries.
+    Returns sd."""
+    M, T, P = "mask_decoder.", "mask_decoder.transformer.", "prompt_encoder."
+    # The positional encoding's frequencies are doubled (a buffer of the model like any other: the kernel's main lobe becomes
+    # person-sized, ~45 px at 1024) and the kernel uses a middle band of 64 of the 128: the lowest ones would put a pedestal as
+    # wide as the image under it, the very highest add only ripple
+    gm = sd[P + "pe_layer.positional_encoding_gaussian_matrix"]
+    gm *= pe_scale
+    freq = torch.argsort((gm * gm).sum(0), descending=True)[20:84].tolist()
+    S = freq + [128 + f for f in freq]                      # their sin / cos channels
+    spare = [f for f in range(128) if f not in freq]
+    E, Dk = 128 + spare[0], 128 + spare[1]                  # point-marker channel, blob key channel (outside the kernel's band)
+    z = lambda name: sd[name].zero_()
+    # neck: the image embedding leaves the kernel channels nearly empty and the blob channel empty
+    sd["image_encoder.neck.3.weight"][S] = 0.05
+    sd["image_encoder.neck.3.bias"][S] = 0.0
+    sd["image_encoder.neck.3.weight"][Dk] = 0.0
+    sd["image_encoder.neck.3.bias"][Dk] = 0.0
+    for name in (P + "no_mask_embed.weight", P + "not_a_point_embed.weight", M + "iou_token.weight", M + "mask_tokens.weight",
+                 P + "point_embeddings.1.weight"):
+        sd[name][:, S] = 0.0
+        sd[name][:, E] = 0.0
+        sd[name][:, Dk] = 0.0
+    sd[P + "point_embeddings.1.weight"][0, E] = point_const
+    eye = torch.eye(256)
+    for i in range(2):
+        L = f"{T}layers.{i}."
+        if i == 0:      # layer 0's self-attention REPLACES the tokens: make it (nearly) the identity
+            for pr, g in (("q_proj", 5.0), ("k_proj", 5.0), ("v_proj", 1.0), ("out_proj", 1.0)):
+                sd[L + f"self_attn.{pr}.weight"].copy_(eye * g)
+                z(L + f"self_attn.{pr}.bias")
+        else:
+            sd[L + "self_attn.out_proj.weight"] *= 0.1
+            sd[L + "self_attn.out_proj.bias"] *= 0.1
+        for nm in ("cross_attn_token_to_image.out_proj", "mlp.lin2"):
+            sd[L + nm + ".weight"] *= 0.1
+            sd[L + nm + ".bias"] *= 0.1
+        for nm in ("cross_attn_token_to_image.out_proj", "mlp.lin2") + (("self_attn.out_proj",) if i else ()):
+            sd[L + nm + ".weight"][E] = 0.0                 # nothing but the identity path writes the marker channel
+            sd[L + nm + ".bias"][E] = 0.0
+        for n in ("norm1", "norm2", "norm3", "norm4"):
+            sd[L + n + ".weight"].fill_(1.0)
+            z(L + n + ".bias")
+        sd[L + "norm3.weight"][S] = 0.0                     # the queries carry nothing on the kernel channels: only query_pe does
+        A = L + "cross_attn_image_to_token."
+        if i == 0:
+            for pr in ("q_proj", "k_proj"):
+                w = torch.zeros(128, 256)
+                for h in range(8):                          # head h: eight of the frequencies (every 8th by rank), sin then cos
+                    for t in range(8):
+                        f = freq[t * 8 + h]
+                        w[h * 16 + t, f] = sel_gain * 4.0 ** 0.5
+                        w[h * 16 + 8 + t, 128 + f] = sel_gain * 4.0 ** 0.5
+                sd[A + pr + ".weight"].copy_(w)
+                z(A + pr + ".bias")
+            w = torch.zeros(128, 256)
+            w[:, E] = 1.0 / point_const                     # every value lane = (marker channel) / its nominal size
+            sd[A + "v_proj.weight"].copy_(w)
+            z(A + "v_proj.bias")
+            w = torch.zeros(256, 128)
+            w[Dk, :] = key_gain / 128.0 * 8.0               # sum over heads of the point token's attention mass (0 .. 8)
+            sd[A + "out_proj.weight"].copy_(w)
+            z(A + "out_proj.bias")
+            sd[A + "out_proj.bias"][Dk] = -key_gain * 8.0 / 7.0 * 1.0   # the mass of a uniform softmax over 7 tokens
+        else:
+            sd[A + "out_proj.weight"] *= 0.1
+            sd[A + "out_proj.bias"] *= 0.1
+    sd[T + "final_attn_token_to_image.out_proj.weight"] *= 0.1
+    sd[T + "final_attn_token_to_image.out_proj.bias"] *= 0.1
+    U = M + "output_upscaling."
+    sd[U + "0.weight"][:, 0] = 0.0                          # ConvTranspose2d weight [in 256, out 64, 2, 2]
+    sd[U + "0.weight"][Dk, 0] = 1.0
+    sd[U + "0.bias"][0] = 0.0
+    sd[U + "1.weight"][0] = 1.0
+    sd[U + "1.bias"][0] = 0.0
+    sd[U + "3.weight"][:, 0] = 0.0                          # [in 64, out 32, 2, 2]
+    sd[U + "3.weight"][0, 0] = 1.0
+    sd[U + "3.bias"][0] = -1.0
+    sd[U + "3.weight"][:, 1] = 0.0
+    sd[U + "3.bias"][1] = 2.0
+    for m in range(4):
+        H = f"{M}output_hypernetworks_mlps.{m}.layers.2."
+        sd[H + "weight"] *= noise
+        sd[H + "bias"] *= noise
+        sd[H + "weight"][0:2] = 0.0
+        sd[H + "bias"][0] = steep
+        sd[H + "bias"][1] = -steep * level[m] / 1.954       # GELU(2) = 1.954: mask m = steep * (blob - level[m]) + noise
+    # the predicted-IoU head's output bias: about a quarter of the prompts then clear the shipped pred_iou_thresh (0.1) -- a dense grid
+    # over a crowd has most of its points on background or on an already-covered person
+    sd[M + "iou_prediction_head.layers.2.bias"] += iou_shift
+    return sd
