@@ -38,7 +38,7 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate passes: tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json).  PMC collection
     needs rocprofv3 around the process, so it cannot be live inside this run; None when the file is absent."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", "r0%d_pmc_traffic.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", "r0%d_pmc_traffic.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     try:
         d = json.load(open(path))
@@ -731,7 +731,7 @@ def main():
                             % (per_prompt / 1e6, 4 if fused_passes else 6)}
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_note = pmc_traffic("gemm_f16_kernel")
-            res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm_f16_kernel + gemm256_kernel (csam_gemm_f16*)",
+            res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm4w_kernel + gemm_f16_kernel (+ gemm256_kernel where K is not a multiple of 128) (csam_gemm_f16*)",
                                     "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                                     "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                                     "launches": calls, "avg_launch_us": 1e3 * ms / max(calls, 1),
