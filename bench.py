@@ -757,7 +757,7 @@ def main():
                              "12.9 G erf-GELU evaluations per launch as packed-fp32 polynomials (870 VALU + 112 MFMA instructions per "
                              "32-token tile and wave).  Round 4 measured the same throughput at 1, 2 and 3 resident waves per SIMD "
                              "(wave-specialised kernel, third-wave probe: profiles/r04_upscale_wave_specialised.txt, "
-                             "r04_upscale_rank_probe.txt, r04_valu_rate.txt; DESIGN.md section 4.2e): occupancy and scheduling are not "
+                             "r04_upscale_rank_probe.txt, r04_valu_rate.txt; HISTORY.md section 4.2e): occupancy and scheduling are not "
                              "levers, only less work per pixel is; round 5 measured that too -- packed fp16 issues at the packed-fp32 rate, an output-side clamp (-7 % "
                              "VALU instructions) bought -0.7 %, a degree-6 fit -5 % at 4x the error: rejected, "
                              "profiles/r05_upscale_fp16_gelu.txt.  Ablations: no GELU -40 %, no first-conv MFMAs -18 %, no hyper MFMAs "

@@ -485,62 +485,6 @@ __global__ __launch_bounds__(256) void pool_adjoint_kernel(const float* __restri
   }
 }
 
-// One-pass version for the fused path (the plane max comes from csam_upscale_fused's atomics in stats[r][0]):
-// e = exp(x - max) is evaluated ONCE per pixel, rows go through a per-wave LDS row buffer for the horizontal
-// taps, the [256][73] intermediate lives in LDS for the vertical taps; also writes sum(e) to stats[r][1].
-__global__ __launch_bounds__(256) void pool_adjoint_v2_kernel(const float* __restrict__ masks,
-                                                              float* __restrict__ stats,
-                                                              const AdjTaps* __restrict__ taps,
-                                                              half_t* __restrict__ wout, long ldw) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tmp = (float*)smem;                         // [256][73]
-  float* rowbuf = (float*)(smem + 256 * 73 * 4);     // [4 waves][256]
-  __shared__ AdjTaps tp;
-  __shared__ float red[4];
-  const long r = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < (int)(sizeof(AdjTaps) / 4); i += 256) ((int*)&tp)[i] = ((const int*)taps)[i];
-  const float mx = stats[r * 2];
-  const float* src = masks + (r << 16);
-  float* rb = rowbuf + wave * 256;
-  float esum = 0.f;
-  __syncthreads();
-  for (int it = 0; it < 64; ++it) {
-    const int Y = it * 4 + wave;
-    const floatx4 x = *(const floatx4*)(src + Y * 256 + lane * 4);
-    floatx4 e;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      e[k] = __expf(x[k] - mx);
-      esum += e[k];
-    }
-    *(floatx4*)(rb + lane * 4) = e;
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int tj = lane + h * 64;
-      if (tj < 73) {
-        const int x0 = tp.x0[tj], n = tp.n[tj];
-        float a = 0.f;
-        for (int k = 0; k < n; ++k) a += tp.w[tj][k] * rb[x0 + k];
-        tmp[Y * 73 + tj] = a;
-      }
-    }
-    __syncthreads();
-  }
-  esum = csam_wave_sum(esum);
-  if (lane == 0) red[wave] = esum;
-  __syncthreads();
-  if (tid == 0) stats[r * 2 + 1] = (red[0] + red[1]) + (red[2] + red[3]);
-  for (int it = tid; it < 73 * 73; it += 256) {
-    const int ti = it / 73, tj = it % 73;
-    const int y0 = tp.x0[ti], n = tp.n[ti];
-    float a = 0.f;
-    for (int k = 0; k < n; ++k) a += tp.w[ti][k] * tmp[(y0 + k) * 73 + tj];
-    wout[r * ldw + it] = (half_t)a;
-  }
-}
-
 // MFMA version of the same re-association: out = U^T E U with E = exp(x - max) in fp16 and U the dense form of
 // the (banded) 256 -> 73 adjoint taps.  ONE WAVE PER PLANE, no LDS traffic for the data and no barriers:
 //   T[Y,tj]   = sum_X E[Y,X] U[X,tj]    A = E rows straight from global (exp on the fly), B = packed U blocks
@@ -795,20 +739,6 @@ extern "C" int csam_pool_adjoint(void* stream, const float* masks, const float* 
   hipLaunchKernelGGL(pool_adjoint_kernel, dim3(rows), dim3(256), smem, (hipStream_t)stream, masks, stats,
                      (const AdjTaps*)taps_dev, (half_t*)w_f16, ldw);
   CSAM_LAUNCH_CHECK("csam_pool_adjoint");
-  return CSAM_OK;
-}
-
-// fused-path variant: stats[r][0] (max) must already be filled (csam_upscale_fused); writes stats[r][1]
-extern "C" int csam_pool_adjoint_v2(void* stream, const float* masks, float* stats, const void* taps_dev, void* w_f16,
-                                    long ldw, int rows) {
-  CSAM_REQUIRE(masks && stats && taps_dev && w_f16 && rows > 0 && ldw >= 5329, "csam_pool_adjoint_v2: bad args");
-  const int smem = 256 * 73 * 4 + 4 * 256 * 4;
-  static csam_once_t attr_set;
-  if (csam_first_call(attr_set))
-    hipFuncSetAttribute((const void*)pool_adjoint_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(pool_adjoint_v2_kernel, dim3(rows), dim3(256), smem, (hipStream_t)stream, masks, stats,
-                     (const AdjTaps*)taps_dev, (half_t*)w_f16, ldw);
-  CSAM_LAUNCH_CHECK("csam_pool_adjoint_v2");
   return CSAM_OK;
 }
 

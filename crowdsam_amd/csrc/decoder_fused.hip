@@ -1342,7 +1342,7 @@ constexpr int US_WMX = US_PAR + 2048;              // [4 waves][2]
 constexpr int US_SMEM = US_WMX + 64;
 
 // developer probe (CSAM_DEFS_decoder_fused=-DCSAM_UP_RANKPROBE): the instruction mix and register footprint of a first conv
-// with K = 128 (the rank-112 form of DESIGN.md §8(7): 64 registers of per-prompt operand instead of 128 of W1) plus the per-image
+// with K = 128 (the rank-112 form of HISTORY.md §8(7): 64 registers of per-prompt operand instead of 128 of W1) plus the per-image
 // table added to the accumulators, at THREE workgroups per CU.  Numerically meaningless (it multiplies half the key channels
 // and adds the other half): it answers "does a third wave per SIMD pay" before the producer chain is rebuilt for it.
 #define US_WG_PER_CU 2
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
 
 // -----------------------------------------------------------------------------------------------------
 // (Round 4 built this kernel with SPECIALISED waves -- 4 matrix waves + 4 GELU waves per CU, lane-private LDS mailbox -- and
-// measured it slower, 4.55 vs 3.87 ms per 2048 prompts: profiles/r04_upscale_wave_specialised.txt, DESIGN.md 4.2e.  The code is gone.)
+// measured it slower, 4.55 vs 3.87 ms per 2048 prompts: profiles/r04_upscale_wave_specialised.txt, HISTORY.md 4.2e.  The code is gone.)
 }  // namespace
 
 __global__ void stats_init_kernel(float* stats, int rows) {
@@ -2187,7 +2187,7 @@ extern "C" int csam_t2i_stream(void* stream, const void* X_f16, const void* Wkv_
 // =====================================================================================================
 // csam_t2i_rank (round 2): the token->image attention of layers 1 / final in RANK-56 form.  csam_t2i_stream projects
 // every key: K^T = Wk X^T and V = X Wv^T are 64 of its 72 MFMAs per 32-key tile, and that kernel is issue-bound (VALU +
-// MFMA cycles add up on a SIMD).  With only 7 queries per prompt the projections fold into the
+// MFMA cycles add up on a SIMD, HISTORY.md section 4.1).  With only 7 queries per prompt the projections fold into the
 // token side:
 //     scores[(h,j), t] = q_hj . (Wk_h (x_t + pe_t) + bk_h) = (Wk_h^T q_hj) . x_t  +  q_hj . (Wk_h pe_t)  (+ const per row)
 //     out[(h,j), :]    = sum_t p_t (Wv_h x_t + bv_h)       = Wv_h (sum_t p_t x_t) + bv_h

@@ -95,7 +95,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   <2,4,2,2,3>   64-row tile, 4 waves, 3 x 24 KB: two workgroups per CU; for grids that would leave CUs idle
 //   <3,4,2,2,2>   96-row tile, 4 waves, 2 x 28 KB: two workgroups per CU; fills one round of 512 where 128 rows do not
 // (Round 4 measured producer waves, deeper rings, 192-row tiles, counted waits, interleaved LDS-DMA issue and non-temporal
-// stores on these shapes: all within +-3 % or slower, DESIGN.md 4.2f / profiles/r04_gemm_*.txt; the code is gone.)
+// stores on these shapes: all within +-3 % or slower, HISTORY.md 4.2f / profiles/r04_gemm_*.txt; the code is gone.)
 template <int MI, int NI, int WM, int WN, int NS, int KB>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;

@@ -634,22 +634,3 @@ extern "C" int csam_rle_write_box(void* stream, const void* masks_u8, const int*
   CSAM_LAUNCH_CHECK("csam_rle_write");
   return CSAM_OK;
 }
-
-extern "C" int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
-                                  int* col_offsets, int* totals) {
-  return csam_rle_count_box(stream, masks_u8, idx_or_null, nullptr, N, H, W, col_offsets, totals);
-}
-
-extern "C" int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
-                                  const int* col_offsets, const long* mask_offsets, uint32_t* out_positions) {
-  return csam_rle_write_box(stream, masks_u8, idx_or_null, nullptr, N, H, W, col_offsets, mask_offsets, out_positions);
-}
-
-extern "C" int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals) {
-  return csam_rle_count_idx(stream, masks_u8, nullptr, N, H, W, col_offsets, totals);
-}
-
-extern "C" int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
-                              const long* mask_offsets, uint32_t* out_positions) {
-  return csam_rle_write_idx(stream, masks_u8, nullptr, N, H, W, col_offsets, mask_offsets, out_positions);
-}

@@ -67,10 +67,6 @@ SIGNATURES = {
     "csam_occupancy_prune": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "csam_post_finalize_compact": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "csam_box_nms": [_P, _P, _P, _I, _F, _P, _P, _P, _L],
-    "csam_rle_count": [_P, _P, _I, _I, _I, _P, _P],
-    "csam_rle_write": [_P, _P, _I, _I, _I, _P, _P, _P],
-    "csam_rle_count_idx": [_P, _P, _P, _I, _I, _I, _P, _P],
-    "csam_rle_write_idx": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "csam_rle_count_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "csam_rle_write_box": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "csam_coco_rle_pack": [_P, _P, _P, _P, _I, _L, _L, _P, _L, _P, _L, _P],
@@ -91,7 +87,6 @@ SIGNATURES = {
     "csam_i2t_t2i_fold": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P, _L, _I],
     "csam_i2t_stream": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I],
     "csam_upscale_fused": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I],
-    "csam_pool_adjoint_v2": [_P, _P, _P, _P, _P, _L, _I],
     "csam_head_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F],
     "csam_softmax_relpos": [_P, _P, _P, _P, _I, _I, _I, _I, _F],
     "csam_head_scatter": [_P, _P, _P, _I, _I, _I, _I, _I, _I],
@@ -1030,10 +1025,6 @@ def upscale_fused(keys, W1, b1, ln_g, ln_b, eps, W2_perm, b2, hyper, masks, B, s
 
 def pool_adjoint_mfma(masks, stats, tables, w, rows):
     call("csam_pool_adjoint_mfma", _stream(), _ptr(masks), _ptr(stats), _ptr(tables), _ptr(w), w.stride(0), rows)
-
-
-def pool_adjoint_v2(masks, stats, taps, w, rows):
-    call("csam_pool_adjoint_v2", _stream(), _ptr(masks), _ptr(stats), _ptr(taps), _ptr(w), w.stride(0), rows)
 
 
 def t2i_fused(q, out, B, workspace, X=None, Wkv=None, kpe=None, bv=None, K0=None, V0T=None):

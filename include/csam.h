@@ -17,6 +17,25 @@
  *     message; no C++ exception crosses the ABI;
  *   - "f16" = IEEE half, "f32" = float.  GEMM-shaped work: fp16 operands, fp32 MFMA accumulate.
  *   - reference file:line citations are relative to /root/reference.
+ *
+ * Roles (round 6).  Every entry below is one of:
+ *   PRODUCT     what CrowdSAM.generate / SamPredictor run by default.  Decoder routes depend on the batch size only:
+ *               >= 256 prompts per batch (the dense sweep): csam_i2t_t2i_fold, csam_upscale_stream, csam_t2i_shared,
+ *               csam_pool_adjoint_mfma, csam_mask_post_scored, csam_post_finalize_compact, csam_mask_write;
+ *               < 256 prompts (the shipped 32-prompt EPS batches): csam_token_block_a / _b, csam_token_heads, csam_i2t_stream,
+ *               csam_t2i_fused (+ csam_t2i_merge_launch, csam_t2i_fused_parts / _workspace_bytes), csam_splitk_reduce;
+ *               everything in the encoder, prompt, selection, NMS, small-region, RLE, evaluator and resize groups.
+ *   ROUTE       the kernel a PRODUCT kernel replaced on some batch range, still reachable through a DecoderPlan attribute
+ *               (crowdsam_amd/decoder.py: i2t_t2i, i2t_rank, i2t_rank_l1, t2i_rank, t2i_stream, i2t_stream, up_stream,
+ *               up_stream_small, i2t_fold, token_block, splitk -- attributes, not environment switches) and pinned against its
+ *               successor by a parity test: csam_i2t_t2i (unfolded), csam_i2t_rank, csam_i2t_rank_proj, csam_t2i_rank,
+ *               csam_t2i_stream, csam_i2t_fused, csam_upscale_fused, csam_token_self_attn, csam_mask_post.
+ *   COMPARATOR  reachable only through DecoderPlan(fused=False) -- round 1's unfused kernel chain, kept because the fused
+ *               kernels' tests compare against it -- or from a test directly: csam_attn_t2i, csam_attn_i2t,
+ *               csam_attn_t2i_workspace_bytes, csam_hyper_masks, csam_ln64_gelu, csam_softmax_stats, csam_pool_adjoint,
+ *               csam_post_finalize, csam_i2t_rank_workspace_bytes.
+ * Entries that neither a product path nor a test called were dropped in round 6: csam_rle_count, csam_rle_write,
+ * csam_rle_count_idx, csam_rle_write_idx (the *_box forms with boxes == NULL are they), csam_pool_adjoint_v2.
  */
 #ifndef CSAM_H
 #define CSAM_H
@@ -197,9 +216,6 @@ int csam_softmax_stats(void* stream, const float* masks, float* stats, int rows)
 int csam_adj_taps_bytes(void);
 int csam_pool_adjoint(void* stream, const float* masks, const float* stats, const void* taps_dev, void* w_f16,
                       long ldw, int rows);
-/* one-pass variant: stats[r][0] = plane max (from csam_upscale_fused), writes stats[r][1] = sum exp */
-int csam_pool_adjoint_v2(void* stream, const float* masks, float* stats, const void* taps_dev, void* w_f16, long ldw,
-                         int rows);
 /* the same on the matrix cores: out = U^T exp(x - max) U with the banded U packed into MFMA fragment blocks by the
  * host (csam_adj_mfma_bytes() bytes, layout in decoder.hip); one wave per plane, bound by the fp32 read of the logits */
 int csam_adj_mfma_bytes(void);
@@ -407,18 +423,11 @@ int csam_box_nms(void* stream, const float* boxes, const float* scores, int N, f
 long csam_mask_nms_workspace_bytes(int N);
 int csam_mask_nms(void* stream, const void* masks_u8, const float* scores, int N, int H, int W, float thr,
                   long* out_keep, int* out_count, void* workspace, long workspace_bytes);
-/* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes.  masks_u8 must hold strict 0 / 1 bytes
- * (what csam_mask_write produces and what a torch.bool tensor is): the W % 4 == 0 kernels compare bit 0 of packed bytes. */
-int csam_rle_count(void* stream, const void* masks_u8, int N, int H, int W, int* col_offsets, int* totals);
-int csam_rle_write(void* stream, const void* masks_u8, int N, int H, int W, const int* col_offsets,
-                   const long* mask_offsets, uint32_t* out_positions);
-/* The same two passes over the masks masks_u8[idx[i]] (idx NULL: i): the run-length encoder reads the kept masks in
- * their store slots instead of a gathered copy (amg.py:107-135 via crowdsam/model.py:288-296). */
-int csam_rle_count_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W, int* col_offsets,
-                       int* totals);
-int csam_rle_write_idx(void* stream, const void* masks_u8, const int* idx_or_null, int N, int H, int W,
-                       const int* col_offsets, const long* mask_offsets, uint32_t* out_positions);
-/* The same with the masks' bounding boxes (int32 [N,4] = x0, y0, x1, y1, inclusive maxima; NULL = scan everything): a column
+/* amg.py:107-135 mask_to_rle_pytorch: column-major change positions, two passes, over the masks masks_u8[idx[i]] (idx NULL: i) --
+ * the run-length encoder reads the kept masks in their store slots instead of a gathered copy (crowdsam/model.py:288-296).
+ * masks_u8 must hold strict 0 / 1 bytes (what csam_mask_write produces and what a torch.bool tensor is): the W % 4 == 0 kernels
+ * compare bit 0 of packed bytes.  (Round 6 dropped csam_rle_{count,write}[_idx]: the box forms with boxes == NULL are they.)
+ * With the masks' bounding boxes (int32 [N,4] = x0, y0, x1, y1, inclusive maxima; NULL = scan everything): a column
  * changes value only inside the box rows (and at row 0 against the column to its left), so the passes read the boxes instead
  * of the frames -- person-sized masks of a crowd frame cover a few percent of it. */
 int csam_rle_count_box(void* stream, const void* masks_u8, const int* idx_or_null, const int* boxes_or_null, int N, int H, int W,

@@ -166,7 +166,7 @@ def test_decoder_batch_4096_soak_250_launches(cuda):
 
 def test_flash_attn80_relpos_repeatable_many_launches(cuda):
     """head_dim 80 (ViT-H global blocks): 250 launches of the rel-pos variant on one set of operands must agree bit for bit
-    (the head_dim-64 kernel's intermittent seed error, DESIGN.md 4.2b, was only visible this way)."""
+    (the head_dim-64 kernel's intermittent seed error, HISTORY.md 4.2b, was only visible this way)."""
     from crowdsam_amd import hip
     torch.manual_seed(9)
     nH, D, T = 16, 1280, 4096

@@ -17,7 +17,7 @@ coords = torch.rand(B, 2, device="cuda") * 1023
 for _ in range(2): plan.run_batch(coords)
 torch.cuda.synchronize()
 names = ["csam_i2t_fused", "csam_i2t_stream", "csam_i2t_rank", "csam_i2t_rank_proj", "csam_i2t_t2i", "csam_i2t_t2i_fold", "csam_t2i_stream", "csam_t2i_rank", "csam_t2i_fused", "csam_t2i_shared", "csam_upscale_fused", "csam_upscale_stream", "csam_gemm_f16", "csam_gemm_f16_batched", "csam_linear_f32",
-         "csam_pool_adjoint", "csam_pool_adjoint_v2", "csam_pool_adjoint_mfma", "csam_softmax_stats", "csam_layernorm", "csam_add_cast", "csam_token_self_attn", "csam_point_tokens", "csam_rowscale_bias"]
+         "csam_pool_adjoint", "csam_pool_adjoint_mfma", "csam_softmax_stats", "csam_layernorm", "csam_add_cast", "csam_token_self_attn", "csam_point_tokens", "csam_rowscale_bias"]
 t = hip.KernelTimer(names); hip.set_timer(t)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

@@ -2,7 +2,7 @@
 """Build-time lint: an MFMA whose SrcC lives in VGPRs and is NOT its own vDst, followed closely by a load (LDS / global /
 scratch return) or another non-MFMA write into those SrcC registers (a write-after-read on the accumulator input).
 
-What is established: the hardware interlocks this case -- tools/probe/mfma_srcc_war.hip and
+What is established (HISTORY.md section 4.2b): the hardware interlocks this case -- tools/probe/mfma_srcc_war.hip and
 mfma_srcc_lds_war.hip found 0 wrong values with 0..32 wait states and 0..8 MFMAs queued ahead -- and for MFMAs the COMPILER
 emits (intrinsics) LLVM's hazard recognizer additionally pads the overwrite (`s_nop 2` = 3 wait states in every site of this
 tree).  The round-2 suspicion that such a site produced the intermittent flash-attention error was refuted in round 3 (the

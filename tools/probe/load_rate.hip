@@ -1,5 +1,5 @@
 // How many bytes per cycle does ONE CU move L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), and L2 -> registers by
-// global_load_dwordx4, with 4 / 8 / 16 waves per CU streaming a 2 MB (L2-resident) buffer?  (round 4, DESIGN.md 4.2f: the
+// global_load_dwordx4, with 4 / 8 / 16 waves per CU streaming a 2 MB (L2-resident) buffer?  (round 4, HISTORY.md 4.2f: the
 // 64- / 96- / 128-row GEMM kernel moves its operands at ~20 B/clk/CU however its waves are organised.)
 //   hipcc --offload-arch=gfx950 -O3 -o load_rate tools/probe/load_rate.hip && ./load_rate
 #include <hip/hip_runtime.h>

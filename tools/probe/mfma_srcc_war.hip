@@ -1,6 +1,6 @@
 // developer probe (gfx950): how many wait states does "v_mfma_f32_16x16x32_f16 reads SrcC" -> "VALU overwrites that VGPR"
 // need?  hipcc (ROCm 7.2 LLVM) separates the two by s_nop 2; csam_flash_attn's rel-pos variant produced wrong scores in
-// lanes 48..63 exactly where the compiler had re-used an accumulator-init quad that way.
+// lanes 48..63 exactly where the compiler had re-used an accumulator-init quad that way (HISTORY.md section 4.1).
 // For N = 0..9 wait states and P = 0..3 independent MFMAs queued ahead: D must equal A.B + C_old in every lane.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

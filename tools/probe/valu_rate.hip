@@ -1,4 +1,4 @@
-// What does the VALU pipe of a gfx950 SIMD charge per instruction class?  (round 4)
+// What does the VALU pipe of a gfx950 SIMD charge per instruction class?  (round 4, HISTORY.md §4.2e)
 // Every wave runs ITER x 16 INDEPENDENT instructions of one class (inline asm, 16 separate destination registers, so neither a
 // dependency nor the compiler is in the way) at 1 / 2 / 3 / 4 waves per SIMD; wave 0 of every workgroup brackets the loop
 // with s_memtime.  Printed: shader cycles per instruction as ONE wave sees it, and per SIMD (= that / waves per SIMD) -- the
