@@ -56,6 +56,17 @@ def settle_host():
     return gc.get_freeze_count()
 
 
+def settled(results, after=2):
+    """Wrap a stream of results (CrowdSAM.generate_stream): once ``after`` frames are through -- plans, workspaces and graphs are
+    created lazily by the first frames -- settle_host() runs again, so what the warm-up allocated is frozen too (the
+    call right after construction froze a cold model).  gc.freeze() is cumulative and permanent for the process: cycles among
+    frozen objects are never collected (a model deleted later keeps its memory until exit); gc.unfreeze() undoes it."""
+    for n, r in enumerate(results, 1):
+        yield r
+        if n == after:
+            settle_host()
+
+
 def profile(on=True, ranges=True):
     """tools/test.py --profile: per-stage times into CrowdSAM.timings (device-synchronised, so the stages no longer overlap)
     and roctx ranges for rocprofv3 --marker-trace (the reference has neither).  ``ranges`` alone

@@ -264,16 +264,35 @@ class SamPredictor:
         if dino is None or not hip.GRAPHS_ENABLED or hip.timer_active():
             return run()
         key = (B, tuple(g["input_sizes"]), c, n, g["bufset"], enc.cap, dino.cap, self.group_two_streams and two_streams)
+        # A key holds every frame's input size: a dataset of mixed aspect ratios would make nearly every group a new key, each
+        # costing an eager run, a device-wide synchronize and a capture that is never replayed.  So a key of MIXED
+        # sizes runs eagerly the first time it is seen and is captured the second time; the cache is a bounded LRU (graphs hold
+        # private memory pools).
         ent = self._group_graphs.get(key)
+        if ent is None and len(set(g["input_sizes"])) > 1:
+            self._group_graphs[key] = 1             # mixed frame sizes, seen once: eager, no capture yet
+            self._group_graphs_trim()
+            return run()
         if ent is None:
+            ent = 1                                 # a group of equal-sized frames (every uniform stream): captured at first sight
+        if ent == 1:
             run()                                   # this call's execution (also sets kernel attributes)
             torch.cuda.synchronize()
             ent = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ent):
                 run()                               # recorded, not executed
-            self._group_graphs[key] = ent
+            self._group_graphs.pop(key, None)
+            self._group_graphs[key] = ent           # most recently used last
+            self._group_graphs_trim()
             return
+        self._group_graphs[key] = self._group_graphs.pop(key)
         ent.replay()
+
+    _GROUP_GRAPH_CAP = 64        # chunk graphs kept (a uniform stream needs n_chunks x ramp sizes x 2 buffer sets ~ 30)
+
+    def _group_graphs_trim(self):
+        while len(self._group_graphs) > self._GROUP_GRAPH_CAP:
+            self._group_graphs.pop(next(iter(self._group_graphs)))
 
     @torch.no_grad()
     def group_bundle(self, g, b):

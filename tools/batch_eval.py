@@ -136,7 +136,7 @@ def worker(args):
         cm.settle_host()                 # long-lived objects out of the garbage collector's way (crowdsam.model.settle_host)
         t_run, kept = time.perf_counter(), 0
         # the rank's shard as ONE stream (CrowdSAM.generate_stream: the next frames' encoders run beside this frame's tail)
-        for i, out in zip(range(start, end), model.generate_stream(load(i) for i in range(start, end))):
+        for i, out in zip(range(start, end), cm.settled(model.generate_stream(load(i) for i in range(start, end)))):
             rows.append(detections_to_rows(i, out["boxes"], out["scores"]))
             kept += len(out["boxes"])
         if args.profile:

@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the library's kernel names, from its symbol table
 syms = subprocess.run(["bash", "-c", "strings %s/crowdsam_amd/libcsam_hip.so | grep -E '_kernel' | head -4000" % sys.argv[2]], capture_output=True, text=True).stdout
-own = set(re.findall(r"(\w+_kernel)", syms))
+own = syms            # mangled names: a kernel is the library's when its base name occurs in one of them
 ups = [i for i, r in enumerate(rows) if "upscale_stream_kernel" in r["Kernel_Name"]]
 a, b = ups[3], ups[8]            # five timed frames (launch 0 = setup, 1-2 = warm-up)
 acc = collections.defaultdict(lambda: [0, 0.0])
@@ -23,7 +23,8 @@ for r in rows[a:b]:
     n = r["Kernel_Name"]
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     m = re.search(r"(\w+_kernel)", n)
-    if m and m.group(1) in own and "elementwise" not in n and "reduce_kernel" not in n and "index" not in n:
+    base = m.group(1) if m else None
+    if base and base in own and not any(t in n for t in ("at::native", "rocprim", "rocclr", "hipcub", "Cijk", "rocblas")):
         n_own += 1; t_own += dur
         continue
     key = re.sub(r"<.*", "", n.split("(")[0])[-60:]

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Developer: per timed frame of the pipelined bench, what each HIP stream (queue) does and when -- start / end / kernel time of
 # the frame's own stream (sweep + tail) and of the look-ahead stream (encoder chunk + decoder constants), relative to the
-# frame's upscaler launch.   bash tools/dev_stream_timeline.sh [bench args]   -> gpurun_out/r05_stream_timeline.txt
+# frame's upscaler launch.   bash tools/dev_stream_timeline.sh [bench args]   -> gpurun_out/r06_stream_timeline.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$R TMPDIR=/tmp
 cd /tmp && rm -rf /tmp/stl && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/stl -o t -- \
   python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timer "$@" > /tmp/stl.log 2>&1
 F=$(find /tmp/stl -name "*kernel_trace.csv" | head -1)
-python - "$F" "$@" > $R/gpurun_out/r05_stream_timeline.txt <<'PY'
+python - "$F" "$@" > $R/gpurun_out/r06_stream_timeline.txt <<'PY'
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
@@ -42,4 +42,4 @@ for k in range(first, first + 8):
         for g, n0, n1, at in gaps[:6]:
             print("        gap %.2f ms at +%.2f after %s before %s" % (g / 1e6, at, n0, n1))
 PY
-cat $R/gpurun_out/r05_stream_timeline.txt
+cat $R/gpurun_out/r06_stream_timeline.txt

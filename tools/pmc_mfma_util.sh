@@ -2,8 +2,8 @@
 # Counter-derived MFMA utilisation per kernel, with the calibration of tools/pmc_mfma_calib.sh:
 # SQ_VALU_MFMA_BUSY_CYCLES charges 16 per v_mfma_f32_16x16x32_f16 (= its matrix-pipe occupancy), summed over all SIMDs;
 # GRBM_GUI_ACTIVE is summed over the 8 XCDs.  utilisation = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8).
-#   bash tools/pmc_mfma_util.sh encoder   (bench.py --encoder-only)     -> gpurun_out/r05_mfma_util_encoder.txt
-#   bash tools/pmc_mfma_util.sh frame     (bench.py, one crowded frame) -> gpurun_out/r05_mfma_util_frame.txt
+#   bash tools/pmc_mfma_util.sh encoder   (bench.py --encoder-only)     -> gpurun_out/r06_mfma_util_encoder.txt
+#   bash tools/pmc_mfma_util.sh frame     (bench.py, one crowded frame) -> gpurun_out/r06_mfma_util_frame.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$R CSAM_GRAPHS=0 TMPDIR=/tmp
 WHAT=${1:-encoder}
@@ -15,7 +15,7 @@ cd /tmp && rm -rf /tmp/pmc_mu
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -d /tmp/pmc_mu -o p -- \
   python $R/bench.py $ARGS --no-cpu-baseline --no-kernel-timer > /tmp/pmc_mu.log 2>&1
 DB=$(find /tmp/pmc_mu -name "*.db" | head -1)
-python - "$DB" > $R/gpurun_out/r05_mfma_util_$WHAT.txt <<'PY'
+python - "$DB" > $R/gpurun_out/r06_mfma_util_$WHAT.txt <<'PY'
 import sqlite3, sys, re, collections
 c = sqlite3.connect(sys.argv[1])
 cols = [d[0] for d in c.execute("select * from counters_collection limit 1").description]
@@ -44,4 +44,4 @@ ob = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in own.values())
 oa = sum(d.get("GRBM_GUI_ACTIVE", 0) / 8.0 for d in own.values())
 print("%-44s %7s %14.4g %14.4g %8.3f   (without torch's copy / elementwise / plan-build kernels)" % ("libcsam_hip KERNELS (time-weighted)", "", ob, oa, ob / (1024.0 * oa)))
 PY
-cat $R/gpurun_out/r05_mfma_util_$WHAT.txt
+cat $R/gpurun_out/r06_mfma_util_$WHAT.txt

@@ -85,7 +85,7 @@ def run(args, config, logger):
         end_idx = args.synthetic if args.end_idx == -1 else min(args.end_idx, args.synthetic)
         ids = list(range(args.start_idx, end_idx))
         # one frame of look-ahead (CrowdSAM.generate_stream): frame i+1's encoders run beside frame i's tail
-        for id_, result in zip(ids, model.generate_stream(synth.synthetic_crowd_frame(i) for i in ids)):
+        for id_, result in zip(ids, _cm.settled(model.generate_stream(synth.synthetic_crowd_frame(i) for i in ids))):
             output_content.append(instance_record(f"synthetic_{id_}.jpg", 0, result))
     else:
         model = CrowdSAM(config, logger)
@@ -109,7 +109,7 @@ def run(args, config, logger):
                 yield rec[0]
 
         results = model.generate_stream(frames()) if hasattr(model, "generate_stream") else (model.generate(f) for f in frames())
-        for id_, result in zip(image_ids, results):
+        for id_, result in zip(image_ids, _cm.settled(results)):
             logger.debug(f"start processing {id_}")
             image, gt_boxes, image_id = pending.popleft()
             output_content.append(instance_record(image_id, len(gt_boxes) - 1, result))     # "- 1" as tools/test.py:69
