@@ -13,17 +13,17 @@ from crowdsam.utils import DEFAULT_TEST_CONFIG
 from crowdsam_amd import synth
 
 t = dict(DEFAULT_TEST_CONFIG)
-t.update(grid_size=64, points_per_batch=4096, stability_score_thresh=0.25, pos_sim_thresh=-float("inf"),
-         filter_thresh=float("inf"), max_prompts=4096, box_nms_thresh=1.0, crop_nms_thresh=1.0, pred_iou_thresh=0.889)
+t.update(grid_size=64, points_per_batch=4096, pos_sim_thresh=-float("inf"), filter_thresh=float("inf"), max_prompts=4096)   # bench default
 cfg = {"environ": {"device": "cuda:0"}, "model": {"sam_model": "vit_l", "sam_arch": "crowdsam", "n_class": 1, "trainfree": False}, "test": t}
-m = CrowdSAM(cfg, sam_state_dict=synth.make_sam_state_dict("vit_l"), dino_state_dict=synth.make_dino_state_dict())
+m = CrowdSAM(cfg, sam_state_dict=synth.blob_heads(synth.make_sam_state_dict("vit_l")), dino_state_dict=synth.make_dino_state_dict())
 np.random.seed(42)
 frames = [synth.synthetic_crowd_frame(i, 1024, 150) for i in range(5)]
 for f in frames[:2]:
     m.generate(f)
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     for f in frames[2:2 + N]:
         m.generate(f)
     torch.cuda.synchronize()
