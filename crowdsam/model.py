@@ -363,21 +363,13 @@ class CrowdSAM:
         sim_c = sim[: int(feat_size[0]), : int(feat_size[1])]
         inv_factor = torch.tensor([feat_size[1] / w, feat_size[0] / h])
         if on_device:
-            # dense sweep (pos_sim_thresh = -inf): every grid cell passes whatever the prior says, so the list depends on the
-            # frame geometry only -- built once per (h, w, grid) instead of by ten small torch launches per frame (round 6)
-            dense_key = (h, w, g, str(sim.device)) if self.pos_sim_thresh == -float("inf") else None
-            if dense_key is not None and getattr(self, "_dense_points", (None, None))[0] == dense_key:
-                return self._dense_points[1]
             # same arithmetic where the map already is: nonzero() in row-major order, fp32 division, truncation
             # (:230's astype("int")) -- the map never goes D2H and only the point COUNT reaches the host
             coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
             # fp32 quotient via float64 (exactly the correctly rounded fp32 division of the host path, whatever the
             # device's fp32 divide does: 53 >= 2 * 24 + 2 bits make the double rounding innocuous)
             q = (coords.to(torch.float64) / inv_factor.to(coords.device, torch.float64)).to(torch.float32)
-            pts = q.to(torch.int32).contiguous()
-            if dense_key is not None:
-                self._dense_points = (dense_key, pts)
-            return pts
+            return q.to(torch.int32).contiguous()
         sim_c = sim_c.cpu()                                              # one small D2H
         coords = (sim_c > self.pos_sim_thresh).nonzero()[:, [1, 0]]
         return (coords / inv_factor).numpy()

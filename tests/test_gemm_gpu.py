@@ -249,3 +249,41 @@ def test_gemm_splitk_matches_single_pass(cuda, M, N, K, S):
     assert torch.equal(out, first)
     hip.gemm_f16_splitk(a, w, out, S, scratch, bias=bias, rowstats=stats)
     assert (out - (ref / stats[:, 1:2] + bias)).abs().max().item() < 2e-3 * scale
+
+
+def test_gemm4w_is_bitwise_the_128_column_kernel(cuda):
+    """Round 6: the hand-scheduled four-wave kernel (gemm4w_kernel) and the 128-column kernel must round alike -- an image's features
+    may not depend on which of them its batch size selects.  Same rows through both, compared bit for bit:
+    fp16 output + folded LayerNorm + GELU: M = 8192, N = 3072 is 1.5 rounds of 256 x 256 tiles -> 128-column kernel; its two halves
+    (192 tiles each) -> gemm4w.  fp32 output + residual + LayerScale + fp16 copy + LayerNorm partials: M = 16384, N = 1024 (256 tiles)
+    -> gemm4w; its quarters (64 tiles) -> 128-column kernel."""
+    from crowdsam_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 8192, 3072, 1024
+    a = (torch.randn(M, K, generator=g) * 0.5).to(cuda).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(cuda).half()
+    bias = torch.randn(N, generator=g).to(cuda)
+    af = a.float().view(M, K // 128, 128)
+    stats = torch.stack([af.sum(-1), (af * af).sum(-1)], -1).contiguous()
+    colsum = w.float().sum(1).contiguous()
+    whole = torch.empty(M, N, device=cuda, dtype=torch.float16)
+    hip.gemm_f16_ln(a, w, whole, bias=bias, act=hip.ACT_GELU, stats_in=stats, colsum=colsum, eps=1e-6)
+    for h in range(2):
+        r = slice(h * 4096, (h + 1) * 4096)
+        part = torch.empty(4096, N, device=cuda, dtype=torch.float16)
+        hip.gemm_f16_ln(a[r], w, part, bias=bias, act=hip.ACT_GELU, stats_in=stats[r].contiguous(), colsum=colsum, eps=1e-6)
+        assert torch.equal(part, whole[r]), "fp16 + LayerNorm fold + GELU: half %d differs" % h
+    M, N, K = 16384, 1024, 1024
+    a = (torch.randn(M, K, generator=g) * 0.5).to(cuda).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(cuda).half()
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    ls = (torch.rand(N, generator=g) + 0.5).to(cuda)
+    out, o16, st = torch.empty(M, N, device=cuda), torch.empty(M, N, device=cuda, dtype=torch.float16), torch.empty(M, N // 128, 2, device=cuda)
+    hip.gemm_f16_ln(a, w, out, bias=bias, residual=res, colscale=ls, out16=o16, stats_out=st)
+    assert torch.isfinite(out).all() and torch.isfinite(st).all() and torch.equal(o16, out.half())
+    for q in range(4):
+        r = slice(q * 4096, (q + 1) * 4096)
+        po, p16, ps = torch.empty(4096, N, device=cuda), torch.empty(4096, N, device=cuda, dtype=torch.float16), torch.empty(4096, N // 128, 2, device=cuda)
+        hip.gemm_f16_ln(a[r], w, po, bias=bias, residual=res[r].contiguous(), colscale=ls, out16=p16, stats_out=ps)
+        assert torch.equal(po, out[r]) and torch.equal(p16, o16[r]) and torch.equal(ps, st[r]), "fp32 epilogue: quarter %d differs" % q
