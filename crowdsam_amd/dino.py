@@ -162,7 +162,7 @@ class DinoPlan:
             if fold:
                 hip.gemm_f16_ln(ws["attn"], b["proj_w"], x, bias=b["proj_b"], colscale=b["ls1"], residual=x, M=T, out16=x16,
                                 stats_out=st)
-                # ONE image: fc1 in two row ranges.  4096 rows are exactly one round of the 256 x 256 ping-pong kernel (16 x 16
+                # ONE image: fc1 in two row ranges.  4096 rows are exactly one round of the 256 x 256 four-wave kernel (gemm4w; 16 x 16
                 # tiles on 256 CUs, as in the SAM encoder); all 5330 rows would be 336 tiles = 1.3 rounds and fall back to the
                 # 128 x 128 kernel (77 us at 580 TFLOP/s alone, 127 us beside the SAM encoder's stream); the remaining 1234 rows
                 # are 80 more tiles of the same kernel: -1.4 ms of GEMM time per frame (profiles/r04_dino_fc1_split.txt).

@@ -63,7 +63,11 @@ const char* csam_last_error(void);
  * Replaces every nn.Linear / 1x1 conv / im2col'd conv / ConvTranspose2d(k2,s2) on the path:
  * image_encoder.py:227,238 (qkv, proj), common.py:25-26 (MLP), image_encoder.py:88-104 (neck),
  * transformer.py:228-254 (decoder projections), mask_decoder.py:56-62 (upscaler), :187 (dino_proj).
- * W is the PyTorch Linear layout.  N % 128 == 0, K % 64 == 0, any M. */
+ * W is the PyTorch Linear layout.  N % 128 == 0, K % 64 == 0, any M.
+ * Kernel selection is a function of the arguments only (csrc/gemm_f16.hip gemm_launch): the hand-scheduled four-wave 256 x 256 x 64
+ * kernel (gemm4w, generated assembly main loop) for fp16 outputs with N >= 2048 and for fp32 outputs + fp32 residual from 192 tiles,
+ * K % 128 == 0; 128-column tiles of 64 / 96 / 128 / 256 rows otherwise.  Every kernel accumulates an output element over the same
+ * ascending chain of 32-wide MFMA steps and rounds its epilogue the same way: results do not depend on the kernel chosen. */
 int csam_gemm_f16(void* stream, const void* A_f16, long lda, const void* W_f16, long ldw, void* C, long ldc,
                   int c_dtype, const float* bias, const float* colscale, const void* residual, long ldr,
                   int r_dtype, int act, int M, int N, int K);
