@@ -84,3 +84,76 @@ def test_generated_asm_blocks_are_up_to_date():
         assert r.returncode == 0, r.stderr
         have = open(os.path.join(ROOT, "crowdsam_amd", "csrc", inc)).read()
         assert r.stdout == have, "%s is stale: python tools/gen/%s > crowdsam_amd/csrc/%s" % (inc, gen, inc)
+
+
+def _gemm4w_program():
+    env = {k: v for k, v in os.environ.items() if not k.startswith("G4_")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_gemm4w_asm.py")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_gemm4w_main_loop_is_up_to_date_and_ordered():
+    """The hand-scheduled GEMM main loop (crowdsam_amd/csrc/gemm4w_asm.inc) is what tools/gen/gen_gemm4w_asm.py emits with default
+    knobs, and its synchronisation reads as designed: per 64-wide K tile 128 MFMAs, 32 fragment reads, 16 LDS-DMA pieces each
+    directly preceded by its m0 write; every fragment read of an LDS stage comes after a barrier that follows a `vmcnt(0)`
+    issued after the LAST LDS-DMA into that stage (an LDS-DMA piece is ordered for another wave's ds_read only by the issuing
+    wave's vmcnt + a barrier); an LDS-DMA into a stage comes after a barrier that follows the last read of that stage's previous
+    tile (with its lgkmcnt(0) before the barrier)."""
+    import re
+    out = _gemm4w_program()
+    assert out == open(os.path.join(ROOT, "crowdsam_amd", "csrc", "gemm4w_asm.inc")).read(), \
+        "gemm4w_asm.inc is stale: python tools/gen/gen_gemm4w_asm.py > crowdsam_amd/csrc/gemm4w_asm.inc"
+    ins = re.findall(r'^\s+"([^"\\]+)\\n\\t"', out, flags=re.M)
+    assert sum(i.startswith("v_mfma") for i in ins) == 4 * 128        # two tiles in the loop body + two peeled tiles
+    assert sum(i.startswith("ds_read_b128") for i in ins) == 16 + 3 * 32 + 16
+    assert sum("global_load_lds" in i for i in ins) == 2 * 16 + 2 * 16  # prologue (tiles 0, 1) + the loop body's two tiles
+    for k, i in enumerate(ins):
+        if "global_load_lds" in i:
+            prev = [j for j in ins[max(0, k - 3):k] if not j.startswith("v_mfma")]
+            assert prev and prev[-1].startswith(("s_add_u32 m0", "s_nop")), (k, ins[k - 3:k + 1])
+
+    def stage_of_read(i):       # operand names ra<stage><ks> / rw<stage><ks>
+        return int(re.search(r"%\[r[aw](\d)\d\]", i).group(1))
+
+    def stage_of_dma(k):        # the m0 write before it: offset // 65536
+        j = k - 1
+        while not ins[j].startswith("s_add_u32 m0"):
+            j -= 1
+        return int(ins[j].split(",")[-1]) // 65536
+
+    # walk the straight-line stream twice around the loop body (prologue, body, body, tail): state per stage
+    a, b = ins.index("L_g4_loop_%=:"), ins.index("L_g4_tail_%=:")
+    stream = ins[:a] + [x for x in ins[a + 1:b] if "s_cbranch" not in x] * 2 + ins[b + 1:]
+    dma_pending = {0: False, 1: False}      # LDS-DMA issued into the stage and not yet (vmcnt(0) -> barrier)-published
+    waited = {0: True, 1: True}             # ... vmcnt(0) seen since the last DMA into the stage (publication needs a barrier next)
+    reads_open = {0: False, 1: False}       # fragment reads of the stage issued and not yet (lgkmcnt(0) -> barrier)-retired
+    lgkm_ok = True
+    for k, i in enumerate(stream):
+        if "global_load_lds" in i:
+            # find its stage from the nearest preceding m0 write in the stream
+            j = k - 1
+            while not stream[j].startswith("s_add_u32 m0"):
+                j -= 1
+            s = int(stream[j].split(",")[-1]) // 65536
+            assert not reads_open[s], "LDS-DMA into stage %d while its previous tile's reads are not retired (instruction %d)" % (s, k)
+            dma_pending[s], waited[s] = True, False
+        elif i.startswith("ds_read_b128"):
+            s = stage_of_read(i)
+            assert not dma_pending[s], "fragment read of stage %d before its LDS-DMA was published (instruction %d)" % (s, k)
+            reads_open[s] = True
+            lgkm_ok = False
+        elif i.startswith("s_waitcnt"):
+            if "vmcnt(0)" in i:
+                waited = {0: True, 1: True}
+            if "lgkmcnt(0)" in i:
+                lgkm_ok = True
+            m = re.search(r"vmcnt\((\d+)\)", i)
+            if m and int(m.group(1)) == 16:          # prologue: tile 0's sixteen pieces have landed, tile 1's may be in flight
+                waited[0] = True
+        elif i == "s_barrier":
+            for s in (0, 1):
+                if dma_pending[s] and waited[s]:
+                    dma_pending[s] = False
+                if reads_open[s] and lgkm_ok:
+                    reads_open[s] = False
