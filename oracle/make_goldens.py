@@ -136,6 +136,52 @@ def golden_decoder_big():
     print("decoder_big", low.shape, float(low.abs().mean()), iou[:2], cls[:2, :, 0])
 
 
+def decoder_blob_inputs(n=24):
+    """Decoder case for the blob-mask weight set (crowdsam_amd.synth.blob_heads): an image embedding shaped like the neck's output
+    under those weights (per-pixel LayerNorm of seeded noise x the modified neck.3 gamma / beta: the kernel channels nearly empty,
+    the blob channel empty), seeded DINO tokens, n seeded prompts (the frame centre among them)."""
+    sd = synth.blob_heads(synth.make_sam_state_dict(TEST_ARCH))
+    rs = np.random.RandomState(31)
+    x = torch.from_numpy(rs.standard_normal((1, 256, 64, 64)).astype(np.float32))
+    x = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+    emb = x * sd["image_encoder.neck.3.weight"].view(1, -1, 1, 1) + sd["image_encoder.neck.3.bias"].view(1, -1, 1, 1)
+    dino = torch.from_numpy(rs.standard_normal((1, 73, 73, 1024)).astype(np.float32))
+    pts = rs.randint(0, 1024, size=(n, 1, 2)).astype(np.float64)
+    pts[0, 0] = (512.0, 512.0)
+    return sd, emb, dino, pts
+
+
+def golden_decoder_blob():
+    """The blob-mask weight set through the REFERENCE prompt encoder + mask decoder (mask_decoder.py:138-199): pins the oracle
+    (and through it the HIP path, tests/test_pipeline_gpu.py::test_generate_blob_weights_matches_oracle) on the weights the
+    bench runs since round 6."""
+    modeling, build, amg = ref_import.load_modeling()
+    D, depth, heads, gidx = synth.SAM_CONFIGS[TEST_ARCH]
+    sd, emb, dino, pts = decoder_blob_inputs()
+    sam = build._build_sam(D, depth, heads, 1, list(gidx))
+    sam.load_state_dict(sd, strict=True)
+    sam.eval()
+    with torch.no_grad():
+        coords = torch.as_tensor(pts)
+        labels = torch.ones(len(pts), 1, dtype=torch.int)
+        sparse, dense = sam.prompt_encoder(points=(coords, labels), boxes=None, masks=None)
+        pe = sam.prompt_encoder.get_dense_pe()
+        low, iou, cls = sam.mask_decoder(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse,
+                                         dense_prompt_embeddings=dense, multimask_output=True, dino_feats=dino)
+    area = (low > 0).sum((2, 3))
+    inter, union = (low > 1).sum((2, 3)), (low > -1).sum((2, 3))
+    np.savez_compressed(os.path.join(OUT, "decoder_blob_test128.npz"), low_sample=low[:, :, 1::8, 3::8].numpy(),
+                        low_sum=low.double().sum((2, 3)).numpy(), low_abs_sum=low.double().abs().sum((2, 3)).numpy(),
+                        area=area.numpy(), inter=inter.numpy(), union=union.numpy(), iou=iou.numpy(), cls=cls.numpy())
+    yy, xx = torch.meshgrid(torch.arange(256.), torch.arange(256.), indexing="ij")
+    m3 = (low[:, 3] > 0).float()
+    cx = (m3 * xx).sum((1, 2)) / m3.sum((1, 2)).clamp(min=1) * 4
+    cy = (m3 * yy).sum((1, 2)) / m3.sum((1, 2)).clamp(min=1) * 4
+    off = torch.sqrt((cx - coords[:, 0, 0]) ** 2 + (cy - coords[:, 0, 1]) ** 2)
+    print("decoder_blob", low.shape, "areas (256^2 px) median", area.median().item(), "stability median",
+          float((inter.double() / union.clamp(min=1)).median()), "centroid offset of the largest blob from its prompt: median %.1f px" % off.median().item())
+
+
 def golden_encoder_vitl():
     """Full-depth (24 blocks) ViT-L reference encoder on the BASELINE configs[1] input."""
     sam, sd, _ = load_ref_sam("vit_l")

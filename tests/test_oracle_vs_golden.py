@@ -86,6 +86,37 @@ def test_box_prompts_match_reference(sd):
     np.testing.assert_allclose(cls.numpy(), g["cls"], rtol=1e-4, atol=1e-5)
 
 
+def test_blob_weight_decoder_matches_reference():
+    """Round 6: the blob-mask weight set (synth.blob_heads -- what bench.py runs) through the oracle's prompt encoder + mask decoder
+    against the REFERENCE's own run on the same weights (tests/golden/decoder_blob_test128.npz): logits, the pixel counts behind
+    area / stability, IoU and class scores; and the property the weight set exists for -- every mask is a compact region around
+    its prompt with a high stability score."""
+    from oracle.make_goldens import decoder_blob_inputs
+    g = _load("decoder_blob_test128.npz")
+    bsd, emb, dino, pts = decoder_blob_inputs()
+    with torch.no_grad():
+        sparse = so.embed_points(bsd, torch.as_tensor(pts), torch.ones(len(pts), 1, dtype=torch.int))
+        low, iou, cls = so.mask_decoder(bsd, emb, so.dense_pe(bsd), sparse, dino)
+    scale = np.abs(g["low_sample"]).mean()
+    np.testing.assert_allclose(low[:, :, 1::8, 3::8].numpy(), g["low_sample"], rtol=1e-4, atol=2e-4 * scale + 1e-4)
+    np.testing.assert_allclose(low.double().abs().sum((2, 3)).numpy(), g["low_abs_sum"], rtol=1e-4)
+    np.testing.assert_allclose(iou.numpy(), g["iou"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cls.numpy(), g["cls"], rtol=1e-4, atol=1e-5)
+    for name, thr in (("area", 0.0), ("inter", 1.0), ("union", -1.0)):
+        cnt = (low > thr).sum((2, 3)).numpy()
+        assert np.abs(cnt - g[name]).max() <= 2, name                  # a pixel within fp32 round-off of a threshold may flip
+    # the reference's own masks are blobs at the prompt: largest candidate 100 .. 12 000 of 65 536 low-res pixels, stability >= 0.8
+    # for most, centred within a few pixels of the prompt
+    area, stab = g["area"][:, 3], g["inter"][:, 3] / np.maximum(g["union"][:, 3], 1)
+    assert (area > 100).all() and np.median(area) < 2000 and np.median(stab) > 0.85
+    yy, xx = np.mgrid[0:256, 0:256]
+    m3 = (low[:, 3] > 0).numpy()
+    cx = (m3 * xx).sum((1, 2)) / np.maximum(m3.sum((1, 2)), 1) * 4
+    cy = (m3 * yy).sum((1, 2)) / np.maximum(m3.sum((1, 2)), 1) * 4
+    off = np.hypot(cx - pts[:, 0, 0], cy - pts[:, 0, 1])
+    assert np.median(off) < 8.0, off
+
+
 def test_encoder_matches_reference(sd):
     g = _load("encoder_test128.npz")
     D, depth, heads, gidx = synth.SAM_CONFIGS[ARCH]
