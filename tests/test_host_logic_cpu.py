@@ -204,3 +204,15 @@ def test_roctx_ranges_are_balanced_and_off_by_default():
     finally:
         trace.disable()
     assert not trace.enabled
+
+
+def test_settled_passes_results_through_and_freezes_once(monkeypatch):
+    """crowdsam.model.settled (round 6): a transparent wrapper around a result stream that calls settle_host() exactly once,
+    after the `after`-th result (plans and graphs are built lazily by the first frames)."""
+    import crowdsam.model as cm
+    calls = []
+    monkeypatch.setattr(cm, "settle_host", lambda: calls.append(1) or 0)
+    assert list(cm.settled(iter(range(5)), after=2)) == [0, 1, 2, 3, 4] and calls == [1]
+    calls.clear()
+    assert list(cm.settled(iter(range(1)), after=2)) == [0] and calls == []          # shorter than the warm-up: no second freeze
+    assert list(zip("ab", cm.settled(iter([10, 20, 30])))) == [("a", 10), ("b", 20)]  # zip may stop early: nothing breaks
