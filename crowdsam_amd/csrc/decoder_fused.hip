@@ -1332,6 +1332,9 @@ namespace {
 // phase and a rank-112 first conv at three waves per SIMD were measured in round 4 and are gone: profiles/r04_valu_rate.txt,
 // r04_upscale_prio.txt, r04_upscale_rank_probe.txt
 #define CSAM_UP_XDEPTH 3
+#ifndef CSAM_UP_PIN
+#define CSAM_UP_PIN 1
+#endif
 constexpr int US_TOK = 32;
 constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
 constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
@@ -1453,6 +1456,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
         half8_t xf[XD];
 #pragma unroll
         for (int ks = 0; ks < XD - 1; ++ks) xf[ks] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
+        if (CSAM_UP_PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < US_KS; ++ks) {
           if (ks + XD - 1 < US_KS)
@@ -1460,7 +1464,11 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni][ks], xf[ks % XD], a1[ni], 0, 0, 0);
-          asm volatile("" ::: "memory");
+          // CSAM_UP_PIN: a scheduling barrier per k-step.  With the memory fence alone the MFMAs float up to their fragment read:
+          // `ds_read_b128; s_waitcnt lgkmcnt(0); 4 x v_mfma` on six of the eight k-steps (ISA of round 6), the ring collapsed to
+          // one register quad
+          if (CSAM_UP_PIN) __builtin_amdgcn_sched_barrier(0);
+          else asm volatile("" ::: "memory");
         }
       }
       // LayerNorm2d statistics over the 64 channels of a pixel: in-lane partial sums (16 channels, packed), the
@@ -1478,7 +1486,7 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
       const floatx4 qsum = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, q2[0] + q2[1], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const float mean = ssum[0] * (1.f / 64.f);
       const float var = fmaxf(qsum[0] * (1.f / 64.f) - mean * mean, 0.f);
-      const float rstd = 1.0f / sqrtf(var + p.eps);
+      const float rstd = rsqrtf(var + p.eps);          // v_rsq_f32 (1 ulp), as every other LayerNorm here; the IEEE sqrt + divide was ~30 dependent VALU instructions per sub-tile
       const float nmr = -mean * rstd;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {                // two N tiles (4 channel pairs) at a time
@@ -2439,8 +2447,68 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
 // =====================================================================================================
 namespace {
 
+// FUSE_SWAP_REDUCE: the lane-group reductions of the two softmaxes (partners 16 and 32 lanes away) by v_permlane16_swap /
+// v_permlane32_swap (gfx950) instead of __shfl_xor.  The shuffle is a ds_bpermute_b32 -- an LDS round trip with `s_waitcnt
+// lgkmcnt(0)` two instructions later, eight per producer tile and four per reader step (ISA of round 6), and that wait also drains
+// every fragment read in flight.  Swapping a register with a copy of itself leaves (own, partner) or (partner, own) in the pair;
+// max and + are commutative, so the results are bit-identical.  0 = the shuffles.
+#ifndef FUSE_SWAP_REDUCE
+#define FUSE_SWAP_REDUCE 1
+#endif
+__device__ __forceinline__ float fuse_max16(float v) {
+#if FUSE_SWAP_REDUCE
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a = s[0], b = s[1];      // scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 (clang)
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+#else
+  return fmaxf(v, __shfl_xor(v, 16, 64));
+#endif
+}
+__device__ __forceinline__ float fuse_sum16(float v) {
+#if FUSE_SWAP_REDUCE
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a = s[0], b = s[1];
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+#else
+  return v + __shfl_xor(v, 16, 64);
+#endif
+}
+__device__ __forceinline__ float fuse_max32(float v) {
+#if FUSE_SWAP_REDUCE
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned a = s[0], b = s[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+#else
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+#endif
+}
+
 #define FUSE_RING 8       // M fragments in flight in the P . M phase
+// FUSE_PM_PIPE (round 6, from the ISA): with the grouped form below (FUSE_RING loads, then FUSE_RING MFMAs, one fence per group)
+// the machine scheduler sinks every fragment read to ONE MFMA before its use -- `ds_read_b128; s_waitcnt lgkmcnt(1); v_mfma` 32
+// times per tile, two fragment registers alternating whatever FUSE_RING says (which is why rings of 4 / 8 / 16 measured equal in
+// round 3) -- so each of the 32 MFMAs of the phase waits an LDS round trip less 16 cycles.  1 = the fenced pipeline, 0 = the
+// grouped form.
+#ifndef FUSE_PM_PIPE
+#define FUSE_PM_PIPE 1
+#endif
+// FUSE_RD_PIPE: the same for the READER waves (score fragments pinned above their MFMAs; a ring of this many transposed-read pairs
+// for the P^T . X product, its first pairs requested ahead of the softmax).  0 = the compiler's order.
+#ifndef FUSE_RD_PIPE
+#define FUSE_RD_PIPE 8
+#endif
 #define FUSE_PF_EARLY -1  // next tile's q / residual loads before P . M: 1 yes, 0 no, -1 = only in the projected form
+// gamma / beta rows of the LayerNorm (layer 0: FOLD bit 1 clear) requested FUSE_GB_DEPTH channel blocks ahead of their use.  The
+// compiler's own order requests block ni + 1 four packed FMAs (~30 cycles) before `s_waitcnt lgkmcnt(0)`: sixteen exposed LDS round
+// trips per 16-token tile (ISA of round 6).  With a depth the first blocks are requested BEFORE the statistics (the M ring's 32
+// registers are dead by then) and block ni + depth when block ni has been consumed; same loads, same arithmetic, same order of
+// floating-point operations: bit-identical by construction.  0 = the compiler's order.
+#ifndef FUSE_GB_DEPTH
+#define FUSE_GB_DEPTH 4
+#endif
 template <bool PROJ>
 struct IF {
   static constexpr int KP = IR_M_BYTES;
@@ -2543,7 +2611,27 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           __builtin_memcpy(&qf, &qraw[pr], 16);
           sc[pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[pr], qf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        if constexpr (PROJ) {
+        // (see FUSE_PM_PIPE: product instantiations only)
+        constexpr bool PM_PIPE = FUSE_PM_PIPE && ((!PROJ && FOLD == 1) || (PROJ && FOLD == 3));
+        if constexpr (PROJ && PM_PIPE) {
+          // Kp fragments j = nj * 4 + pr through a pinned ring, as P . M below (the compiler's order: one MFMA ahead)
+          half8_t kr[FUSE_RING];
+          auto kpread = [&](int j) {
+            const int row = (j & 3) * 16 + fr;
+            return *(const half8_t*)(smem + G::KP + row * 512 + ((((j >> 2) * 4 + fg) ^ fr) << 4));
+          };
+#pragma unroll
+          for (int i = 0; i < FUSE_RING; ++i) kr[i] = kpread(i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            half8_t xf;
+            __builtin_memcpy(&xf, &xres[j >> 2], 16);
+            sc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kr[j % FUSE_RING], xf, sc[j & 3], 0, 0, 0);
+            if (j + FUSE_RING < 32) kr[j % FUSE_RING] = kpread(j + FUSE_RING);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if constexpr (PROJ) {
 #pragma unroll
           for (int nj = 0; nj < 8; ++nj) {
             half8_t xf;
@@ -2562,11 +2650,11 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           const floatx4 s4 = sc[pr];
           const float s3 = key7 ? -INFINITY : s4[3];
           float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
-          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fuse_max16(mx);
           const float p0 = csam_exp2(s4[0] - mx), p1 = csam_exp2(s4[1] - mx);
           const float p2 = csam_exp2(s4[2] - mx), p3 = csam_exp2(s3 - mx);
           float sum = (p0 + p1) + (p2 + p3);
-          sum += __shfl_xor(sum, 16, 64);
+          sum = fuse_sum16(sum);
           const float inv = __builtin_amdgcn_rcpf(sum);
           const int o = (pr & 1) * 4;
           pf[pr >> 1][o] = (half_t)(p0 * inv);
@@ -2593,6 +2681,27 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         // next tile's q / residual fragments: the hoisted-Q layer reads them from L2 (shared by all prompts) and issues them
         // AFTER P . M, which leaves their 48 registers to the M fragments in flight (3.92 vs 4.30 ms per 4096 prompts); the
         // projected layer reads per-prompt keys from HBM and needs the whole tile to hide them (4.63 vs 4.88 ms)
+        // the product instantiations only (layer 0 <false, 1>, layer 1 <true, 3>): the comparator forms keep more rows in LDS
+        // reads of their own and would spill
+        if constexpr (PM_PIPE) {
+          // P . M as an explicit software pipeline over k = ks * 16 + n: fragment k + FUSE_RING is requested right after MFMA k
+          // and a scheduling barrier after every pair keeps both there (see FUSE_PM_PIPE above).  Per accumulator the two k-steps
+          // still arrive in ascending order: bit-identical to the grouped form.
+          half8_t mf[FUSE_RING];
+          auto mread = [&](int k) {
+            const int row = (k & 15) * 16 + fr;
+            return *(const half8_t*)(smem + row * 128 + ((((k >> 4) * 4 + fg) ^ (row & 7)) << 4));
+          };
+#pragma unroll
+          for (int i = 0; i < FUSE_RING; ++i) mf[i] = mread(i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            acc[k & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf[k % FUSE_RING], pf[k >> 4], acc[k & 15], 0, 0, 0);
+            if (k + FUSE_RING < 32) mf[k % FUSE_RING] = mread(k + FUSE_RING);
+            __builtin_amdgcn_sched_barrier(0);                 // a memory fence is not enough: the MFMAs themselves float up to their reads
+          }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -2609,7 +2718,18 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
             asm volatile("" ::: "memory");
           }
         }
+        }
         if (!PF_EARLY && st + 1 < spp) prefetch(tile + 4);   // lands under LayerNorm + stores
+        constexpr int GBD = ((FOLD & 2) || PROJ) ? 0 : FUSE_GB_DEPTH;   // the projected form has no registers to spare (it would spill)
+        floatx4 gmr[GBD > 0 ? GBD : 1], ber[GBD > 0 ? GBD : 1];
+        if constexpr (GBD > 0) {
+#pragma unroll
+          for (int i = 0; i < GBD; ++i) {
+            gmr[i] = *(const floatx4*)(par + 256 + i * 16 + fg * 4);
+            ber[i] = *(const floatx4*)(par + 512 + i * 16 + fg * 4);
+          }
+          asm volatile("" ::: "memory");                      // the requests stay above the statistics
+        }
         float2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int ni = 0; ni < 16; ++ni) {
@@ -2627,12 +2747,18 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         const float2_t rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
 #pragma unroll
         for (int ni = 0; ni < 16; ++ni) {
-          if ((ni & 3) == 0) asm volatile("" ::: "memory");
+          if (GBD > 0 || (ni & 3) == 0) asm volatile("" ::: "memory");
           const float2_t v0 = {acc[ni][0], acc[ni][1]}, v1 = {acc[ni][2], acc[ni][3]};
           float2_t y0 = __builtin_elementwise_fma(v0, rs2, nm2), y1 = __builtin_elementwise_fma(v1, rs2, nm2);
           if constexpr (!(FOLD & 2)) {
-            const floatx4 gm = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
-            const floatx4 be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
+            floatx4 gm, be;
+            if constexpr (GBD > 0) {
+              gm = gmr[ni % (GBD > 0 ? GBD : 1)];
+              be = ber[ni % (GBD > 0 ? GBD : 1)];
+            } else {
+              gm = *(const floatx4*)(par + 256 + ni * 16 + fg * 4);
+              be = *(const floatx4*)(par + 512 + ni * 16 + fg * 4);
+            }
             const float2_t g0 = {gm[0], gm[1]}, g1 = {gm[2], gm[3]}, b0 = {be[0], be[1]}, b1 = {be[2], be[3]};
             y0 = __builtin_elementwise_fma(y0, g0, b0);
             y1 = __builtin_elementwise_fma(y1, g1, b1);
@@ -2640,6 +2766,12 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           const int chunk = ni * 2 + (fg >> 1);
           *(half4_t*)(slice + fr * 512 + ((chunk ^ fr) << 4) + (fg & 1) * 8) =
               half4_t{(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1]};
+          if constexpr (GBD > 0) {
+            if (ni + GBD < 16) {                               // block ni + depth into the registers block ni just left
+              gmr[ni % (GBD > 0 ? GBD : 1)] = *(const floatx4*)(par + 256 + (ni + GBD) * 16 + fg * 4);
+              ber[ni % (GBD > 0 ? GBD : 1)] = *(const floatx4*)(par + 512 + (ni + GBD) * 16 + fg * 4);
+            }
+          }
         }
         // next tile's operands land here; the asm RE-DEFINES them, so whatever copies the register allocator places on
         // the loop edge move landed data (an in-flight asm load result must never reach a compiler-made copy)
@@ -2729,24 +2861,55 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kp8, qblk, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
         {
-          // the reader has ~80 spare registers: all 16 key fragments of the half-step in flight at once (the stand-alone
-          // kernel keeps one step of read-ahead and waits an LDS round trip per MFMA pair)
-          half8_t xf[8][MI];
+          // key fragments of the half-step j = ks * MI + mi.  The compiler's own order puts every read ONE MFMA before its use
+          // (`ds_read_b128; s_waitcnt lgkmcnt(1); v_mfma`, ISA of round 6 -- whatever the source order says); FUSE_RD_PIPE pins a
+          // ring of eight fragments (all sixteen at once spill the reader)
+          if (FUSE_RD_PIPE) {
+            constexpr int R1 = 8;
+            half8_t xr[R1];
+            auto kread = [&](int j) {
+              return *(const half8_t*)(xb + ((j % MI) * 16 + fr) * 512 + ((((j / MI) * 4 + fg) ^ fr) << 4));
+            };
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks)
+            for (int j = 0; j < R1; ++j) xr[j] = kread(j);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              xf[ks][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
+            for (int j = 0; j < 8 * MI; ++j) {
+              sa[j % MI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[j % R1], qp[j / MI], sa[j % MI], 0, 0, 0);
+              if (j + R1 < 8 * MI) xr[j % R1] = kread(j + R1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+            half8_t xf[8][MI];
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks)
+            for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks][mi], qp[ks], sa[mi], 0, 0, 0);
+              for (int mi = 0; mi < MI; ++mi)
+                xf[ks][mi] = *(const half8_t*)(xb + (mi * 16 + fr) * 512 + (((ks * 4 + fg) ^ fr) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+                sa[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks][mi], qp[ks], sa[mi], 0, 0, 0);
+          }
+        }
+        // transposed key fragments of the P^T . X product: the first FUSE_RD_PIPE pairs are requested here, ahead of the
+        // softmax (they depend on the keys only), the rest as the ring drains; 0 = the compiler's order (one pair ahead)
+        constexpr int RD = FUSE_RD_PIPE > 0 ? FUSE_RD_PIPE : 1;
+        half4_t xa0[RD], xa1[RD];
+        auto tr_pair = [&](int n, half4_t& a0, half4_t& a1) {
+          a0 = ds_tr_b64(xb + troff[0] + (((2 * n + tsub) ^ trow[0]) << 4));
+          a1 = ds_tr_b64(xb + troff[1] + (((2 * n + tsub) ^ trow[1]) << 4));
+        };
+        if (FUSE_RD_PIPE) {
+#pragma unroll
+          for (int i = 0; i < RD; ++i) tr_pair(i, xa0[i], xa1[i]);
+          __builtin_amdgcn_sched_barrier(0);
         }
         float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
                          fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fuse_max16(mx);
+        mx = fuse_max32(mx);
         const float mnew = fmaxf(m, mx);
         const float alpha = csam_exp2(m - mnew);
         m = mnew;
@@ -2765,12 +2928,24 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
 #pragma unroll
           for (int n = 0; n < 16; ++n) y[n] *= alpha;
         }
+        if (FUSE_RD_PIPE) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-          const half4_t a0 = ds_tr_b64(xb + troff[0] + (((2 * n + tsub) ^ trow[0]) << 4));
-          const half4_t a1 = ds_tr_b64(xb + troff[1] + (((2 * n + tsub) ^ trow[1]) << 4));
-          const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
+          for (int n = 0; n < 16; ++n) {
+            const half4_t a0 = xa0[n % RD], a1 = xa1[n % RD];
+            const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
+            if (n + RD < 16) tr_pair(n + RD, xa0[n % RD], xa1[n % RD]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int n = 0; n < 16; ++n) {
+            half4_t a0, a1;
+            tr_pair(n, a0, a1);
+            const half8_t xt = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xt, pb, y[n], 0, 0, 0);
+          }
         }
       }
       if (more) land_kpe();                          // requested a whole step ago: no exposed latency
