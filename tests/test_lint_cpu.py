@@ -157,3 +157,38 @@ def test_gemm4w_main_loop_is_up_to_date_and_ordered():
                     dma_pending[s] = False
                 if reads_open[s] and lgkm_ok:
                     reads_open[s] = False
+
+
+def test_lds_fragment_rings_are_not_collapsed():
+    """tools/lint_lds_ring.py: in the product kernels of the decoder sweep (csam_i2t_t2i both layers, csam_upscale_stream) the
+    LDS reads that feed MFMAs are issued a ring ahead of them.  Round 6 found in the ISA that the machine scheduler had sunk every
+    one of them to a single MFMA before its use (119 of 162 LDS-fed MFMAs of the layer-0 kernel waited an LDS round trip); the
+    scheduling barriers of FUSE_PM_PIPE / FUSE_RD_PIPE / CSAM_UP_PIN keep the source order, and this gate notices when a compiler
+    update or an edit collapses a ring again."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_lds_ring.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") >= 3 and "OVER" not in r.stdout, r.stdout
+
+
+def test_lds_ring_lint_measures_the_distance(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lint_lds_ring as L
+    isa = tmp_path / "k.s"
+    isa.write_text("""
+_Z1kv:                                  ; @k
+	ds_read_b128 v[4:7], v20
+	ds_read_b128 v[8:11], v20 offset:16
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[12:15], v[0:3]
+	ds_read_b128 v[4:7], v20 offset:32
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]
+	v_mfma_f32_16x16x32_f16 v[16:19], v[24:27], v[12:15], v[16:19]
+	s_waitcnt lgkmcnt(0)
+	v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[12:15], v[0:3]
+	s_endpgm
+""")
+    res = L.scan(str(isa))
+    # three LDS-fed MFMAs at distances 0, 1 and 2 (the register-fed one in between does not count); two of them tight
+    assert res == {"_Z1kv": (3, 2, {0: 1, 1: 1, 2: 1})}, res
