@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
       p[kt] = acc;
     }
     p[13] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = csam_max_x16(mx);
+    mx = csam_max_x32(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 14; ++kt) {
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void win_attn2_kernel(const half_t* __restr
         sum += e;
       }
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = csam_sum_x16(sum);
+    sum = csam_sum_x32(sum);
     const float inv = 1.0f / sum;
 
     half8_t pf[7];
@@ -447,8 +447,8 @@ __global__ __launch_bounds__(64 * NW80, 1) void win_attn2_hd80_kernel(const half
       p[kt] = acc;
     }
     p[13] = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = csam_max_x16(mx);
+    mx = csam_max_x32(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 14; ++kt) {
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(64 * NW80, 1) void win_attn2_hd80_kernel(const half
         sum += e;
       }
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = csam_sum_x16(sum);
+    sum = csam_sum_x32(sum);
     const float inv = 1.0f / sum;
 
     half8_t pf[7];

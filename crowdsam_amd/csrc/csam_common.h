@@ -149,14 +149,52 @@ __device__ __forceinline__ float csam_apply_act(float v, int act) {
   if (act == CSAM_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
+// Reductions with the partner 32 / 16 lanes away through v_permlane32_swap / v_permlane16_swap (gfx950) instead of __shfl_xor
+// (= ds_bpermute_b32: an LDS round trip and an `s_waitcnt lgkmcnt(0)` that also drains every LDS read in flight).  Swapping a
+// register with a copy of itself leaves (own, partner) in the even 16- / 32-lane groups and (partner, own) in the odd ones; +
+// and max are commutative, so every lane gets the bits the shuffle form gave it.  The results are copied to scalars before the
+// bit cast: __builtin_bit_cast of an ELEMENT of the builtin's vector result reads element 0 (clang; seen in the ISA).
+__device__ __forceinline__ void csam_swap32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned x = s[0], y = s[1];
+  a = __builtin_bit_cast(float, x);
+  b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void csam_swap16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned x = s[0], y = s[1];
+  a = __builtin_bit_cast(float, x);
+  b = __builtin_bit_cast(float, y);
+}
+#ifndef CSAM_SWAP_REDUCE      // developer A/B: -DCSAM_SWAP_REDUCE=0 = the __shfl_xor forms
+#define CSAM_SWAP_REDUCE 1
+#endif
+#if CSAM_SWAP_REDUCE
+__device__ __forceinline__ float csam_max_x32(float v) { float a, b; csam_swap32(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float csam_max_x16(float v) { float a, b; csam_swap16(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float csam_sum_x32(float v) { float a, b; csam_swap32(v, a, b); return a + b; }
+__device__ __forceinline__ float csam_sum_x16(float v) { float a, b; csam_swap16(v, a, b); return a + b; }
+#else
+__device__ __forceinline__ float csam_max_x32(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float csam_max_x16(float v) { return fmaxf(v, __shfl_xor(v, 16, 64)); }
+__device__ __forceinline__ float csam_sum_x32(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float csam_sum_x16(float v) { return v + __shfl_xor(v, 16, 64); }
+#endif
+
 __device__ __forceinline__ float csam_wave_sum(float v) {
+  v = csam_sum_x32(v);
+  v = csam_sum_x16(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 __device__ __forceinline__ float csam_wave_max(float v) {
+  v = csam_max_x32(v);
+  v = csam_max_x16(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 

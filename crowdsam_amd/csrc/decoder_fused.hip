@@ -188,13 +188,13 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
       const float s0 = fmaf(sacc[0], sc, mb[0]), s1 = fmaf(sacc[1], sc, mb[1]);
       const float s2 = fmaf(sacc[2], sc, mb[2]), s3 = fmaf(sacc[3], sc, mb[3]);
       float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = csam_max_x16(mx);
+      mx = csam_max_x32(mx);
       const float p0 = csam_exp2(s0 - mx), p1 = csam_exp2(s1 - mx);
       const float p2 = csam_exp2(s2 - mx), p3 = csam_exp2(s3 - mx);
       float sum = (p0 + p1) + (p2 + p3);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = csam_sum_x16(sum);
+      sum = csam_sum_x32(sum);
       const half4_t pb = {(half_t)p0, (half_t)p1, (half_t)p2, (half_t)p3};
       const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const float inv = __builtin_amdgcn_rcpf(sum);
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
       }
       acc[mi][ni] = v;
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = csam_sum_x16(sum);
+    sum = csam_sum_x32(sum);
     const float mean = sum * (1.f / 256.f);
     float var = 0.f;
 #pragma unroll
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void i2t_fused_kernel(I2tArgs p) {
         const float d = acc[mi][ni][e] - mean;
         var += d * d;
       }
-    var += __shfl_xor(var, 16, 64);
-    var += __shfl_xor(var, 32, 64);
+    var = csam_sum_x16(var);
+    var = csam_sum_x32(var);
     const float rstd = rsqrtf(var * (1.f / 256.f) + p.eps);
 #pragma unroll
     for (int ni = 0; ni < 16; ++ni) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_stream_kernel(I2tArgs p, 
         const floatx4 sacc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka[hh], qb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const float s3 = sacc[3] + mb3;
         float mx = fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], s3));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = csam_max_x16(mx);
         const half4_t pb = {(half_t)csam_exp2(sacc[0] - mx), (half_t)csam_exp2(sacc[1] - mx),
                             (half_t)csam_exp2(sacc[2] - mx), (half_t)csam_exp2(s3 - mx)};
         const floatx4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(va[hh], pb, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -886,11 +886,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void i2t_rank_kernel(IrArgs p, int
         const floatx4 s4 = sc[pr];
         const float s3 = key7 ? -INFINITY : s4[3];
         float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = csam_max_x16(mx);
         const float p0 = csam_exp2(s4[0] - mx), p1 = csam_exp2(s4[1] - mx);
         const float p2 = csam_exp2(s4[2] - mx), p3 = csam_exp2(s3 - mx);
         float sum = (p0 + p1) + (p2 + p3);
-        sum += __shfl_xor(sum, 16, 64);
+        sum = csam_sum_x16(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         const int o = (pr & 1) * 4;
         pf[pr >> 1][o] = (half_t)(p0 * inv);
@@ -1200,8 +1200,8 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
       a1[mi][ni] += b1v[ni];
       sum += (a1[mi][ni][0] + a1[mi][ni][1]) + (a1[mi][ni][2] + a1[mi][ni][3]);
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = csam_sum_x16(sum);
+    sum = csam_sum_x32(sum);
     const float mean = sum * (1.f / 64.f);
     float var = 0.f;
 #pragma unroll
@@ -1211,8 +1211,8 @@ __global__ __launch_bounds__(256, 2) void upscale_fused_kernel(UpArgs p) {
         const float d = a1[mi][ni][e] - mean;
         var += d * d;
       }
-    var += __shfl_xor(var, 16, 64);
-    var += __shfl_xor(var, 32, 64);
+    var = csam_sum_x16(var);
+    var = csam_sum_x32(var);
     const float rstd = 1.0f / sqrtf(var * (1.f / 64.f) + p.eps);
     const float nmr = -mean * rstd;
 #pragma unroll
@@ -1827,8 +1827,8 @@ __global__ __launch_bounds__(256, 2) void t2i_fused_kernel(T2iArgs p) {
       s[mi][ni] = a;
       mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = csam_max_x16(mx);
+    mx = csam_max_x32(mx);
     if (fg == 0) wmax[(wave * 8 + ni) * 16 + fr] = mx;
   }
   __syncthreads();
@@ -1853,8 +1853,8 @@ __global__ __launch_bounds__(256, 2) void t2i_fused_kernel(T2iArgs p) {
       }
       o[ni] = __builtin_amdgcn_mfma_f32_16x16x16f16(pb, vf[mi][ni], o[ni], 0, 0, 0);   // [j][d]
     }
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
+    ls = csam_sum_x16(ls);
+    ls = csam_sum_x32(ls);
     lsum[ni] = ls;
   }
   // per-wave partials -> LDS (disjoint from wmax): O lane = (d = l&15, queries j = 4g+r); l lane = (j = l&15)
@@ -1942,8 +1942,8 @@ __global__ __launch_bounds__(256) void t2i_shared_kernel(const half_t* __restric
     mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
     mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
     mx = fmaxf(mx, s[3][3]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = csam_max_x16(mx);
+    mx = csam_max_x32(mx);
     const float mnew = fmaxf(m, mx);
     const float alpha = csam_exp2((m - mnew) * sl2);
     m = mnew;
@@ -1968,8 +1968,8 @@ __global__ __launch_bounds__(256) void t2i_shared_kernel(const half_t* __restric
       vf[i] = vn[i];
     }
   }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  l = csam_sum_x16(l);
+  l = csam_sum_x32(l);
   if (row0 + fr < R) {
     const float inv = 1.f / l;
     half4_t r;
@@ -2135,8 +2135,8 @@ __global__ __launch_bounds__(256, 2) void t2i_stream_kernel(T2sArgs p, int promp
         sa[mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[hh][mi], qb[hh], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         mx = fmaxf(mx, fmaxf(fmaxf(sa[mi][0], sa[mi][1]), fmaxf(sa[mi][2], sa[mi][3])));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = csam_max_x16(mx);
+      mx = csam_max_x32(mx);
       const float mnew = fmaxf(m[hh], mx);
       const float alpha = csam_exp2((m[hh] - mnew) * sc);
       m[hh] = mnew;
@@ -2162,8 +2162,8 @@ __global__ __launch_bounds__(256, 2) void t2i_stream_kernel(T2sArgs p, int promp
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         float ls = l[hh];
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
+        ls = csam_sum_x16(ls);
+        ls = csam_sum_x32(ls);
         const float inv = 1.f / ls;
         if (fr < 7) {
           half4_t r;
@@ -2355,8 +2355,8 @@ __global__ __launch_bounds__(256, T2R_OCC) void t2i_rank_kernel(T2rArgs p, int p
     // ---- online softmax over this lane's 8 keys of softmax row fr (base-2 scores); P^T as the B operand of Y^T += X^T P^T
     float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
                      fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = csam_max_x16(mx);
+    mx = csam_max_x32(mx);
     const float mnew = fmaxf(m, mx);
     const float alpha = csam_exp2(m - mnew);
     m = mnew;
@@ -2387,8 +2387,8 @@ __global__ __launch_bounds__(256, T2R_OCC) void t2i_rank_kernel(T2rArgs p, int p
     if (tp == tpp - 1) {                           // prompt complete: normalise and write Y[b][j][head][256] fp16
       const int b = t / tpp;
       float ls = l;
-      ls += __shfl_xor(ls, 16, 64);
-      ls += __shfl_xor(ls, 32, 64);
+      ls = csam_sum_x16(ls);
+      ls = csam_sum_x32(ls);
       const float inv = 1.f / ls;
       const int hh = fr >> 3, j = fr & 7;
       if (j < 7) {
@@ -2447,45 +2447,10 @@ extern "C" int csam_t2i_rank(void* stream, const void* X_f16, const void* Wk_f16
 // =====================================================================================================
 namespace {
 
-// FUSE_SWAP_REDUCE: the lane-group reductions of the two softmaxes (partners 16 and 32 lanes away) by v_permlane16_swap /
-// v_permlane32_swap (gfx950) instead of __shfl_xor.  The shuffle is a ds_bpermute_b32 -- an LDS round trip with `s_waitcnt
-// lgkmcnt(0)` two instructions later, eight per producer tile and four per reader step (ISA of round 6), and that wait also drains
-// every fragment read in flight.  Swapping a register with a copy of itself leaves (own, partner) or (partner, own) in the pair;
-// max and + are commutative, so the results are bit-identical.  0 = the shuffles.
-#ifndef FUSE_SWAP_REDUCE
-#define FUSE_SWAP_REDUCE 1
-#endif
-__device__ __forceinline__ float fuse_max16(float v) {
-#if FUSE_SWAP_REDUCE
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const unsigned a = s[0], b = s[1];      // scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 (clang)
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-#else
-  return fmaxf(v, __shfl_xor(v, 16, 64));
-#endif
-}
-__device__ __forceinline__ float fuse_sum16(float v) {
-#if FUSE_SWAP_REDUCE
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const unsigned a = s[0], b = s[1];
-  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-#else
-  return v + __shfl_xor(v, 16, 64);
-#endif
-}
-__device__ __forceinline__ float fuse_max32(float v) {
-#if FUSE_SWAP_REDUCE
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  const unsigned a = s[0], b = s[1];
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-#else
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-#endif
-}
-
+// The lane-group reductions of the two softmaxes (partners 16 and 32 lanes away) go through csam_max_x16 / csam_sum_x16 /
+// csam_max_x32 (csam_common.h: v_permlane16_swap / v_permlane32_swap instead of __shfl_xor = ds_bpermute_b32 + `s_waitcnt
+// lgkmcnt(0)`, eight per producer tile and four per reader step in the ISA of round 6; that wait also drained every fragment
+// read in flight).  Bit-identical: max and + are commutative.
 #define FUSE_RING 8       // M fragments in flight in the P . M phase
 // FUSE_PM_PIPE (round 6, from the ISA): with the grouped form below (FUSE_RING loads, then FUSE_RING MFMAs, one fence per group)
 // the machine scheduler sinks every fragment read to ONE MFMA before its use -- `ds_read_b128; s_waitcnt lgkmcnt(1); v_mfma` 32
@@ -2650,11 +2615,11 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
           const floatx4 s4 = sc[pr];
           const float s3 = key7 ? -INFINITY : s4[3];
           float mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s3));
-          mx = fuse_max16(mx);
+          mx = csam_max_x16(mx);
           const float p0 = csam_exp2(s4[0] - mx), p1 = csam_exp2(s4[1] - mx);
           const float p2 = csam_exp2(s4[2] - mx), p3 = csam_exp2(s3 - mx);
           float sum = (p0 + p1) + (p2 + p3);
-          sum = fuse_sum16(sum);
+          sum = csam_sum_x16(sum);
           const float inv = __builtin_amdgcn_rcpf(sum);
           const int o = (pr & 1) * 4;
           pf[pr >> 1][o] = (half_t)(p0 * inv);
@@ -2908,8 +2873,8 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
         }
         float mx = fmaxf(fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3])),
                          fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3])));
-        mx = fuse_max16(mx);
-        mx = fuse_max32(mx);
+        mx = csam_max_x16(mx);
+        mx = csam_max_x32(mx);
         const float mnew = fmaxf(m, mx);
         const float alpha = csam_exp2(m - mnew);
         m = mnew;
@@ -2951,8 +2916,8 @@ __global__ __launch_bounds__(512, 1) void i2t_t2i_kernel(IrArgs p, T2rArgs r, in
       if (more) land_kpe();                          // requested a whole step ago: no exposed latency
       if (st == spp - 1) {
         float ls = l;
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
+        ls = csam_sum_x16(ls);
+        ls = csam_sum_x32(ls);
         const float inv = 1.f / ls;
         const int hh = fr >> 3, j = fr & 7;
         if (j < 7) {
