@@ -504,6 +504,9 @@ struct AdjMfma {
   half8_t blk2[16][64];    // A fragments: lane (ti = 16i + l&15, g): U[(2s + (e>=4))*16 + 4g + (e&3)][ti]
 };
 
+#ifndef POOL_RING
+#define POOL_RING 1
+#endif
 __global__ __launch_bounds__(256, 1) void pool_adjoint_mfma_kernel(const float* __restrict__ masks,
                                                                    float* __restrict__ stats,
                                                                    const AdjMfma* __restrict__ tab,
@@ -524,6 +527,23 @@ __global__ __launch_bounds__(256, 1) void pool_adjoint_mfma_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
   float esum = 0.f;
+  // POOL_RING (round 6, from the ISA): the kernel runs ONE wave per SIMD (376 registers) and the compiler kept two or three pairs
+  // of 16-byte loads in flight per lane -- 16-24 KB per CU against the ~60 KB that 8 TB/s x ~2 us of loaded latency ask for,
+  // which is the 0.58 of the HBM roof it measured at.  The logits now come through a ring of POOL_RING (a, b) pairs: pair q + 8
+  // (the same k-step of the NEXT 16-row half block) is requested when pair q has been consumed, a scheduling barrier per
+  // k-step keeps the requests where they are written: 16 loads = 64 KB per CU in flight.  Same loads, same arithmetic order.
+  floatx4 ra[8], rb[8];
+  auto ld_pair = [&](int q, floatx4& a, floatx4& b) {      // q = (2 s + h) * 8 + kx, clamped: the last half block re-requests itself
+    const int qq = q < 128 ? q : q - 8;
+    const float* rp = src + (qq >> 3) * 16 * 256 + (qq & 7) * 32;
+    a = *(const floatx4*)rp;
+    b = *(const floatx4*)(rp + 4);
+  };
+  if (POOL_RING) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_pair(i, ra[i], rb[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll 1
   for (int s = 0; s < 8; ++s) {
     floatx4 t[2][5];
@@ -534,7 +554,16 @@ __global__ __launch_bounds__(256, 1) void pool_adjoint_mfma_kernel(const float* 
       for (int j = 0; j < 5; ++j) t[h][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kx = 0; kx < 8; ++kx) {              // k-step outer: one E fragment live at a time
-        const floatx4 a = *(const floatx4*)(rowp + kx * 32), b = *(const floatx4*)(rowp + kx * 32 + 4);
+        floatx4 a, b;
+        if (POOL_RING) {
+          a = ra[kx];
+          b = rb[kx];
+          ld_pair((2 * s + h) * 8 + kx + 8, ra[kx], rb[kx]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          a = *(const floatx4*)(rowp + kx * 32);
+          b = *(const floatx4*)(rowp + kx * 32 + 4);
+        }
         half8_t ef;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
