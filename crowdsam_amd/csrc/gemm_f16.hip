@@ -96,6 +96,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   <3,4,2,2,2>   96-row tile, 4 waves, 2 x 28 KB: two workgroups per CU; fills one round of 512 where 128 rows do not
 // (Round 4 measured producer waves, deeper rings, 192-row tiles, counted waits, interleaved LDS-DMA issue and non-temporal
 // stores on these shapes: all within +-3 % or slower, HISTORY.md 4.2f / profiles/r04_gemm_*.txt; the code is gone.)
+#ifndef G128_READS_FIRST
+#define G128_READS_FIRST 1
+#endif
 template <int MI, int NI, int WM, int WN, int NS, int KB>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
@@ -195,6 +198,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
     if (kt + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * KB);
     const char* base = smem + cur * STAGE;
+#if G128_READS_FIRST
+    // every fragment of the K tile requested before its first MFMA, kept there by a scheduling barrier.  The compiler's own
+    // order waits `lgkmcnt(0)` three times per 64-wide tile (k-step 0's reads, a late straggler, k-step 1's reads issued only
+    // after k-step 0's MFMAs; ISA of round 6); this form exposes one LDS round trip per tile.  Per accumulator the k-steps still
+    // arrive in ascending order: bit-identical.
+    half8_t af[KB / 32][MI], wf[KB / 32][NI];
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      const int coff = ((kk * 4 + fg) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[kk][i] = *(const half8_t*)(base + w_off[i] + coff);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[kk][i] = *(const half8_t*)(base + a_off[i] + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
+#else
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       const int coff = ((kk * 4 + fg) ^ sw) << 4;
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
+#endif
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
   __syncthreads();                                     // operand ring is free: reuse it for the output tile
