@@ -649,14 +649,34 @@ __device__ __forceinline__ void gemm4w_store_row(half_t* crow, bool ok, const fl
 // (csam_gemm_f16_ln producer), all straight from the registers: per lane 8 x 16-byte residual loads (issued one tile row
 // ahead), 8 x 16-byte fp32 stores, 4 x 16-byte fp16 stores (permlane16-widened), and the 128-column statistics as the same
 // butterfly the 128-column kernel runs over lanes -- strides 16, 8, 4 are register pairs here, 2 and 1 are lane ^ 32, lane ^ 16.
-template <int I>
+// G4_RES_AHEAD (round 6, untimed): residual rows requested this many tile rows ahead of their use.  One row ahead (rounds 5-6 as
+// measured) leaves 8 x 16 B per lane = 32 KB per CU in flight and a tile row's arithmetic (~0.4 us) as the only cover for an HBM
+// access under a 168 MB burst: every one of the eight rows waits.  After the main loop the fragment registers v[128:255] are
+// free, so three rows fit.  A lane reads exactly the elements it later overwrites, so in-place C == R stays fine at any depth.
+#ifndef G4_RES_AHEAD
+#define G4_RES_AHEAD 3
+#endif
+#ifndef G4_FULL_PATH          // developer A/B: 0 = every tile through the guarded epilogues (rounds 5-6 as measured)
+#define G4_FULL_PATH 1
+#endif
+// FULL: every row of the workgroup's tile is inside M (all tiles of SAM's passes, all but the last tile row of DINOv2's).  The
+// guarded form puts each store behind an exec-mask branch, and across those joins the compiler cannot count the memory operations
+// in flight: it waits `vmcnt(0)` -- every residual row requested ahead AND every store issued so far -- at the first residual use
+// of a tile row (ISA of round 6: two such waits per tile even with rows requested ahead; eight with one row ahead).  The
+// straight-line form gets counted waits.
+// HASR: p.R != null, as a template parameter for the same reason (no join behind a uniform branch either).
+template <int I, bool FULL, bool HASR>
 __device__ __forceinline__ void gemm4w_f32_row(const GemmArgs& p, int m, int n0, int fg, const floatx4 (&bz)[8], const floatx4 (&cz)[8],
-                                               floatx4 (&rc)[8], floatx4 (&rn)[8]) {
-  const bool ok = m < p.M, okn = m + 16 < p.M;
-  if (I < 7 && p.R) {                                  // residual of the NEXT tile row (in-place C == R is fine: other rows)
+                                               floatx4 (&rr)[G4_RES_AHEAD][8]) {
+  constexpr int RA = G4_RES_AHEAD;
+  const bool ok = FULL || m < p.M, okn = FULL || m + 16 * RA < p.M;
+  floatx4 rn[8];
+  floatx4 (&rc)[8] = rr[I % RA];
+  if (I + RA < 8 && HASR) {                             // residual of tile row I + RA (in-place C == R is fine: other rows)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      rn[j] = okn ? *(const floatx4*)((const float*)p.R + (long)(m + 16) * p.ldr + n0 + j * 16) : floatx4{0.f, 0.f, 0.f, 0.f};
+      rn[j] = okn ? *(const floatx4*)((const float*)p.R + (long)(m + 16 * RA) * p.ldr + n0 + j * 16) : floatx4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);                 // the requests stay ahead of this row's arithmetic and stores
   }
   floatx4 v[8] = {gemm4w_acc<I * 8 + 0>(), gemm4w_acc<I * 8 + 1>(), gemm4w_acc<I * 8 + 2>(), gemm4w_acc<I * 8 + 3>(),
                   gemm4w_acc<I * 8 + 4>(), gemm4w_acc<I * 8 + 5>(), gemm4w_acc<I * 8 + 6>(), gemm4w_acc<I * 8 + 7>()};
@@ -668,7 +688,7 @@ __device__ __forceinline__ void gemm4w_f32_row(const GemmArgs& p, int m, int n0,
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[j][e] = __fmul_rn(v[j][e], cz[j][e]);
     }
-    if (p.R) {
+    if (HASR) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[j][e] = __fadd_rn(v[j][e], rc[j][e]);
     }
@@ -711,8 +731,32 @@ __device__ __forceinline__ void gemm4w_f32_row(const GemmArgs& p, int m, int n0,
     b = __fadd_rn(b, __shfl_xor(b, 16, 64));
     if (fg == 0 && ok) *(float2_t*)(p.st_out + ((long)m * (p.N / BN) + (n0 >> 7)) * 2) = float2_t{a, b};
   }
+  if (I + RA < 8 && HASR) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) rc[j] = rn[j];
+    for (int j = 0; j < 8; ++j) rc[j] = rn[j];
+  }
+}
+
+// the whole fp32 epilogue of a wave's 128 x 128 outputs as ONE straight line per (FULL, HASR)
+template <bool FULL, bool HASR>
+__device__ __forceinline__ void gemm4w_f32_epilogue(const GemmArgs& p, int m0, int n0, int fg, const floatx4 (&bz)[8],
+                                                    const floatx4 (&cz)[8]) {
+  floatx4 rr[G4_RES_AHEAD][8];
+#pragma unroll
+  for (int i = 0; i < G4_RES_AHEAD; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rr[i][j] = (HASR && (FULL || m0 + 16 * i < p.M)) ? *(const floatx4*)((const float*)p.R + (long)(m0 + 16 * i) * p.ldr + n0 + j * 16)
+                                                        : floatx4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);
+  gemm4w_f32_row<0, FULL, HASR>(p, m0, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<1, FULL, HASR>(p, m0 + 16, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<2, FULL, HASR>(p, m0 + 32, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<3, FULL, HASR>(p, m0 + 48, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<4, FULL, HASR>(p, m0 + 64, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<5, FULL, HASR>(p, m0 + 80, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<6, FULL, HASR>(p, m0 + 96, n0, fg, bz, cz, rr);
+  gemm4w_f32_row<7, FULL, HASR>(p, m0 + 112, n0, fg, bz, cz, rr);
 }
 
 template <bool LN, int ACT, bool F32>
@@ -783,20 +827,14 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
 #endif
   if (F32) {
     const int m0 = bm0 + wm * 128 + fr, n0 = bn0 + wn * 128 + fg * 4;
-    floatx4 rc[8], rn[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      rc[j] = (p.R && m0 < p.M) ? *(const floatx4*)((const float*)p.R + (long)m0 * p.ldr + n0 + j * 16) : floatx4{0.f, 0.f, 0.f, 0.f};
-      rn[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const bool full = G4_FULL_PATH && bm0 + 256 <= p.M;   // workgroup-uniform, as is p.R
+    if (full) {
+      if (p.R) gemm4w_f32_epilogue<true, true>(p, m0, n0, fg, bz, cz);
+      else gemm4w_f32_epilogue<true, false>(p, m0, n0, fg, bz, cz);
+    } else {
+      if (p.R) gemm4w_f32_epilogue<false, true>(p, m0, n0, fg, bz, cz);
+      else gemm4w_f32_epilogue<false, false>(p, m0, n0, fg, bz, cz);
     }
-    gemm4w_f32_row<0>(p, m0, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<1>(p, m0 + 16, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<2>(p, m0 + 32, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<3>(p, m0 + 48, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<4>(p, m0 + 64, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<5>(p, m0 + 80, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<6>(p, m0 + 96, n0, fg, bz, cz, rc, rn);
-    gemm4w_f32_row<7>(p, m0 + 112, n0, fg, bz, cz, rc, rn);
     return;
   }
   float2_t ms[8];                                      // (mean, rstd) of the lane's row in each of its 8 row tiles
@@ -824,6 +862,17 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmArgs p) {
   const int m0 = bm0 + wm * 128 + fr;
   half_t* c0 = (half_t*)p.C + (long)m0 * p.ldc + bn0 + wn * 128 + (fg & 1) * 16 + (fg >> 1) * 8;
   const long rs = 16 * p.ldc;
+  if (G4_FULL_PATH && bm0 + 256 <= p.M) {      // whole tile inside M (workgroup-uniform): the 64 stores of a wave as one straight line, no exec-mask branches
+    gemm4w_store_row<LN, ACT, 0>(c0, true, bz, cz, ms[0][0], ms[0][1]);
+    gemm4w_store_row<LN, ACT, 1>(c0 + rs, true, bz, cz, ms[1][0], ms[1][1]);
+    gemm4w_store_row<LN, ACT, 2>(c0 + 2 * rs, true, bz, cz, ms[2][0], ms[2][1]);
+    gemm4w_store_row<LN, ACT, 3>(c0 + 3 * rs, true, bz, cz, ms[3][0], ms[3][1]);
+    gemm4w_store_row<LN, ACT, 4>(c0 + 4 * rs, true, bz, cz, ms[4][0], ms[4][1]);
+    gemm4w_store_row<LN, ACT, 5>(c0 + 5 * rs, true, bz, cz, ms[5][0], ms[5][1]);
+    gemm4w_store_row<LN, ACT, 6>(c0 + 6 * rs, true, bz, cz, ms[6][0], ms[6][1]);
+    gemm4w_store_row<LN, ACT, 7>(c0 + 7 * rs, true, bz, cz, ms[7][0], ms[7][1]);
+    return;
+  }
   gemm4w_store_row<LN, ACT, 0>(c0, m0 < p.M, bz, cz, ms[0][0], ms[0][1]);
   gemm4w_store_row<LN, ACT, 1>(c0 + rs, m0 + 16 < p.M, bz, cz, ms[1][0], ms[1][1]);
   gemm4w_store_row<LN, ACT, 2>(c0 + 2 * rs, m0 + 32 < p.M, bz, cz, ms[2][0], ms[2][1]);
