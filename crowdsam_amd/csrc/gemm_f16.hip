@@ -18,6 +18,7 @@
 //     lane ends up with 4 consecutive N columns of one output row -> 8/16-byte stores.
 //   * epilogue fused: +bias[n], GELU(erf)/ReLU, *colscale[n] (DINOv2 LayerScale),
 //     +residual[m,n] (f16 or f32), cast to f16 or f32.
+#include <type_traits>
 #include "csam_common.h"
 
 namespace {
@@ -98,6 +99,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // stores on these shapes: all within +-3 % or slower, HISTORY.md 4.2f / profiles/r04_gemm_*.txt; the code is gone.)
 #ifndef G128_READS_FIRST
 #define G128_READS_FIRST 1
+#endif
+#ifndef G128_FULL_PATH        // developer A/B: 0 = the guarded fp32 copy-out for every tile
+#define G128_FULL_PATH 1
+#endif
+#ifndef G128_HOIST            // developer A/B: 0 = bias / column sums / column scales loaded per tile in the epilogue
+#define G128_HOIST 1
 #endif
 template <int MI, int NI, int WM, int WN, int NS, int KB>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
@@ -189,6 +196,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) stage(s, s * KB);
 
+  // the wave's NI x 4 bias / column-sum / column-scale values, requested here, under the whole main loop (as gemm4w does).  In the
+  // epilogue each was a load behind a uniform branch with `s_waitcnt vmcnt(0)` right after it, once per (mi, ni) tile: up to
+  // 3 MI NI serialised L2 round trips with nothing to cover them (ISA of round 6).  Same values: bit-identical.
+  // (HOIST: the four-wave workgroups only -- two of them share a CU and have 256 registers per wave; the eight-wave 256-row form
+  // must stay inside 128 to keep two workgroups per CU and loads these values in its epilogue as before)
+  constexpr bool HOIST = G128_HOIST && NW <= 4;
+  floatx4 bzv[NI], csv[NI], scv[NI];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = bn0 + wn * NI * 16 + ni * 16 + (lane >> 4) * 4;
+      bzv[ni] = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+      csv[ni] = p.st_in ? *(const floatx4*)(p.colsum + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+      scv[ni] = p.colscale ? *(const floatx4*)(p.colscale + n) : floatx4{1.f, 1.f, 1.f, 1.f};
+    }
+  }
+
   int cur = 0;                                         // kt % NS
   for (int kt = 0; kt < nk; ++kt) {
     // my loads of stage kt have landed; the barrier then covers everybody's, and also says every wave is
@@ -270,10 +294,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
       const int col = wn * NI * 16 + ni * 16 + fg * 4;    // column inside the 128-col tile
       const int n = bn0 + col;
       floatx4 v = acc[mi][ni];
-      const floatx4 bb = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+      floatx4 bb;
+      if constexpr (HOIST) bb = bzv[ni];
+      else bb = p.bias ? *(const floatx4*)(p.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
       if (p.st_in) {                                      // folded LayerNorm: rstd * (acc - mean * colsum) + bias
         const float mean = stab[2 * trow], rstd = stab[2 * trow + 1];
-        const floatx4 cs = *(const floatx4*)(p.colsum + n);
+        floatx4 cs;
+        if constexpr (HOIST) cs = csv[ni];
+        else cs = *(const floatx4*)(p.colsum + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ln_fold1(v[j], mean, rstd, cs[j], bb[j]);
       } else {
@@ -288,7 +316,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = csam_apply_act(v[j], p.act);
       }
-      if (p.colscale) v *= *(const floatx4*)(p.colscale + n);
+      if (p.colscale) {
+        if constexpr (HOIST) v *= scv[ni];
+        else v *= *(const floatx4*)(p.colscale + n);
+      }
       if (p.R && !res_late && m < p.M) {
         const int mr = p.res_mod > 0 ? m % p.res_mod : m;
         if (p.r_dt == CSAM_DT_F32) {
@@ -314,13 +345,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
   }
   __syncthreads();
   if (p.c_dt == CSAM_DT_F32) {
+    // FULLC: the whole tile lies inside M (workgroup-uniform) -- the copy-out as ONE straight line.  Behind the per-row exec-mask
+    // guard the compiler can neither hoist the residual loads of later pieces nor count the memory operations in flight, so every
+    // piece was load -> `vmcnt(0)` -> add -> store: PR * 32 / NT dependent memory round trips per thread (ISA of round 6).
+    auto copy_out_f32 = [&](auto FULLC) {
+    constexpr bool FULL = decltype(FULLC)::value;
+    constexpr int NIT = PR * 32 / NT;
+    floatx4 rres[NIT];
+    if (FULL && res_late) {                            // all residual pieces requested before the first is needed
 #pragma unroll
-    for (int it = 0; it < PR * 32 / NT; ++it) {
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + it * NT, row = c >> 5, sl = c & 31;
+        const int m = bm0 + pass * PR + row;
+        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+        rres[it] = *(const floatx4*)((const float*)p.R + (long)mr * p.ldr + bn0 + ((sl ^ (row & 31)) << 2));
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int c = tid + it * NT;                     // PR*32 16-B pieces: row c>>5, LDS slot c&31
       const int row = c >> 5, sl = c & 31;
       const int m = bm0 + pass * PR + row;
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) {
+      if (FULL) {
+        const int n = bn0 + ((sl ^ (row & 31)) << 2);
+        v = *(const floatx4*)(smem + c * 16);
+        if (res_late) v += rres[it];
+        GEMM_ST((floatx4*)((float*)p.C + (long)m * p.ldc + n), v);
+        if (p.C16) {
+          half4_t h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
+          GEMM_ST((half4_t*)(p.C16 + (long)m * p.ldc16 + n), h);
+        }
+      } else if (m < p.M) {
         const int n = bn0 + ((sl ^ (row & 31)) << 2);
         v = *(const floatx4*)(smem + c * 16);
         if (res_late) {
@@ -343,13 +401,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(GemmArgs p) {
           sm += __shfl_xor(sm, o, 64);
           sq += __shfl_xor(sq, o, 64);
         }
-        if ((c & 31) == 0 && m < p.M) {
+        if ((c & 31) == 0 && (FULL || m < p.M)) {
           float* d = p.st_out + ((long)m * (p.N / BN) + bn0 / BN) * 2;
           d[0] = sm;
           d[1] = sq;
         }
       }
     }
+    };
+    if (G128_FULL_PATH && NW <= 4 && bm0 + TBM <= p.M) copy_out_f32(std::true_type{});
+    else copy_out_f32(std::false_type{});
   } else {
 #pragma unroll
     for (int it = 0; it < PR * 16 / NT; ++it) {
