@@ -1335,6 +1335,9 @@ namespace {
 #ifndef CSAM_UP_PIN
 #define CSAM_UP_PIN 1
 #endif
+#ifndef CSAM_UP_ONE_STORE_BLOCK
+#define CSAM_UP_ONE_STORE_BLOCK 1
+#endif
 constexpr int US_TOK = 32;
 constexpr int US_BUF = US_TOK * 512;               // 16 KB key tile
 constexpr int US_W2S = 2 * US_BUF;                 // W2' 16 KB
@@ -1514,6 +1517,9 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
     }
     // second conv + GELU + hyper product in two halves of its 8 N tiles (= output sub-positions 0,1 then 2,3), so that
     // only 32 accumulator registers are live beside the 128 of the resident W1 slice
+#if CSAM_UP_ONE_STORE_BLOCK
+    floatx4 mres[2][2][US_MG];
+#endif
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
       floatx4 a2[US_MG][4];                             // seeded with the second conv's bias
@@ -1553,15 +1559,35 @@ __global__ __launch_bounds__(256, US_WG_PER_CU) void upscale_stream_kernel(UpArg
           }
           floatx4 m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hhi, ub, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           m4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hlo, ub, m4, 0, 0, 0);
+#if CSAM_UP_ONE_STORE_BLOCK
+          mres[ph][p2][m] = m4;
+#else
           if (fg == 0) {   // rows 0..3 of the product = the 4 mask logits of this pixel
             const int yy = (pos >> 1) * 2 + (pos2 >> 1);
             const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
 #pragma unroll
             for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = m4[l];
           }
+#endif
         }
       }
     }
+#if CSAM_UP_ONE_STORE_BLOCK
+    if (fg == 0) {   // rows 0..3 of each product = the 4 mask logits of a pixel: ONE exec-masked block per tile instead of eight
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+          for (int m = 0; m < US_MG; ++m) {
+            const int pos2 = ph * 2 + p2, mi = g * US_MG + m;
+            const int yy = (pos >> 1) * 2 + (pos2 >> 1);
+            const int X = 4 * (mi * 16 + fr) + 2 * (pos & 1) + (pos2 & 1);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) outs[(l * 4 + yy) * 128 + X] = mres[ph][p2][m][l];
+          }
+    }
+#endif
     }   // g
     // (b) output half-rows complete; also retires the next tile's LDS-DMA (a whole tile old) BEFORE this tile's stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 rounds="${1:-2}"
 out=gpurun_out/lds_ring_ab.txt
 mkdir -p gpurun_out
-OFF="-DFUSE_PM_PIPE=0 -DFUSE_RD_PIPE=0 -DFUSE_GB_DEPTH=0 -DCSAM_UP_PIN=0 -DCSAM_SWAP_REDUCE=0"
+OFF="-DCSAM_UP_ONE_STORE_BLOCK=0 -DFUSE_PM_PIPE=0 -DFUSE_RD_PIPE=0 -DFUSE_GB_DEPTH=0 -DCSAM_UP_PIN=0 -DCSAM_SWAP_REDUCE=0"
 CSAM_BUILD_TAG=old CSAM_EXTRA_FLAGS="-DCSAM_SWAP_REDUCE=0" CSAM_DEFS_decoder_fused="$OFF" CSAM_DEFS_decoder="-DPOOL_RING=0" CSAM_DEFS_gemm_f16="-DG128_READS_FIRST=0 -DG128_FULL_PATH=0 -DG128_HOIST=0 -DG4_RES_AHEAD=1 -DG4_FULL_PATH=0" \
   python -m crowdsam_amd.build > /dev/null 2>&1 || { echo "old-schedule build failed" | tee $out; exit 1; }
 cp crowdsam_amd/libcsam_hip.so /tmp/lib_new.so
