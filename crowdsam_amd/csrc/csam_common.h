@@ -154,6 +154,8 @@ __device__ __forceinline__ float csam_apply_act(float v, int act) {
 // register with a copy of itself leaves (own, partner) in the even 16- / 32-lane groups and (partner, own) in the odd ones; +
 // and max are commutative, so every lane gets the bits the shuffle form gave it.  The results are copied to scalars before the
 // bit cast: __builtin_bit_cast of an ELEMENT of the builtin's vector result reads element 0 (clang; seen in the ISA).
+// (The same idiom -- permlane32_swap(x, x), then op(result.x, result.y) -- is what the vendor's ck_tile fmha v3 pipeline uses on
+// gfx950 for its row maximum and row sum: /opt/rocm/include/ck_tile/ops/fmha/pipeline/block_fmha_fwd_v3_pipeline.hpp.)
 __device__ __forceinline__ void csam_swap32(float v, float& a, float& b) {
   const unsigned u = __builtin_bit_cast(unsigned, v);
   const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
