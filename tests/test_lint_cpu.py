@@ -162,7 +162,7 @@ def test_gemm4w_main_loop_is_up_to_date_and_ordered():
 def test_lds_fragment_rings_are_not_collapsed():
     """tools/lint_lds_ring.py: in the product kernels of the decoder sweep (csam_i2t_t2i both layers, csam_upscale_stream) the
     LDS reads that feed MFMAs are issued a ring ahead of them.  Round 6 found in the ISA that the machine scheduler had sunk every
-    one of them to a single MFMA before its use (119 of 162 LDS-fed MFMAs of the layer-0 kernel waited an LDS round trip); the
+    one of them to a single MFMA before its use (121 of 162 LDS-fed MFMAs of the layer-0 kernel waited an LDS round trip); the
     scheduling barriers of FUSE_PM_PIPE / FUSE_RD_PIPE / CSAM_UP_PIN keep the source order, and this gate notices when a compiler
     update or an edit collapses a ring again."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_lds_ring.py")], capture_output=True, text=True,
